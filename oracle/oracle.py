@@ -1,0 +1,316 @@
+"""ctypes bindings for the CPU oracle (oracle/liboracle.so) and, when present,
+the reference's own compiled sources (oracle/_ref/*.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable only from tests/, bench.py's cpu_baseline
+leg and __graft_entry__.smoke(); the product package dsp_amd never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_F = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_D = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+class MfccCfg(C.Structure):
+    """Mirror of orc_mfcc_cfg (oracle/dsp_oracle.h)."""
+
+    _fields_ = [
+        ("sample_rate", C.c_int), ("n_fft", C.c_int), ("frame_length", C.c_int),
+        ("hop_length", C.c_int), ("n_mels", C.c_int), ("n_mfcc", C.c_int),
+        ("window", C.c_int), ("mel_norm", C.c_int), ("log_mode", C.c_int),
+        ("fft_mode", C.c_int), ("prefilter", C.c_int),
+        ("fmin", C.c_float), ("fmax", C.c_float), ("amin", C.c_float),
+        ("top_db", C.c_float),
+    ]
+
+
+class ClassifyTrace(C.Structure):
+    _fields_ = [("n_midpoints", C.c_int), ("midpoints", C.c_float * 64),
+                ("sums", (C.c_float * 3) * 64)]
+
+
+class SvmModel(C.Structure):
+    _fields_ = [("n_features", C.c_int), ("n_sv", C.c_int), ("gamma", C.c_float),
+                ("rho", C.c_float), ("prob_a", C.c_float), ("prob_b", C.c_float),
+                ("offset", C.POINTER(C.c_float)), ("scale", C.POINTER(C.c_float)),
+                ("sv", C.POINTER(C.c_float)), ("coef", C.POINTER(C.c_float))]
+
+
+WINDOW_HANN, WINDOW_HAMMING, WINDOW_RECT = 0, 1, 2
+MELNORM_NONE, MELNORM_SLANEY = 0, 1
+LOG_PER_FRAME_MAX, LOG_GLOBAL_REF1 = 0, 1
+FFT_REFERENCE_ORDER, FFT_FLOAT64 = 0, 1
+PREFILTER_NONE, PREFILTER_BUTTER_1000_3000, PREFILTER_BUTTER_3000_7500 = 0, 1, 2
+
+
+def build(force: bool = False) -> None:
+    """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "dsp_oracle.c")
+    stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
+    if os.path.isdir(os.environ.get("DSP_REF", "/root/reference")):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        L.orc_mfcc_default_cfg.argtypes = [C.POINTER(MfccCfg)]
+        L.orc_window.argtypes = [C.c_int, C.c_int, _F]
+        L.orc_mel_filterbank.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _F]
+        L.orc_dct_ortho.argtypes = [C.c_int, C.c_int, _F]
+        L.orc_fft_real_forward.argtypes = [_F, C.c_int, C.c_int, C.c_int, _F]
+        L.orc_compute_mfcc.argtypes = [C.POINTER(MfccCfg), _F, C.c_int, _F, C.c_int]
+        L.orc_compute_mfcc.restype = C.c_int
+        L.orc_mfcc_frames.argtypes = [C.POINTER(MfccCfg), _F, C.c_long, _F]
+        L.orc_mfcc_frames_mt.argtypes = [C.POINTER(MfccCfg), _F, C.c_long, _F, C.c_int]
+        L.orc_butter_bandpass.argtypes = [C.c_double, C.c_double, _D, _D]
+        L.orc_butter_bandpass.restype = C.c_int
+        L.orc_iir_df2_f64.argtypes = [_D, C.c_int, _D, _D, _D]
+        L.orc_iir_df2_f32.argtypes = [_F, C.c_int, _F, _F, _F]
+        L.orc_spectrogram_bins.argtypes = [C.c_int]
+        L.orc_spectrogram_bins.restype = C.c_int
+        L.orc_spectrogram_f32.argtypes = [_F, C.c_int, C.c_int, _F, _F, _F]
+        L.orc_spectrogram_f32.restype = C.c_int
+        L.orc_spectrogram_f64.argtypes = [_D, C.c_int, C.c_int, _D, _D, _D]
+        L.orc_spectrogram_f64.restype = C.c_int
+        L.orc_sum_intense.argtypes = [C.c_float, C.c_float, C.c_float, _F, C.c_int, _F, C.c_int, _F, C.c_float]
+        L.orc_sum_intense.restype = C.c_float
+        L.orc_find_midpoints.argtypes = [_F, C.c_int, C.c_int, _F, C.c_int]
+        L.orc_find_midpoints.restype = C.c_int
+        L.orc_classify.argtypes = [_F, C.c_int, C.POINTER(ClassifyTrace)]
+        L.orc_classify.restype = C.c_int
+        L.orc_mfcc_stats.argtypes = [_F, C.c_int, C.c_int, _F]
+        L.orc_svm_predict.argtypes = [C.POINTER(SvmModel), _F, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_svm_predict.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def default_cfg(**over) -> MfccCfg:
+    cfg = MfccCfg()
+    lib().orc_mfcc_default_cfg(C.byref(cfg))
+    for k, v in over.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+# ---- tables ---------------------------------------------------------------
+
+def window(kind: int, n: int) -> np.ndarray:
+    out = np.empty(n, np.float32)
+    lib().orc_window(kind, n, out)
+    return out
+
+
+def mel_filterbank(sr=16000, n_fft=512, n_mels=40, fmin=0.0, fmax=8000.0, norm=MELNORM_NONE) -> np.ndarray:
+    out = np.empty((n_mels, n_fft // 2 + 1), np.float32)
+    lib().orc_mel_filterbank(sr, n_fft, n_mels, fmin, fmax, norm, out)
+    return out
+
+
+def dct_ortho(n_mfcc=13, n_mels=40) -> np.ndarray:
+    out = np.empty((n_mfcc, n_mels), np.float32)
+    lib().orc_dct_ortho(n_mfcc, n_mels, out)
+    return out
+
+
+# ---- MFCC -------------------------------------------------------------------
+
+def fft_real_forward(x: np.ndarray, n_fft=512, fft_mode=FFT_REFERENCE_ORDER) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(2 * n_fft, np.float32)
+    lib().orc_fft_real_forward(x, x.size, n_fft, fft_mode, out)
+    return out
+
+
+def compute_mfcc(signal: np.ndarray, max_frames: int, cfg: MfccCfg | None = None) -> np.ndarray:
+    """orc_compute_mfcc: returns [T][n_mfcc] (T may be 0)."""
+    cfg = cfg or default_cfg()
+    signal = np.ascontiguousarray(signal, np.float32)
+    out = np.zeros((max(max_frames, 0), cfg.n_mfcc), np.float32)
+    t = lib().orc_compute_mfcc(C.byref(cfg), signal, signal.size, out.reshape(-1) if out.size else np.zeros(1, np.float32), max_frames)
+    return out[:t]
+
+
+def mfcc_frames(frames: np.ndarray, cfg: MfccCfg, threads: int = 1) -> np.ndarray:
+    frames = np.ascontiguousarray(frames, np.float32)
+    assert frames.ndim == 2 and frames.shape[1] == cfg.frame_length
+    out = np.empty((frames.shape[0], cfg.n_mfcc), np.float32)
+    if frames.shape[0] == 0:
+        return out
+    if threads > 1:
+        lib().orc_mfcc_frames_mt(C.byref(cfg), frames.reshape(-1), frames.shape[0], out.reshape(-1), threads)
+    else:
+        lib().orc_mfcc_frames(C.byref(cfg), frames.reshape(-1), frames.shape[0], out.reshape(-1))
+    return out
+
+
+# ---- Butterworth ------------------------------------------------------------
+
+def butter_bandpass(lo: float, hi: float):
+    b = np.zeros(9, np.float64)
+    a = np.zeros(9, np.float64)
+    ok = lib().orc_butter_bandpass(lo, hi, b, a)
+    return bool(ok), b, a
+
+
+def iir_f64(x, b, a) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.empty_like(x)
+    lib().orc_iir_df2_f64(x, x.size, np.ascontiguousarray(b, np.float64), np.ascontiguousarray(a, np.float64), y)
+    return y
+
+
+def iir_f32(x, b, a) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().orc_iir_df2_f32(x, x.size, np.ascontiguousarray(b, np.float32), np.ascontiguousarray(a, np.float32), y)
+    return y
+
+
+# ---- spectrogram / classify ---------------------------------------------------
+
+def spectrogram_f32(signal, fs=16000):
+    signal = np.ascontiguousarray(signal, np.float32)
+    t = lib().orc_spectrogram_bins(signal.size)
+    freqs = np.empty(129, np.float32)
+    times = np.empty(max(t, 1), np.float32)
+    sxx = np.empty((129, max(t, 1)), np.float32)
+    lib().orc_spectrogram_f32(signal, signal.size, fs, freqs, times, sxx.reshape(-1))
+    return freqs, times[:t], sxx[:, :t]
+
+
+def spectrogram_f64(signal, fs=16000):
+    signal = np.ascontiguousarray(signal, np.float64)
+    t = lib().orc_spectrogram_bins(signal.size)
+    freqs = np.empty(129, np.float64)
+    times = np.empty(max(t, 1), np.float64)
+    sxx = np.empty((129, max(t, 1)), np.float64)
+    lib().orc_spectrogram_f64(signal, signal.size, fs, freqs, times, sxx.reshape(-1))
+    return freqs, times[:t], sxx[:, :t]
+
+
+def sum_intense(lower, upper, half_range, freqs, times, db, midpoint) -> float:
+    db = np.ascontiguousarray(db, np.float32)
+    return float(lib().orc_sum_intense(lower, upper, half_range, np.ascontiguousarray(freqs, np.float32), db.shape[0],
+                                       np.ascontiguousarray(times, np.float32), db.shape[1], db.reshape(-1), midpoint))
+
+
+def find_midpoints(data, fs=16000) -> np.ndarray:
+    data = np.ascontiguousarray(data, np.float32)
+    out = np.zeros(64, np.float32)
+    n = lib().orc_find_midpoints(data, data.size, fs, out, 64)
+    return out[:n]
+
+
+def classify(data):
+    data = np.ascontiguousarray(data, np.float32)
+    tr = ClassifyTrace()
+    label = lib().orc_classify(data, data.size, C.byref(tr))
+    mids = np.array(tr.midpoints[: tr.n_midpoints], np.float32)
+    sums = np.array([[tr.sums[i][j] for j in range(3)] for i in range(tr.n_midpoints)], np.float32).reshape(-1, 3)
+    return int(label), mids, sums
+
+
+# ---- pooling + SVM ------------------------------------------------------------
+
+def mfcc_stats(mfcc: np.ndarray) -> np.ndarray:
+    mfcc = np.ascontiguousarray(mfcc, np.float32)
+    out = np.empty(2 * mfcc.shape[1], np.float32)
+    lib().orc_mfcc_stats(mfcc.reshape(-1), mfcc.shape[0], mfcc.shape[1], out)
+    return out
+
+
+def svm_predict(model: dict, x: np.ndarray):
+    """model: dict with offset, scale, sv [n_sv][n_f], coef, gamma, rho, prob_a, prob_b."""
+    keep = [np.ascontiguousarray(model[k], np.float32) for k in ("offset", "scale", "sv", "coef")]
+    m = SvmModel()
+    m.n_features = keep[0].size
+    m.n_sv = keep[3].size
+    m.gamma, m.rho = float(model["gamma"]), float(model["rho"])
+    m.prob_a, m.prob_b = float(model["prob_a"]), float(model["prob_b"])
+    m.offset, m.scale, m.sv, m.coef = [k.ctypes.data_as(C.POINTER(C.c_float)) for k in keep]
+    dec, p1 = C.c_float(), C.c_float()
+    label = lib().orc_svm_predict(C.byref(m), np.ascontiguousarray(x, np.float32), C.byref(dec), C.byref(p1))
+    return int(label), float(dec.value), float(p1.value)
+
+
+# ---- the reference itself (only where oracle/_ref was built) -------------------
+
+def have_ref() -> bool:
+    return os.path.exists(os.path.join(_HERE, "_ref", "libref_mfcc.so"))
+
+
+_ref_mfcc = None
+_ref_cls = None
+
+
+def ref_mfcc_lib() -> C.CDLL:
+    global _ref_mfcc
+    if _ref_mfcc is None:
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_mfcc.so"))
+        L.compute_mfcc.argtypes = [_F, C.c_int, _F, C.c_int]
+        L.compute_mfcc.restype = C.c_int
+        L.fft_real_forward.argtypes = [_F, _F]
+        for name in ("ref_hann_window",):
+            getattr(L, name).argtypes = [C.POINTER(C.c_int)]
+            getattr(L, name).restype = C.POINTER(C.c_float)
+        for name in ("ref_mel_filter", "ref_dct_matrix"):
+            getattr(L, name).argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+            getattr(L, name).restype = C.POINTER(C.c_float)
+        _ref_mfcc = L
+    return _ref_mfcc
+
+
+def ref_compute_mfcc(signal: np.ndarray, max_frames: int) -> np.ndarray:
+    signal = np.ascontiguousarray(signal, np.float32)
+    out = np.zeros((max(max_frames, 1), 13), np.float32)
+    t = ref_mfcc_lib().compute_mfcc(signal, signal.size, out.reshape(-1), max_frames)
+    return out[:t]
+
+
+def ref_tables():
+    L = ref_mfcc_lib()
+    n, r, c = C.c_int(), C.c_int(), C.c_int()
+    p = L.ref_hann_window(C.byref(n))
+    hann = np.ctypeslib.as_array(p, (n.value,)).copy()
+    p = L.ref_mel_filter(C.byref(r), C.byref(c))
+    mel = np.ctypeslib.as_array(p, (r.value, c.value)).copy()
+    p = L.ref_dct_matrix(C.byref(r), C.byref(c))
+    dct = np.ctypeslib.as_array(p, (r.value, c.value)).copy()
+    return hann, mel, dct
+
+
+def ref_classifier_lib() -> C.CDLL:
+    global _ref_cls
+    if _ref_cls is None:
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_classifier.so"))
+        L.ref_classify.argtypes = [_F, C.c_int]
+        L.ref_classify.restype = C.c_int
+        L.ref_butter_bandpass.argtypes = [C.c_float, C.c_float, _F, _F]
+        L.ref_butter_bandpass.restype = C.c_int
+        L.ref_butter_bandpass_filter.argtypes = [_F, C.c_int, _F, _F, _F]
+        L.ref_compute_spectrogram.argtypes = [_F, C.c_int, C.c_int, _F, _F, _F]
+        L.ref_compute_spectrogram.restype = C.c_int
+        L.ref_find_midpoints.argtypes = [_F, C.c_int, C.c_int, _F, C.c_int]
+        L.ref_find_midpoints.restype = C.c_int
+        L.ref_sum_intense.argtypes = [C.c_float, C.c_float, C.c_float, _F, C.c_int, _F, C.c_int, _F, C.c_float]
+        L.ref_sum_intense.restype = C.c_float
+        _ref_cls = L
+    return _ref_cls

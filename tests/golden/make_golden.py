@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/*.npz from the reference checkout.
+
+Runs only where /root/reference exists (the build container).  It executes the
+reference's OWN code -- its C sources compiled unmodified into oracle/_ref/ by
+oracle/Makefile -- on seeded / excerpted inputs and stores inputs + outputs as
+small numpy fixtures.  No reference source text is stored, only data:
+inputs (PCM excerpts of the reference's WAV files, seeds), expected outputs,
+and digests of the reference's constant tables.
+
+    python tests/golden/make_golden.py [--ref /root/reference]
+
+Fixtures written (all float32 unless noted):
+  mfcc_ref.npz        compute_mfcc goldens (2fa/audio/word/c/mfcc.c:108)
+  tables_ref.npz      digests of HANN_WINDOW / MEL_FILTER / DCT_MATRIX (mfcc_params.h)
+  iir_kat.npz         donut-classifier/_postbutter.txt excerpt + matching input
+  blobtimes_kat.npz   donut-classifier/_blobtimes.txt + PCM excerpt
+  classifier_ref.npz  butter filter / spectrogram / midpoints / classify goldens
+                      (sync/lib/classifier.cpp)
+  pcm_kat.npz         donut-classifier/data/*.wav.txt PCM16->float dump excerpt
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import sys
+import wave
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+from tests import signals as S  # noqa: E402  (seeded input recipes shared with the tests)
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def read_wav_i16(path):
+    w = wave.open(path)
+    assert w.getsampwidth() == 2
+    d = np.frombuffer(w.readframes(w.getnframes()), np.int16)
+    return d.reshape(-1, w.getnchannels()), w.getframerate()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    ref = args.ref
+    O.build(force=True)
+    assert O.have_ref(), "oracle/_ref not built (reference checkout missing?)"
+
+    # ---- compute_mfcc goldens ------------------------------------------------
+    cases = {}
+    for name, sig in S.mfcc_cases().items():
+        cases[name] = sig
+    bird, sr = read_wav_i16(os.path.join(ref, "sound-processing/birdQ_stereo_16k.wav"))
+    assert sr == 16000 and bird.shape == (24029, 2)
+    stop, sr = read_wav_i16(os.path.join(ref, "2fa/audio/data/testing/stop_121417.wav"))
+    assert sr == 16000 and stop.shape[1] == 1
+    out = {"birdq_pcm": bird.copy(), "stop_pcm": stop[:, 0].copy()}
+    # channel 0 convention: donut-classifier/classifier.c:292-297
+    cases["birdq_ch0"] = (bird[:, 0] / np.float32(32768.0)).astype(np.float32)
+    # stereo average convention: 2fa/audio/word/c/main_test.c:205-217
+    cases["birdq_avg"] = (np.float32(0.5) * (bird[:, 0] / np.float32(32768.0) + bird[:, 1] / np.float32(32768.0))).astype(np.float32)
+    cases["stop_121417"] = (stop[:, 0] / np.float32(32768.0)).astype(np.float32)
+    for name, sig in cases.items():
+        got = O.ref_compute_mfcc(sig, 500)
+        out["mfcc__" + name] = got
+        if name == "chirp":
+            out["input__chirp"] = sig  # np.sin may differ by an ulp across libm builds
+        print(f"mfcc {name:20s} n={sig.size:6d} -> T={got.shape[0]}")
+    # max_frames clamp (mfcc.c:137-139)
+    out["mfcc__noise0_max7"] = O.ref_compute_mfcc(cases["noise0"], 7)
+    # reference fft_real_forward on one frame (mfcc.c:16)
+    spec = np.empty(1024, np.float32)
+    O.ref_mfcc_lib().fft_real_forward(np.ascontiguousarray(cases["noise0"][:400]), spec)
+    out["fft__noise0_frame0"] = spec
+    np.savez_compressed(os.path.join(HERE, "mfcc_ref.npz"), **out)
+
+    # ---- table digests -------------------------------------------------------
+    hann, mel, dct = O.ref_tables()
+    odct = O.dct_ortho(13, 40)
+    mism = np.flatnonzero(odct.reshape(-1) != dct.reshape(-1)).astype(np.int32)
+    np.savez_compressed(
+        os.path.join(HERE, "tables_ref.npz"),
+        hann_sha=sha(hann), mel_sha=sha(mel), dct_sha=sha(dct),
+        mel_nonzero=np.int32((mel != 0).sum()),
+        # the reference DCT was exported with numpy's float32 SIMD cos; glibc cosf
+        # differs by 1 ulp in a few dozen entries: keep those entries so the
+        # oracle table can be checked digest-exact after patching them.
+        dct_mismatch_idx=mism, dct_mismatch_val=dct.reshape(-1)[mism],
+    )
+    print("tables: hann/mel exact =", np.array_equal(O.window(0, 400), hann), np.array_equal(O.mel_filterbank(), mel),
+          " dct 1-ulp entries:", mism.size)
+
+    # ---- IIR known-answer: _postbutter.txt ------------------------------------
+    ctl, sr = read_wav_i16(os.path.join(ref, "donut-classifier/testing/1060-control.wav"))
+    assert sr == 96000
+    n_iir = 8192
+    post = np.loadtxt(os.path.join(ref, "donut-classifier/_postbutter.txt"), max_rows=n_iir)
+    # coefficient block the dump was produced with: donut-classifier/classifier.c:323-341
+    b96 = np.array([0.00021314, 0., -0.00085255, 0., 0.00127883, 0., -0.00085255, 0., 0.00021314])
+    a96 = np.array([1., -7.12847885, 22.41882266, -40.62891245, 46.40780141, -34.21333503, 15.89913237, -4.25840048, 0.50337536])
+    n_blob = 65536
+    np.savez_compressed(os.path.join(HERE, "iir_kat.npz"), pcm=ctl[:n_iir, 0].copy(), b=b96, a=a96, postbutter=post)
+    blob = np.loadtxt(os.path.join(ref, "donut-classifier/_blobtimes.txt"))
+    np.savez_compressed(os.path.join(HERE, "blobtimes_kat.npz"), pcm=ctl[:n_blob, 0].copy(), b=b96, a=a96,
+                        blobtimes=blob, fs=np.int32(96000), threshold_db=np.float64(45.0))
+
+    # ---- classifier goldens ---------------------------------------------------
+    L = O.ref_classifier_lib()
+    cout = {}
+    for lo, hi in ((1000, 3000), (3000, 7500)):
+        b = np.zeros(9, np.float32); a = np.zeros(9, np.float32)
+        assert L.ref_butter_bandpass(lo, hi, b, a) == 1
+        cout[f"b_{lo}_{hi}"] = b; cout[f"a_{lo}_{hi}"] = a
+    b = np.zeros(9, np.float32); a = np.zeros(9, np.float32)
+    cout["bad_band_ok"] = np.int32(L.ref_butter_bandpass(2000, 6000, b, a))
+    ccases = S.classify_cases()
+    ccases["birdq_ch0_1s"] = cases["birdq_ch0"][:16000].copy()
+    for name, sig in ccases.items():
+        sig = np.ascontiguousarray(sig, np.float32)
+        y = np.empty_like(sig)
+        L.ref_butter_bandpass_filter(sig.copy(), sig.size, cout["b_3000_7500"].copy(), cout["a_3000_7500"].copy(), y)
+        T = O.lib().orc_spectrogram_bins(sig.size)
+        fr = np.empty(129, np.float32); tm = np.empty(T, np.float32); sx = np.empty((129, T), np.float32)
+        L.ref_compute_spectrogram(y.copy(), y.size, 16000, fr, tm, sx.reshape(-1))
+        mids = np.zeros(64, np.float32)
+        nm = L.ref_find_midpoints(sig.copy(), sig.size, 16000, mids, 64)
+        label = L.ref_classify(sig.copy(), sig.size)
+        cout[f"{name}__input"] = sig
+        cout[f"{name}__filtered"] = y
+        cout[f"{name}__sxx"] = sx
+        cout[f"{name}__midpoints"] = mids[:nm].copy()
+        cout[f"{name}__label"] = np.int32(label)
+        print(f"classify {name:16s} T={T} midpoints={nm} label={label}")
+    cout["freqs"] = fr; cout["times_16000"] = tm
+    np.savez_compressed(os.path.join(HERE, "classifier_ref.npz"), **cout)
+
+    # ---- PCM16 -> float dump (donut-classifier/classifier.c:64-81) -------------
+    txt = os.path.join(ref, "donut-classifier/data/birdQ_stereo_16k.wav.txt")
+    if os.path.exists(txt):
+        vals = np.array(open(txt).read().split(",")[:4096], dtype=np.float64)  # one comma-separated row, "%f"
+        np.savez_compressed(os.path.join(HERE, "pcm_kat.npz"), pcm=bird[: vals.shape[0]].copy(), dump=vals)
+        print("pcm dump rows:", vals.shape)
+
+
+if __name__ == "__main__":
+    main()
