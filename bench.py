@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- MFCC frames/s on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py                                   # 1 GPU, defaults finish in ~1-2 min
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (window -> 512-pt FFT -> power -> 40 mel ->
+log -> 13-coef DCT-II) over one batch of synthetic frames already resident in HBM:
+BASELINE config 2, 1 M x 512 fp32 frames per GPU.  Frames shard embarrassingly
+over ranks (weak scaling, no data-path collective; --gather adds the RCCL
+all-gather of the per-rank feature blocks, BASELINE config 4's exchange step).
+
+Rank 0 prints ONE JSON line.  `value` = frames all ranks processed / max-over-
+ranks wall time of the K timed steps.  `roofline.achieved` = algorithmic bytes
+per launch (2100 B/frame) / average kernel time measured with HIP events on the
+launch stream.  `cpu_baseline` (rank 0, N=1 only) times the reference's own
+compiled compute_mfcc (oracle/_ref, kind "reference") or, where that is absent,
+the CPU oracle (kind "port") on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FRAME = 512
+N_MFCC = 13
+BYTES_PER_FRAME = FRAME * 4 + N_MFCC * 4      # 2100 algorithmic bytes per frame
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(sample_frames: int, seconds_budget: float = 25.0):
+    """Time the CPU path on this host.  Only bench.py's baseline leg touches oracle/."""
+    import numpy as np
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(7)
+    res = {}
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # (a) the reference's own compute_mfcc (400/160 framing over one long clip: the same
+    #     512-point FFT / 40-mel / 13-coef work per frame), single thread: it keeps
+    #     static scratch (mfcc.c:21-22) and is not re-entrant.
+    if O.have_ref():
+        n = min(sample_frames, 400_000)
+        sig = rng.uniform(-1, 1, 400 + 160 * (n - 1)).astype(np.float32)
+        import ctypes as C
+        L = O.ref_mfcc_lib()
+        out = np.empty((n, 13), np.float32)
+        t0 = time.perf_counter()
+        got = L.compute_mfcc(sig, sig.size, out.reshape(-1), n)
+        dt = time.perf_counter() - t0
+        res = {"value": got / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
+               "sample": f"{got} frames (one {sig.size}-sample clip, frame 400 / hop 160, n_fft 512) through the "
+                         f"reference's compute_mfcc compiled -O2 from its own mfcc.c, {dt:.1f} s"}
+    # (b) the oracle (restatement) on the bench's own frame shape, all host cores
+    cfg = O.default_cfg(frame_length=FRAME, hop_length=FRAME)
+    n = min(sample_frames, 60_000 * max(1, ncpu))
+    fr = rng.uniform(-1, 1, (n, FRAME)).astype(np.float32)
+    t0 = time.perf_counter()
+    O.mfcc_frames(fr, cfg, threads=ncpu)
+    dt = time.perf_counter() - t0
+    port = {"value": n / dt, "unit": "frames/s", "cores": ncpu, "kind": "port",
+            "sample": f"{n} x {FRAME}-sample frames through the CPU oracle on {ncpu} threads, {dt:.1f} s"}
+    if not res:
+        return port
+    res["port_all_cores"] = port
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step")
+    ap.add_argument("--gather", action="store_true", help="all-gather the per-rank features every step (RCCL)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import dsp_amd
+
+    cfg = dsp_amd.default_config(frame_length=FRAME, hop_length=FRAME)   # Hann(512), 512-pt FFT, 40 mel, 13 coef
+    plan = dsp_amd.MfccPlan(cfg, local)
+    if args.blocks_per_cu or args.chunk:
+        plan.set_launch(args.blocks_per_cu, args.chunk)
+
+    n = args.frames
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    frames = torch.rand((n, FRAME), device=dev, generator=gen) * 2 - 1    # synthetic PCM in [-1, 1)
+    out = torch.empty((n, N_MFCC), device=dev)
+    gathered = torch.empty((world * n, N_MFCC), device=dev) if (args.gather and world > 1) else None
+
+    def step():
+        plan.frames(frames, out)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, out)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                       # torch's current stream == the stream plan.frames launches on
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps    # back-to-back launches: avg launch duration
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_frames = world * n * args.steps
+        value = total_frames / elapsed
+        achieved = BYTES_PER_FRAME * n / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "MFCC frames/sec (512-pt FFT, 40 mel, 13 coeffs)",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 1 M synthetic 512-sample fp32 frames per GPU, "
+                                   "Hann(512) -> 512-pt FFT -> 40 HTK mel -> per-frame dB -> 13 DCT-II coeffs, "
+                                   "inputs resident in HBM",
+                       "frames_per_gpu": n, "frame_length": FRAME, "n_fft": 512, "n_mels": 40, "n_mfcc": N_MFCC,
+                       "gather": bool(gathered is not None), "parallelism": f"frames sharded over {world} rank(s)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mfcc512_wave_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_FRAME * n},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(600_000)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,11 @@
+"""dsp_amd -- MI355X-native MFCC / Butterworth / spectrogram hot path of
+cornell-c2s2/dsp behind the reference's C entry points (include/dsp_amd.h).
+
+Python here is plumbing over the C ABI (ctypes) plus torch for HBM buffers,
+streams and torch.distributed; all arithmetic runs in the HIP kernels of
+dsp_amd/csrc.  Importing the package does not need a GPU; calling into it does.
+"""
+from .lib import DspError, MfccConfig, load  # noqa: F401
+from .mfcc import MfccPlan, compute_mfcc, default_config, frames_for, tables  # noqa: F401
+
+__all__ = ["DspError", "MfccConfig", "MfccPlan", "compute_mfcc", "default_config", "frames_for", "tables", "load"]

@@ -1,0 +1,326 @@
+// capi.cpp -- the C ABI of libdsp_amd.so (include/dsp_amd.h).
+//
+// Host side of the drop-in boundary: owns plans (device tables + staging
+// buffers), validates arguments the way the reference does, and enqueues the
+// gfx950 kernels.  No CPU fallback exists: without a HIP device every compute
+// entry point fails and says why through dsp_last_error().
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/dsp_amd.h"
+#include "mfcc_kernels.hpp"
+#include "tables.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define DSP_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(DSP_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+bool valid_cfg(const dsp_mfcc_config &c, std::string &why)
+{
+    if (c.sample_rate <= 0) { why = "sample_rate must be positive"; return false; }
+    if (c.hop_length <= 0) { why = "hop_length must be positive"; return false; }
+    if (c.frame_length & 1) { why = "frame_length must be even (8-byte aligned frame loads)"; return false; }
+    if (c.hop_length & 1) { why = "hop_length must be even (8-byte aligned frame loads)"; return false; }
+    if (!(c.fmax > c.fmin) || c.fmin < 0) { why = "need 0 <= fmin < fmax"; return false; }
+    if (!(c.amin > 0)) { why = "amin must be positive"; return false; }
+    if (c.log_mode != DSP_LOG_PER_FRAME_MAX) { why = "only DSP_LOG_PER_FRAME_MAX is implemented"; return false; }
+    if (c.prefilter != DSP_PREFILTER_NONE) { why = "per-frame prefilter is not implemented yet"; return false; }
+    return true;
+}
+
+}  // namespace
+
+struct dsp_mfcc_plan {
+    dsp_mfcc_config cfg;
+    int device = 0;
+    int n_cu = 0;
+    int blocks_per_cu = 0;   // 0 = default
+    int chunk = 0;           // 0 = default
+    dsp::LaneTables512 host;
+    dsp::LaneTables512 *d_tables = nullptr;
+    // staging for the host-pointer entry points
+    float *d_in = nullptr, *d_out = nullptr;
+    size_t in_cap = 0, out_cap = 0;
+    std::mutex mu;
+};
+
+extern "C" {
+
+const char *dsp_last_error(void) { return g_err.c_str(); }
+const char *dsp_version(void) { return "dsp_amd 0.1 (gfx950)"; }
+
+int dsp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void dsp_mfcc_default_config(dsp_mfcc_config *c)
+{
+    // 2fa/audio/word/c/mfcc_params.h:6-12, mfcc.c:172-173, export_mfcc_params.py:44-57
+    c->sample_rate = 16000;
+    c->n_fft = 512;
+    c->frame_length = 400;
+    c->hop_length = 160;
+    c->n_mels = 40;
+    c->n_mfcc = 13;
+    c->window = DSP_WINDOW_HANN;
+    c->mel_norm = DSP_MELNORM_NONE;
+    c->log_mode = DSP_LOG_PER_FRAME_MAX;
+    c->prefilter = DSP_PREFILTER_NONE;
+    c->fmin = 0.0f;
+    c->fmax = 8000.0f;
+    c->amin = 1e-10f;
+    c->top_db = 80.0f;
+}
+
+int dsp_mfcc_frames_for(const dsp_mfcc_config *cfg, int num_samples, int max_frames)
+{
+    // mfcc.c:117-119, 132-139
+    if (!cfg || num_samples < cfg->frame_length || max_frames <= 0) return 0;
+    const int t = 1 + (num_samples - cfg->frame_length) / cfg->hop_length;
+    return std::min(t, max_frames);
+}
+
+int dsp_mfcc_tables(const dsp_mfcc_config *cfg, float *window, float *mel, float *dct)
+{
+    if (!cfg) return fail(DSP_EINVAL, "cfg is NULL");
+    if (window) {
+        auto w = dsp::make_window(cfg->window, cfg->frame_length);
+        std::memcpy(window, w.data(), w.size() * sizeof(float));
+    }
+    if (mel) {
+        auto m = dsp::make_mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin, cfg->fmax, cfg->mel_norm);
+        std::memcpy(mel, m.data(), m.size() * sizeof(float));
+    }
+    if (dct) {
+        auto d = dsp::make_dct_ortho(cfg->n_mfcc, cfg->n_mels);
+        std::memcpy(dct, d.data(), d.size() * sizeof(float));
+    }
+    return DSP_OK;
+}
+
+int dsp_butter_bandpass(double lowcut, double highcut, double *b, double *a)
+{
+    // donut-classifier/classifier.c:342-360, 383-401: the 16 kHz literal tables
+    static const double B1[9] = {0.01020948, 0., -0.04083792, 0., 0.06125688, 0., -0.04083792, 0., 0.01020948};
+    static const double A1[9] = {1., -4.56803686, 9.95922498, -13.49912589, 12.43979269, -7.94997696, 3.43760562, -0.92305481, 0.1203896};
+    static const double B2[9] = {0.1362017, 0., -0.5448068, 0., 0.8172102, 0., -0.5448068, 0., 0.1362017};
+    static const double A2[9] = {1., 2.60935592, 2.32553038, 1.20262614, 1.11690211, 0.76154474, 0.10005124, -0.0129829, 0.02236815};
+    const double *sb, *sa;
+    if (lowcut == 1000 && highcut == 3000) { sb = B1; sa = A1; }
+    else if (lowcut == 3000 && highcut == 7500) { sb = B2; sa = A2; }
+    else { fail(DSP_EINVAL, "invalid bandpass range"); return 0; }   // classifier.c:402-407
+    std::memcpy(b, sb, sizeof(B1));
+    std::memcpy(a, sa, sizeof(A1));
+    return 1;
+}
+
+int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan **out)
+{
+    if (!cfg || !out) return fail(DSP_EINVAL, "cfg/out is NULL");
+    *out = nullptr;
+    std::string why;
+    if (!valid_cfg(*cfg, why)) return fail(DSP_EINVAL, why);
+    auto *p = new dsp_mfcc_plan;
+    p->cfg = *cfg;
+    if (!dsp::build_lane_tables_512(*cfg, p->host, why)) { delete p; return fail(DSP_EINVAL, why); }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { delete p; return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback"); }
+    if (device < 0 || device >= n) { delete p; return fail(DSP_EINVAL, "device index out of range"); }
+    p->device = device;
+    hipError_t e = hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) e = hipMalloc(&p->d_tables, sizeof(dsp::LaneTables512));
+    if (e == hipSuccess) e = hipMemcpy(p->d_tables, &p->host, sizeof(dsp::LaneTables512), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (p->d_tables) hipFree(p->d_tables);
+        delete p;
+        return fail(DSP_EHIP, std::string("plan_create: ") + hipGetErrorString(e));
+    }
+    p->n_cu = prop.multiProcessorCount;
+    *out = p;
+    return DSP_OK;
+}
+
+void dsp_mfcc_plan_destroy(dsp_mfcc_plan *p)
+{
+    if (!p) return;
+    hipSetDevice(p->device);
+    if (p->d_tables) hipFree(p->d_tables);
+    if (p->d_in) hipFree(p->d_in);
+    if (p->d_out) hipFree(p->d_out);
+    delete p;
+}
+
+int dsp_mfcc_plan_config(const dsp_mfcc_plan *p, dsp_mfcc_config *cfg)
+{
+    if (!p || !cfg) return fail(DSP_EINVAL, "plan/cfg is NULL");
+    *cfg = p->cfg;
+    return DSP_OK;
+}
+
+int dsp_mfcc_plan_set_launch(dsp_mfcc_plan *p, int blocks_per_cu, int frames_per_chunk)
+{
+    if (!p || blocks_per_cu < 0 || frames_per_chunk < 0) return fail(DSP_EINVAL, "bad launch knobs");
+    p->blocks_per_cu = blocks_per_cu;
+    p->chunk = frames_per_chunk;
+    return DSP_OK;
+}
+
+static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames, int frames_per_clip,
+               long clip_stride, void *stream)
+{
+    if (n_frames == 0) return DSP_OK;
+    if ((reinterpret_cast<uintptr_t>(d_in) & 7) || (clip_stride & 1))
+        return fail(DSP_EINVAL, "input must be 8-byte aligned with an even clip stride");
+    dsp::Mfcc512Args a;
+    a.in = d_in;
+    a.out = d_out;
+    a.tables = p->d_tables;
+    a.n_frames = n_frames;
+    a.clip_stride = clip_stride;
+    a.frames_per_clip = frames_per_clip;
+    a.hop = p->cfg.hop_length;
+    a.frame_len = p->cfg.frame_length;
+    a.chunk = p->chunk > 0 ? p->chunk : 32;
+    a.n_mels = p->cfg.n_mels;
+    a.n_mfcc = p->cfg.n_mfcc;
+    a.amin = p->cfg.amin;
+    a.top_db = p->cfg.top_db;
+    // persistent-style grid: enough 4-wave blocks to fill every CU, never more
+    // blocks than there are chunks of work
+    const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : 4;
+    long blocks = (long)p->n_cu * per_cu;
+    const long chunks = (n_frames + a.chunk - 1) / a.chunk;
+    blocks = std::max(1L, std::min(blocks, (chunks + 3) / 4));
+    DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, (int)blocks, (hipStream_t)stream));
+    return DSP_OK;
+}
+
+int dsp_mfcc_frames_device(dsp_mfcc_plan *p, const float *d_frames, long n_frames, float *d_out, void *stream)
+{
+    if (!p || n_frames < 0 || (n_frames > 0 && (!d_frames || !d_out))) return fail(DSP_EINVAL, "bad argument");
+    return run(p, d_frames, d_out, n_frames, 0, 0, stream);
+}
+
+int dsp_mfcc_clips_device(dsp_mfcc_plan *p, const float *d_signal, long n_clips, int samples_per_clip,
+                          long clip_stride, float *d_out, int max_frames, void *stream)
+{
+    if (!p || n_clips < 0) return fail(DSP_EINVAL, "bad argument");
+    const int t = dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
+    if (t == 0 || n_clips == 0) return 0;
+    if (!d_signal || !d_out) return fail(DSP_EINVAL, "NULL buffer");
+    if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
+    const int rc = run(p, d_signal, d_out, n_clips * (long)t, t, clip_stride, stream);
+    return rc < 0 ? rc : t;
+}
+
+static int reserve(float **buf, size_t *cap, size_t need)
+{
+    if (*cap >= need) return DSP_OK;
+    if (*buf) { hipFree(*buf); *buf = nullptr; *cap = 0; }
+    DSP_HIP(hipMalloc(buf, need));
+    *cap = need;
+    return DSP_OK;
+}
+
+int dsp_mfcc_frames_host(dsp_mfcc_plan *p, const float *frames, long n_frames, float *out)
+{
+    if (!p || n_frames < 0 || (n_frames > 0 && (!frames || !out))) return fail(DSP_EINVAL, "bad argument");
+    if (n_frames == 0) return DSP_OK;
+    std::lock_guard<std::mutex> lock(p->mu);
+    DSP_HIP(hipSetDevice(p->device));
+    const size_t in_b = (size_t)n_frames * p->cfg.frame_length * sizeof(float);
+    const size_t out_b = (size_t)n_frames * p->cfg.n_mfcc * sizeof(float);
+    int rc;
+    if ((rc = reserve(&p->d_in, &p->in_cap, in_b)) < 0) return rc;
+    if ((rc = reserve(&p->d_out, &p->out_cap, out_b)) < 0) return rc;
+    DSP_HIP(hipMemcpyAsync(p->d_in, frames, in_b, hipMemcpyHostToDevice, nullptr));
+    if ((rc = run(p, p->d_in, p->d_out, n_frames, 0, 0, nullptr)) < 0) return rc;
+    DSP_HIP(hipMemcpyAsync(out, p->d_out, out_b, hipMemcpyDeviceToHost, nullptr));
+    DSP_HIP(hipStreamSynchronize(nullptr));
+    return DSP_OK;
+}
+
+int dsp_mfcc_clips_host(dsp_mfcc_plan *p, const float *signal, long n_clips, int samples_per_clip,
+                        long clip_stride, float *out, int max_frames)
+{
+    if (!p || n_clips < 0) return fail(DSP_EINVAL, "bad argument");
+    const int t = dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
+    if (t == 0 || n_clips == 0) return 0;
+    if (!signal || !out) return fail(DSP_EINVAL, "NULL buffer");
+    if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
+    std::lock_guard<std::mutex> lock(p->mu);
+    DSP_HIP(hipSetDevice(p->device));
+    // device copy is packed with an even stride so every frame start stays 8-byte aligned
+    const long dstride = samples_per_clip + (samples_per_clip & 1);
+    const size_t in_b = (size_t)n_clips * dstride * sizeof(float);
+    const size_t out_b = (size_t)n_clips * t * p->cfg.n_mfcc * sizeof(float);
+    int rc;
+    if ((rc = reserve(&p->d_in, &p->in_cap, in_b)) < 0) return rc;
+    if ((rc = reserve(&p->d_out, &p->out_cap, out_b)) < 0) return rc;
+    DSP_HIP(hipMemcpy2DAsync(p->d_in, dstride * sizeof(float), signal, clip_stride * sizeof(float),
+                             (size_t)samples_per_clip * sizeof(float), (size_t)n_clips, hipMemcpyHostToDevice, nullptr));
+    if ((rc = run(p, p->d_in, p->d_out, n_clips * (long)t, t, dstride, nullptr)) < 0) return rc;
+    DSP_HIP(hipMemcpyAsync(out, p->d_out, out_b, hipMemcpyDeviceToHost, nullptr));
+    DSP_HIP(hipStreamSynchronize(nullptr));
+    return t;
+}
+
+// ---- the reference's entry point ------------------------------------------------
+
+static dsp_mfcc_plan *g_default_plan = nullptr;
+static std::mutex g_default_mu;
+
+// 2fa/audio/word/c/mfcc.h:16-19.  Same contract as the reference: returns the
+// frame count, 0 for "clip too short / no room"; a GPU failure also returns 0
+// (no frames were produced) with the cause in dsp_last_error().
+int compute_mfcc(const float *signal, int num_samples, float *out_mfcc, int max_frames)
+{
+    dsp_mfcc_config cfg;
+    dsp_mfcc_default_config(&cfg);
+    if (dsp_mfcc_frames_for(&cfg, num_samples, max_frames) == 0) return 0;   // mfcc.c:117-119
+    if (!signal || !out_mfcc) { fail(DSP_EINVAL, "NULL buffer"); return 0; }
+    dsp_mfcc_plan *plan;
+    {
+        std::lock_guard<std::mutex> lock(g_default_mu);
+        if (!g_default_plan) {
+            const char *dev = std::getenv("DSP_AMD_DEVICE");
+            if (dsp_mfcc_plan_create(&cfg, dev ? std::atoi(dev) : 0, &g_default_plan) < 0) {
+                std::fprintf(stderr, "libdsp_amd: compute_mfcc: %s\n", dsp_last_error());
+                return 0;
+            }
+        }
+        plan = g_default_plan;
+    }
+    const int t = dsp_mfcc_clips_host(plan, signal, 1, num_samples, num_samples, out_mfcc, max_frames);
+    if (t < 0) {
+        std::fprintf(stderr, "libdsp_amd: compute_mfcc: %s\n", dsp_last_error());
+        return 0;
+    }
+    return t;
+}
+
+}  // extern "C"

@@ -1,0 +1,361 @@
+// mfcc_kernels.hip -- gfx950 (MI355X, CDNA4) MFCC kernels.
+//
+// One 64-lane wavefront owns one 512-sample audio frame from the HBM load to the
+// 13 cepstral coefficients; nothing but the input frame and the coefficients
+// touches HBM.  Per frame (reference chain: 2fa/audio/word/c/mfcc.c:142-221):
+//
+//   load      4 x global_load_dwordx2 per lane: z[l+64a] = x[2n] + i x[2n+1]
+//   window    8 v_mul (window pre-scaled by 1/2, tables.cpp)           mfcc.c:142-144
+//   FFT       512-point real FFT as a 256-point complex radix-4 DIF:    mfcc.c:16-95
+//             stage 1 in registers; exchange 1 = v_permlane32/16_swap;
+//             exchanges 2,3 through a 2 KiB per-wave LDS tile with XOR
+//             swizzles (bank-conflict free, tools/emulate_wave_fft.py)
+//   untangle  conjugate-pair split with ds_bpermute from lane 64-l      (packed real FFT)
+//   power     |X[k]|^2, k = 0..256                                     mfcc.c:151-155
+//   mel       sparse HTK triangles: <= 12 bins per lane + 3-way gather  mfcc.c:158-164
+//   log       per-frame ref = max, amin, top_db (v_log_f32)            mfcc.c:169-206
+//   DCT-II    4 lanes per coefficient, quad DPP reduce                 mfcc.c:210-216
+//   store     n_mfcc floats per frame                                  mfcc.c:219-221
+//
+// No MFMA: a 512-point FFT and a 494-non-zero mel product are not dense
+// contractions.  The bound is HBM (2048 B in + 52 B out per frame).
+#include <hip/hip_runtime.h>
+
+#include "mfcc_kernels.hpp"
+
+namespace dsp {
+
+namespace {
+
+struct c32 { float x, y; };
+
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ c32 cmul(c32 a, c32 w) { return {a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+// multiply by -i
+__device__ __forceinline__ c32 cmul_mi(c32 a) { return {a.y, -a.x}; }
+
+// forward radix-4 butterfly, W4 = -i
+__device__ __forceinline__ void radix4(c32 (&s)[4])
+{
+    const c32 t0 = cadd(s[0], s[2]), t1 = csub(s[0], s[2]);
+    const c32 t2 = cadd(s[1], s[3]), t3 = cmul_mi(csub(s[1], s[3]));
+    s[0] = cadd(t0, t2);
+    s[1] = cadd(t1, t3);
+    s[2] = csub(t0, t2);
+    s[3] = csub(t1, t3);
+}
+
+// Orders this wave's LDS traffic for the compiler.  The hardware executes one
+// wave's DS instructions in order, so no s_barrier / waitcnt is needed between a
+// ds_write and a ds_read of another lane's data inside the same wave.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void swap_hi32(float &a, float &b)
+{   // a[lanes 32..63] <-> b[lanes 0..31]
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_odd16(float &a, float &b)
+{   // a[odd 16-lane rows] <-> b[even 16-lane rows]
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_QUAD_1032 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_2301 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+__device__ __forceinline__ float wave_max(float v)
+{
+    v = fmaxf(v, dpp<DPP_QUAD_1032>(v));
+    v = fmaxf(v, dpp<DPP_QUAD_2301>(v));
+    v = fmaxf(v, dpp<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp<DPP_ROW_MIRROR>(v));           // every lane: max of its 16-lane row
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// per-wave LDS carve (bytes)
+constexpr int LDS_XCHG = 0;                 // 256 x float2 exchange tile, later P[0..256] (+pad)
+constexpr int LDS_PART = 2048 + 64;         // 65 partial sums (+ zero slot), after P[256] spill room
+constexpr int LDS_LOGMEL = LDS_PART + 320;  // up to 80 log-mel values
+constexpr int LDS_WAVE_BYTES = LDS_LOGMEL + 320;
+static_assert(LDS_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
+
+// wave-uniform cursor over the frames this wave owns: chunks of `chunk`
+// consecutive frames dealt round-robin to the waves of the grid, so one wave's
+// 52-byte outputs land in consecutive cache lines.
+struct FrameCursor {
+    long f, chunk_end, chunk_first, stride, n;
+    long clip;      // clip mode: f = clip * fpc + t
+    int t, fpc, chunk;
+    __device__ __forceinline__ void locate()
+    {
+        chunk_end = f + chunk < n ? f + chunk : n;
+        if (fpc > 0 && f < n) { clip = f / fpc; t = (int)(f - clip * fpc); }
+    }
+    __device__ __forceinline__ void init(long wave, long n_waves, int chunk_, long n_, int fpc_)
+    {
+        chunk = chunk_; n = n_; fpc = fpc_; clip = 0; t = 0;
+        stride = n_waves * chunk;
+        chunk_first = wave * chunk;
+        f = chunk_first;
+        locate();
+    }
+    __device__ __forceinline__ bool valid() const { return f < n; }
+    __device__ __forceinline__ void next()
+    {
+        if (++f >= chunk_end) {           // one 64-bit divide per chunk, not per frame
+            chunk_first += stride;
+            f = chunk_first;
+            locate();
+        } else if (++t == fpc) {
+            t = 0; ++clip;
+        }
+    }
+};
+
+template <bool FULL>
+__device__ __forceinline__ void load_frame(const float *__restrict__ src, int lane, int frame_len, c32 (&z)[4])
+{
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = 2 * (lane + 64 * a);
+        if (FULL || i + 1 < frame_len) {
+            const float2 v = *reinterpret_cast<const float2 *>(src + i);
+            z[a] = {v.x, v.y};
+        } else if (i < frame_len) {
+            z[a] = {src[i], 0.0f};
+        } else {
+            z[a] = {0.0f, 0.0f};
+        }
+    }
+}
+
+}  // namespace
+
+// DCT_SPLIT lanes per coefficient, DCT_LEN log-mel values per lane.
+// FULL: frame_length == 512 (no tail predicate on the loads).
+template <int DCT_SPLIT, int DCT_LEN, bool FULL>
+__global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args args)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *wl = smem + wib * LDS_WAVE_BYTES;
+    float2 *xchg = reinterpret_cast<float2 *>(wl + LDS_XCHG);
+    float *pbuf = reinterpret_cast<float *>(wl + LDS_XCHG);
+    float *part = reinterpret_cast<float *>(wl + LDS_PART);
+    float *lmel = reinterpret_cast<float *>(wl + LDS_LOGMEL);
+
+    const LaneTables512 *__restrict__ T = args.tables;
+
+    // ---- per-lane constants (one coalesced dword per field) -----------------
+    float win[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) win[i] = T->win[i][lane];
+    c32 tw1[3], tw2[3], tw3[3], twp[2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        tw1[q] = {T->tw1[2 * q][lane], T->tw1[2 * q + 1][lane]};
+        tw2[q] = {T->tw2[2 * q][lane], T->tw2[2 * q + 1][lane]};
+        tw3[q] = {T->tw3[2 * q][lane], T->tw3[2 * q + 1][lane]};
+    }
+    twp[0] = {T->twp[0][lane], T->twp[1][lane]};
+    twp[1] = {T->twp[2][lane], T->twp[3][lane]};
+    float melw[kMelChunk];
+#pragma unroll
+    for (int i = 0; i < kMelChunk; ++i) melw[i] = T->mel_w[i][lane];
+    const float *mel_rd = pbuf + T->mel_k0[lane];
+    const float *gat0 = part + T->mel_src[0][lane];
+    const float *gat1 = part + T->mel_src[1][lane];
+    const float *gat2 = part + T->mel_src[2][lane];
+    float dctw[DCT_LEN];
+#pragma unroll
+    for (int i = 0; i < DCT_LEN; ++i) dctw[i] = T->dct_w[i][lane];
+    const int n_mels = args.n_mels, n_mfcc = args.n_mfcc;
+    const float *dct_rd = lmel + (lane % DCT_SPLIT) * DCT_LEN;
+    const int dct_c = lane / DCT_SPLIT;
+    const bool dct_store = (lane % DCT_SPLIT == 0) && dct_c < n_mfcc;
+
+    // exchange addresses (float2 units), see tools/emulate_wave_fft.py
+    //   A2(beta,p,r=4c+d) = 64p + 16beta + 4(c^p) + d : writer lane (beta,c,d) slot p, reader lane (beta,p,d) slot c
+    //   A3(beta,p,o,d)    = 64beta + 16o + 4(d^beta) + p : writer lane (beta,p,d) slot o, reader lane (o,p,beta) slot d
+    const int d0 = lane & 3, d1 = (lane >> 2) & 3, d2 = lane >> 4;
+    const int w3base = 64 * d2 + 4 * (d0 ^ d2) + d1;        // + 16 o
+    const int r3base = 64 * d0 + 16 * d2 + d1;              // + 4 (d ^ beta),  beta = d0
+    const int partner = ((64 - lane) & 63) << 2;
+
+    // zero the slots that are only ever read
+    if (lane == 0) part[kZeroSlot] = 0.0f;
+    if (lane < 16) lmel[64 + lane] = 0.0f;
+    if (lane < 64) lmel[lane] = 0.0f;
+    wave_lds_sync();
+
+    const long wave = (long)blockIdx.x * 4 + wib;
+    const long n_waves = (long)gridDim.x * 4;
+    FrameCursor cur;
+    cur.init(wave, n_waves, args.chunk, args.n_frames, args.frames_per_clip);
+    if (!cur.valid()) return;
+
+    const float amin = args.amin;
+    const float neg_top_db = -args.top_db;
+    const int frame_len = args.frame_len;
+
+    auto frame_src = [&]() -> const float * {
+        if (args.frames_per_clip <= 0) return args.in + cur.f * (long)frame_len;
+        return args.in + cur.clip * args.clip_stride + (long)cur.t * args.hop;
+    };
+
+    c32 nxt[4];
+    load_frame<FULL>(frame_src(), lane, frame_len, nxt);
+
+    while (true) {
+        const long f = cur.f;
+        c32 s[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s[a] = {nxt[a].x * win[2 * a], nxt[a].y * win[2 * a + 1]};
+        cur.next();
+        const bool more = cur.valid();
+        if (more) load_frame<FULL>(frame_src(), lane, frame_len, nxt);   // prefetch, hidden by the FFT below
+
+        // ---- 256-point complex FFT, radix-4 DIF --------------------------------
+        radix4(s);                                          // digit a (bits 7:6)
+#pragma unroll
+        for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw1[q - 1]);
+        // exchange 1: slot <-> lane bits 5:4, in registers
+        swap_hi32(s[0].x, s[2].x); swap_hi32(s[0].y, s[2].y);
+        swap_hi32(s[1].x, s[3].x); swap_hi32(s[1].y, s[3].y);
+        swap_odd16(s[0].x, s[1].x); swap_odd16(s[0].y, s[1].y);
+        swap_odd16(s[2].x, s[3].x); swap_odd16(s[2].y, s[3].y);
+        radix4(s);                                          // digit b (bits 5:4)
+#pragma unroll
+        for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw2[q - 1]);
+        // exchange 2: slot <-> lane bits 3:2, through LDS
+#pragma unroll
+        for (int p = 0; p < 4; ++p) xchg[(lane ^ (4 * p)) + 64 * p] = {s[p].x, s[p].y};
+        wave_lds_sync();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float2 v = xchg[64 * d1 + 16 * d2 + 4 * (c ^ d1) + d0];
+            s[c] = {v.x, v.y};
+        }
+        wave_lds_sync();
+        radix4(s);                                          // digit c (bits 3:2)
+#pragma unroll
+        for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw3[q - 1]);
+        // exchange 3: slot <-> lane bits 1:0, through LDS; reader lane = k mod 64
+#pragma unroll
+        for (int o = 0; o < 4; ++o) xchg[w3base + 16 * o] = {s[o].x, s[o].y};
+        wave_lds_sync();
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const float2 v = xchg[r3base + 4 * (dd ^ d0)];
+            s[dd] = {v.x, v.y};
+        }
+        wave_lds_sync();
+        radix4(s);                                          // digit d: s[t] = Z[lane + 64 t] / 2
+
+        // ---- packed-real untangling + power spectrum -------------------------
+        // lane l pairs Z[l] with Z[256-l] and Z[l+64] with Z[192-l]; both partners
+        // live in lane 64-l (slots 3 and 2).  Lane 0 pairs inside itself.
+        c32 b, d;
+        b.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[3].x)));
+        b.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[3].y)));
+        d.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[2].x)));
+        d.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[2].y)));
+        if (lane == 0) { b = s[0]; d = s[3]; }
+        float P[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const c32 u = s[h], v = h == 0 ? b : d;
+            const c32 E = {u.x + v.x, u.y - v.y};           // Z[k] + conj(Z[N-k])
+            const c32 O = {u.x - v.x, u.y + v.y};           // Z[k] - conj(Z[N-k])
+            const c32 Tw = cmul(O, twp[h]);                 // W512^k * O
+            const float xr = E.x + Tw.y, xi = E.y - Tw.x;   // X[k]
+            const float mr = E.x - Tw.y, mi = E.y + Tw.x;   // X[256-k] (conjugated)
+            P[2 * h] = xr * xr + xi * xi;
+            P[2 * h + 1] = mr * mr + mi * mi;
+        }
+        const float p128 = 4.0f * (s[2].x * s[2].x + s[2].y * s[2].y);   // lane 0: |Z[128]|^2 un-halved
+        pbuf[lane] = P[0];
+        pbuf[256 - lane] = P[1];
+        pbuf[64 + lane] = P[2];
+        pbuf[192 - lane] = P[3];
+        if (lane == 0) pbuf[128] = p128;
+        wave_lds_sync();
+
+        // ---- sparse mel filterbank -------------------------------------------
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kMelChunk; ++i) acc = fmaf(melw[i], mel_rd[i], acc);
+        part[lane] = acc;
+        wave_lds_sync();
+        float e = (*gat0 + *gat1) + *gat2;
+        if (lane >= n_mels) e = 0.0f;
+
+        // ---- 10 log10 with per-frame reference (mfcc.c:169-206) ---------------
+        const float ref = fmaxf(wave_max(e), amin);
+        const float k10 = 3.01029995663981195f;            // 10 * log10(2)
+        float db = k10 * (__builtin_amdgcn_logf(fmaxf(e, amin)) - __builtin_amdgcn_logf(ref));
+        db = fmaxf(db, neg_top_db);                         // max over the frame is exactly 0
+        if (lane < n_mels) lmel[lane] = db;
+        wave_lds_sync();
+
+        // ---- DCT-II ------------------------------------------------------------
+        float c = 0.0f;
+#pragma unroll
+        for (int i = 0; i < DCT_LEN; i += 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(dct_rd + i);
+            c = fmaf(dctw[i], v.x, c);
+            c = fmaf(dctw[i + 1], v.y, c);
+        }
+        c += dpp<DPP_QUAD_1032>(c);
+        if (DCT_SPLIT == 4) c += dpp<DPP_QUAD_2301>(c);
+        if (dct_store) args.out[f * n_mfcc + dct_c] = c;
+        wave_lds_sync();
+
+        if (!more) break;
+    }
+}
+
+// -----------------------------------------------------------------------------
+
+hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int blocks,
+                          hipStream_t stream)
+{
+    const bool full = args.frame_len == 512;
+    const size_t lds = 4 * (size_t)LDS_WAVE_BYTES;
+#define DSP_LAUNCH(S, L)                                                                      \
+    do {                                                                                      \
+        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, true>), dim3(blocks), dim3(256), lds, stream, args);  \
+        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, false>), dim3(blocks), dim3(256), lds, stream, args); \
+        return hipGetLastError();                                                             \
+    } while (0)
+    if (dct_split == 4 && dct_len == 10) DSP_LAUNCH(4, 10);
+    if (dct_split == 4 && dct_len == 16) DSP_LAUNCH(4, 16);
+    if (dct_split == 2 && dct_len == 20) DSP_LAUNCH(2, 20);
+#undef DSP_LAUNCH
+    return hipErrorInvalidConfiguration;
+}
+
+int mfcc512_lds_bytes_per_block() { return 4 * LDS_WAVE_BYTES; }
+
+}  // namespace dsp

@@ -1,0 +1,28 @@
+// mfcc_kernels.hpp -- launch interface of mfcc_kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include "tables.hpp"
+
+namespace dsp {
+
+struct Mfcc512Args {
+    const float *in;               // HBM: frames or clips
+    float *out;                    // HBM: [n_frames][n_mfcc]
+    const LaneTables512 *tables;   // HBM: per-lane constants
+    long n_frames;                 // total frames over all clips
+    long clip_stride;              // floats between clip starts (clip mode)
+    int frames_per_clip;           // 0: independent frames back to back
+    int hop;                       // clip mode: floats between frame starts
+    int frame_len;                 // <= 512
+    int chunk;                     // consecutive frames one wave takes at a time
+    int n_mels, n_mfcc;
+    float amin, top_db;
+};
+
+hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int blocks,
+                          hipStream_t stream);
+int mfcc512_lds_bytes_per_block();
+
+}  // namespace dsp

@@ -1,0 +1,165 @@
+// tables.cpp -- see tables.hpp.
+#include "tables.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace dsp {
+
+static const double kPi = 3.14159265358979323846;
+
+// scipy.signal.get_window(name, n, fftbins=True) (export_mfcc_params.py:46):
+// periodic form, float64 evaluation, one rounding to float32.
+std::vector<float> make_window(int kind, int n)
+{
+    std::vector<float> w(n);
+    for (int i = 0; i < n; ++i) {
+        const double ph = 2.0 * kPi * i / n;
+        double v = 1.0;
+        if (kind == DSP_WINDOW_HANN) v = 0.5 - 0.5 * std::cos(ph);
+        else if (kind == DSP_WINDOW_HAMMING) v = 0.54 - 0.46 * std::cos(ph);
+        w[i] = (float)v;
+    }
+    return w;
+}
+
+// librosa.filters.mel(htk=True, norm=None|'slaney') (export_mfcc_params.py:49-57).
+std::vector<float> make_mel_filterbank(int sample_rate, int n_fft, int n_mels, float fmin,
+                                       float fmax, int mel_norm)
+{
+    const int n_bins = n_fft / 2 + 1;
+    auto to_mel = [](double hz) { return 2595.0 * std::log10(1.0 + hz / 700.0); };
+    auto to_hz = [](double mel) { return 700.0 * (std::pow(10.0, mel / 2595.0) - 1.0); };
+    std::vector<double> edge(n_mels + 2);
+    const double lo = to_mel(fmin), hi = to_mel(fmax);
+    const double step = (hi - lo) / (n_mels + 1);
+    for (int i = 0; i < n_mels + 2; ++i) edge[i] = to_hz(i == n_mels + 1 ? hi : lo + i * step);
+    const double bin_hz = 0.5 * sample_rate / (n_bins - 1);
+    std::vector<float> fb((size_t)n_mels * n_bins);
+    for (int m = 0; m < n_mels; ++m) {
+        const double rise = edge[m + 1] - edge[m], fall = edge[m + 2] - edge[m + 1];
+        const double area = mel_norm == DSP_MELNORM_SLANEY ? 2.0 / (edge[m + 2] - edge[m]) : 1.0;
+        for (int k = 0; k < n_bins; ++k) {
+            const double f = (k == n_bins - 1) ? 0.5 * sample_rate : k * bin_hz;
+            double w = std::min((f - edge[m]) / rise, (edge[m + 2] - f) / fall);
+            if (!(w > 0.0)) w = 0.0;
+            float wf = (float)w;
+            if (mel_norm == DSP_MELNORM_SLANEY) wf = (float)((double)wf * area);
+            fb[(size_t)m * n_bins + k] = wf;
+        }
+    }
+    return fb;
+}
+
+// Orthonormal DCT-II rows, float32 argument like the exporter (export_mfcc_params.py:27-41).
+std::vector<float> make_dct_ortho(int n_mfcc, int n_mels)
+{
+    std::vector<float> d((size_t)n_mfcc * n_mels);
+    const float pif = (float)kPi;
+    const double s0 = std::sqrt(1.0 / n_mels), s1 = std::sqrt(2.0 / n_mels);
+    for (int k = 0; k < n_mfcc; ++k)
+        for (int m = 0; m < n_mels; ++m) {
+            if (k == 0) { d[m] = (float)s0; continue; }
+            float arg = pif * ((float)m + 0.5f);
+            arg *= (float)k;
+            arg /= (float)n_mels;
+            d[(size_t)k * n_mels + m] = (float)(s1 * (double)std::cos(arg));
+        }
+    return d;
+}
+
+static void unit(double turns, float &c, float &s)
+{
+    // exp(-2*pi*i*turns), evaluated in float64
+    c = (float)std::cos(-2.0 * kPi * turns);
+    s = (float)std::sin(-2.0 * kPi * turns);
+}
+
+bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::string &why)
+{
+    std::memset(&t, 0, sizeof(t));
+    const int n_fft = 512, n_bins = 257;
+    if (cfg.n_fft != n_fft) { why = "n_fft must be 512 for this kernel"; return false; }
+    if (cfg.frame_length < 2 || cfg.frame_length > n_fft) { why = "frame_length must be in [2, n_fft]"; return false; }
+    if (cfg.n_mels < 1 || cfg.n_mels > kLanes) { why = "n_mels must be in [1, 64]"; return false; }
+    if (cfg.n_mfcc < 1 || cfg.n_mfcc > 32) { why = "n_mfcc must be in [1, 32]"; return false; }
+    t.n_mels = cfg.n_mels;
+    t.n_mfcc = cfg.n_mfcc;
+
+    // window, pre-scaled by 1/2: the packed real FFT untangling X[k] =
+    // ((Z[k]+Z*[N/2-k]) - i W^k (Z[k]-Z*[N/2-k]))/2 then needs no scaling
+    // (multiplying by 0.5 is exact in binary floating point).
+    std::vector<float> win = make_window(cfg.window, cfg.frame_length);
+    win.resize(n_fft, 0.0f);
+    for (int l = 0; l < kLanes; ++l)
+        for (int a = 0; a < 4; ++a) {
+            const int n = l + 64 * a;
+            t.win[2 * a][l] = 0.5f * win[2 * n];
+            t.win[2 * a + 1][l] = 0.5f * win[2 * n + 1];
+        }
+    for (int l = 0; l < kLanes; ++l) {
+        for (int q = 1; q <= 3; ++q) {
+            unit((double)(l * q) / 256.0, t.tw1[2 * (q - 1)][l], t.tw1[2 * (q - 1) + 1][l]);
+            unit((double)((l & 15) * q) / 64.0, t.tw2[2 * (q - 1)][l], t.tw2[2 * (q - 1) + 1][l]);
+            unit((double)((l & 3) * q) / 16.0, t.tw3[2 * (q - 1)][l], t.tw3[2 * (q - 1) + 1][l]);
+        }
+        unit((double)l / 512.0, t.twp[0][l], t.twp[1][l]);
+        unit((double)(l + 64) / 512.0, t.twp[2][l], t.twp[3][l]);
+    }
+
+    // sparse mel: every filter's non-zero run is cut into chunks of <= 12 bins,
+    // one chunk per lane (494 non-zeros in 61 chunks for the reference config).
+    const std::vector<float> fb = make_mel_filterbank(cfg.sample_rate, n_fft, cfg.n_mels, cfg.fmin,
+                                                      cfg.fmax, cfg.mel_norm);
+    for (int g = 0; g < kMelGather; ++g)
+        for (int l = 0; l < kLanes; ++l) t.mel_src[g][l] = kZeroSlot;
+    int next = 0;
+    for (int m = 0; m < cfg.n_mels; ++m) {
+        const float *row = &fb[(size_t)m * n_bins];
+        int first = -1, last = -1;
+        for (int k = 0; k < n_bins; ++k)
+            if (row[k] != 0.0f) { if (first < 0) first = k; last = k; }
+        if (first < 0) continue;  // empty filter -> energy 0 (all sources = zero slot)
+        for (int k = first; k <= last; ++k)
+            if (row[k] == 0.0f) { /* interior zero is fine: weight 0 */ }
+        int g = 0;
+        for (int k = first; k <= last; k += kMelChunk, ++g) {
+            if (g >= kMelGather) { why = "a mel filter spans more than 36 bins"; return false; }
+            if (next >= kLanes) { why = "mel filterbank needs more than 64 chunks of 12 bins"; return false; }
+            const int len = std::min(kMelChunk, last - k + 1);
+            const int k0 = std::min(k, n_bins - kMelChunk);  // keep every read inside [0, 256]
+            t.mel_k0[next] = k0;
+            for (int i = 0; i < kMelChunk; ++i) {
+                const int kk = k0 + i;
+                t.mel_w[i][next] = (kk >= k && kk < k + len) ? row[kk] : 0.0f;
+            }
+            t.mel_src[g][m] = next;
+            ++next;
+        }
+    }
+
+    // DCT: split the n_mels-long dot product over 4 (or 2) neighbouring lanes.
+    t.dct_split = cfg.n_mfcc <= 16 ? 4 : 2;
+    // the kernel is instantiated for (split, len) in {(4,10), (4,16), (2,20)}:
+    // take the smallest instantiated length that covers n_mels (extra weights are 0)
+    const int need = (cfg.n_mels + t.dct_split - 1) / t.dct_split;
+    int len;
+    if (t.dct_split == 4 && need <= 10) len = 10;
+    else if (t.dct_split == 4 && need <= 16) len = 16;
+    else if (t.dct_split == 2 && need <= 20) len = 20;
+    else { why = "n_mels too large for this n_mfcc (need n_mels <= 64 for n_mfcc <= 16, <= 40 otherwise)"; return false; }
+    t.dct_len = len;
+    const std::vector<float> dct = make_dct_ortho(cfg.n_mfcc, cfg.n_mels);
+    for (int c = 0; c < cfg.n_mfcc; ++c)
+        for (int q = 0; q < t.dct_split; ++q) {
+            const int lane = t.dct_split * c + q;
+            for (int i = 0; i < len; ++i) {
+                const int m = q * len + i;
+                t.dct_w[i][lane] = m < cfg.n_mels ? dct[(size_t)c * cfg.n_mels + m] : 0.0f;
+            }
+        }
+    return true;
+}
+
+}  // namespace dsp

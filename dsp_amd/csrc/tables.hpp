@@ -1,0 +1,57 @@
+// tables.hpp -- host-side constant tables for the MFCC kernels.
+//
+// The reference ships its constants as generated headers (mfcc_params.h); the
+// generator is 2fa/audio/word/python/export_mfcc_params.py.  Here the same
+// formulas are evaluated at plan-creation time for any configuration and then
+// re-laid-out per lane for the wave-per-frame kernel.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/dsp_amd.h"
+
+namespace dsp {
+
+// ---- plain tables (reference layouts) --------------------------------------
+std::vector<float> make_window(int kind, int n);                                  // export_mfcc_params.py:46
+std::vector<float> make_mel_filterbank(int sample_rate, int n_fft, int n_mels,    // :49-57, [n_mels][n_fft/2+1]
+                                       float fmin, float fmax, int mel_norm);
+std::vector<float> make_dct_ortho(int n_mfcc, int n_mels);                        // :27-41, [n_mfcc][n_mels]
+
+// ---- per-lane layout for the 512-point wave-per-frame kernel ---------------
+// Every array is [field][64 lanes] so a wave loads one field with one coalesced
+// dword load per lane.
+constexpr int kLanes = 64;
+constexpr int kMelChunk = 12;   // bins per lane in the sparse mel product
+constexpr int kMelGather = 3;   // max chunks per filter
+constexpr int kDctMaxLen = 20;  // log-mel values per lane in the DCT (n_mels / split, padded even)
+constexpr int kZeroSlot = 64;   // LDS partial slot that always reads 0
+
+struct LaneTables512 {
+    // window (x0.5, see kernel) for samples 2(l+64a) and 2(l+64a)+1, a = 0..3
+    float win[8][kLanes];
+    // FFT twiddles, (cos, sin) pairs for q = 1..3
+    float tw1[6][kLanes];   // W256^(l q)
+    float tw2[6][kLanes];   // W64^((l%16) q)
+    float tw3[6][kLanes];   // W16^((l%4) q)
+    float twp[4][kLanes];   // W512^l, W512^(l+64)
+    // sparse mel: lane owns bins [k0, k0+12) of one filter
+    int32_t mel_k0[kLanes];
+    float mel_w[kMelChunk][kLanes];
+    // filter m (lane m) = sum of up to 3 partial slots
+    int32_t mel_src[kMelGather][kLanes];
+    // DCT: `split` lanes cooperate on one coefficient; lane = split*c + q
+    // multiplies log-mel [q*len, (q+1)*len)
+    float dct_w[kDctMaxLen][kLanes];
+    int32_t dct_split;         // 4 (n_mfcc <= 16) or 2 (n_mfcc <= 32)
+    int32_t dct_len;           // floats per part (even, <= kDctMaxLen)
+    int32_t n_mels, n_mfcc;
+};
+
+// Fills `t`; returns false (with a message) when the configuration does not
+// fit this kernel's layout.
+bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::string &why);
+
+}  // namespace dsp

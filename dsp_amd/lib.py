@@ -1,0 +1,90 @@
+"""ctypes binding of libdsp_amd.so (include/dsp_amd.h).  Fails loudly: there is
+no Python/CPU implementation behind these calls."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+
+class DspError(RuntimeError):
+    pass
+
+
+class MfccConfig(C.Structure):
+    """dsp_mfcc_config (include/dsp_amd.h); defaults = mfcc_params.h:6-12 of the reference."""
+
+    _fields_ = [
+        ("sample_rate", C.c_int), ("n_fft", C.c_int), ("frame_length", C.c_int),
+        ("hop_length", C.c_int), ("n_mels", C.c_int), ("n_mfcc", C.c_int),
+        ("window", C.c_int), ("mel_norm", C.c_int), ("log_mode", C.c_int),
+        ("prefilter", C.c_int),
+        ("fmin", C.c_float), ("fmax", C.c_float), ("amin", C.c_float), ("top_db", C.c_float),
+    ]
+
+
+WINDOW_HANN, WINDOW_HAMMING, WINDOW_RECT = 0, 1, 2
+MELNORM_NONE, MELNORM_SLANEY = 0, 1
+LOG_PER_FRAME_MAX, LOG_GLOBAL_REF1 = 0, 1
+PREFILTER_NONE, PREFILTER_BUTTER_1000_3000, PREFILTER_BUTTER_3000_7500 = 0, 1, 2
+
+# every symbol include/dsp_amd.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "compute_mfcc",
+    "dsp_mfcc_default_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
+    "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",
+    "dsp_mfcc_clips_host", "dsp_mfcc_plan_set_launch", "dsp_butter_bandpass", "dsp_mfcc_tables",
+    "dsp_last_error", "dsp_device_count", "dsp_version",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (building first if the sources are newer) the in-tree libdsp_amd.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if _build.is_stale():
+        try:
+            _build.build()
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(path):
+                raise DspError(f"libdsp_amd.so is missing and could not be built: {e}") from e
+    try:
+        L = C.CDLL(path)
+    except OSError as e:
+        raise DspError(f"cannot load {path}: {e} (the HIP extension is required; there is no fallback)") from e
+    vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.c_int
+    cfgp = C.POINTER(MfccConfig)
+    L.compute_mfcc.argtypes = [vp, ip, vp, ip]; L.compute_mfcc.restype = ip
+    L.dsp_mfcc_default_config.argtypes = [cfgp]; L.dsp_mfcc_default_config.restype = None
+    L.dsp_mfcc_plan_create.argtypes = [cfgp, ip, C.POINTER(vp)]; L.dsp_mfcc_plan_create.restype = ip
+    L.dsp_mfcc_plan_destroy.argtypes = [vp]; L.dsp_mfcc_plan_destroy.restype = None
+    L.dsp_mfcc_plan_config.argtypes = [vp, cfgp]; L.dsp_mfcc_plan_config.restype = ip
+    L.dsp_mfcc_frames_for.argtypes = [cfgp, ip, ip]; L.dsp_mfcc_frames_for.restype = ip
+    L.dsp_mfcc_frames_device.argtypes = [vp, vp, C.c_long, vp, vp]; L.dsp_mfcc_frames_device.restype = ip
+    L.dsp_mfcc_clips_device.argtypes = [vp, vp, C.c_long, ip, C.c_long, vp, ip, vp]; L.dsp_mfcc_clips_device.restype = ip
+    L.dsp_mfcc_frames_host.argtypes = [vp, vp, C.c_long, vp]; L.dsp_mfcc_frames_host.restype = ip
+    L.dsp_mfcc_clips_host.argtypes = [vp, vp, C.c_long, ip, C.c_long, vp, ip]; L.dsp_mfcc_clips_host.restype = ip
+    L.dsp_mfcc_plan_set_launch.argtypes = [vp, ip, ip]; L.dsp_mfcc_plan_set_launch.restype = ip
+    L.dsp_butter_bandpass.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.dsp_butter_bandpass.restype = ip
+    L.dsp_mfcc_tables.argtypes = [cfgp, vp, vp, vp]; L.dsp_mfcc_tables.restype = ip
+    L.dsp_last_error.argtypes = []; L.dsp_last_error.restype = C.c_char_p
+    L.dsp_device_count.argtypes = []; L.dsp_device_count.restype = ip
+    L.dsp_version.argtypes = []; L.dsp_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return load().dsp_last_error().decode()
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        raise DspError(f"{what} failed ({rc}): {last_error()}")
+    return rc

@@ -1,0 +1,131 @@
+/*
+ * dsp_amd.h -- C ABI of libdsp_amd.so: the MI355X (gfx950) MFCC / Butterworth /
+ * spectrogram hot path of cornell-c2s2/dsp behind the reference's own C entry
+ * points.  Plain C: pointers and sizes only, no torch / HIP types (streams are
+ * passed as void*).
+ *
+ * Section 1 are the reference's symbols, bit-for-bit the same signatures, so the
+ * library links in place of the reference's mfcc.c / classifier.cpp object
+ * files.  Section 2 are batch / device-resident extensions the reference does
+ * not have; the Section-1 symbols are thin wrappers over them.
+ *
+ * Reference paths are relative to the upstream repository root.
+ * Error convention: Section-1 functions keep the reference's return values
+ * (frame count / 0-1 label, 0 on failure) and never change them to signal GPU
+ * trouble; the cause is readable through dsp_last_error().  Section-2 functions
+ * return >= 0 on success and a negative DSP_E* code on failure.
+ */
+#ifndef DSP_AMD_H
+#define DSP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===================================================================== */
+/* 1. Reference entry points (drop-in)                                    */
+/* ===================================================================== */
+
+/* Replaces 2fa/audio/word/c/mfcc.h:16-19 (definition mfcc.c:108-232; identical
+ * copy 2fa/audio/pico-audio/src/mfcc.c).  Mono float PCM in [-1,1] at 16 kHz
+ * -> frame-major out_mfcc[T][13], T = min(max_frames, 1 + (n-400)/160);
+ * returns T, 0 when num_samples < 400 or max_frames <= 0 (mfcc.c:117-119).
+ * Caller owns both buffers (host memory); out_mfcc holds max_frames*13 floats. */
+int compute_mfcc(const float *signal, int num_samples, float *out_mfcc, int max_frames);
+
+/* ===================================================================== */
+/* 2. Extensions                                                          */
+/* ===================================================================== */
+
+enum {
+    DSP_OK = 0,
+    DSP_EINVAL = -1,      /* bad argument / unsupported configuration      */
+    DSP_ENODEV = -2,      /* no usable HIP device                           */
+    DSP_EHIP = -3,        /* a HIP runtime call failed (see dsp_last_error) */
+    DSP_ENOMEM = -4
+};
+
+enum { DSP_WINDOW_HANN = 0, DSP_WINDOW_HAMMING = 1, DSP_WINDOW_RECT = 2 };
+enum { DSP_MELNORM_NONE = 0, DSP_MELNORM_SLANEY = 1 };
+enum { DSP_LOG_PER_FRAME_MAX = 0, DSP_LOG_GLOBAL_REF1 = 1 };
+enum { DSP_PREFILTER_NONE = 0, DSP_PREFILTER_BUTTER_1000_3000 = 1, DSP_PREFILTER_BUTTER_3000_7500 = 2 };
+
+/* Compile-time constants of the reference (mfcc_params.h:6-12, mfcc.c:172-173)
+ * turned into a POD; dsp_mfcc_default_config() fills in the reference values. */
+typedef struct dsp_mfcc_config {
+    int sample_rate;  /* 16000 */
+    int n_fft;        /* 512   (supported: 512) */
+    int frame_length; /* 400   (<= n_fft) */
+    int hop_length;   /* 160 */
+    int n_mels;       /* 40 */
+    int n_mfcc;       /* 13 */
+    int window;       /* DSP_WINDOW_*  (reference: periodic Hann, export_mfcc_params.py:46) */
+    int mel_norm;     /* DSP_MELNORM_* (reference: none, export_mfcc_params.py:56) */
+    int log_mode;     /* DSP_LOG_*     (reference: per-frame max, mfcc.c:169-206) */
+    int prefilter;    /* DSP_PREFILTER_* fp64 Butterworth per frame from zero state */
+    float fmin, fmax; /* 0, 8000 */
+    float amin;       /* 1e-10 */
+    float top_db;     /* 80 */
+} dsp_mfcc_config;
+
+void dsp_mfcc_default_config(dsp_mfcc_config *cfg);
+
+typedef struct dsp_mfcc_plan dsp_mfcc_plan; /* opaque: device tables for one config on one GPU */
+
+/* Builds the constant tables (window, FFT twiddles, sparse HTK-mel chunks,
+ * DCT-II basis; formulas of 2fa/audio/word/python/export_mfcc_params.py:27-60)
+ * on the host and uploads them to `device`.                                   */
+int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan **out);
+void dsp_mfcc_plan_destroy(dsp_mfcc_plan *plan);
+int dsp_mfcc_plan_config(const dsp_mfcc_plan *plan, dsp_mfcc_config *cfg);
+
+/* Number of frames compute_mfcc produces for an n-sample clip (mfcc.c:132-139). */
+int dsp_mfcc_frames_for(const dsp_mfcc_config *cfg, int num_samples, int max_frames);
+
+/* --- device-resident entry points: pointers are HBM addresses on the plan's
+ * device, work is enqueued on `stream` (a hipStream_t, NULL = default stream)
+ * and the call returns without synchronising.                                 */
+
+/* n_frames independent frames, d_frames[n_frames][frame_length] back to back
+ * -> d_out[n_frames][n_mfcc]  (BASELINE configs 2/3).                          */
+int dsp_mfcc_frames_device(dsp_mfcc_plan *plan, const float *d_frames, long n_frames,
+                           float *d_out, void *stream);
+
+/* n_clips clips of samples_per_clip floats, clip c starting at
+ * d_signal + c*clip_stride; each framed like compute_mfcc (frame_length/hop)
+ * and capped at max_frames -> d_out[n_clips][T][n_mfcc]; returns T.           */
+int dsp_mfcc_clips_device(dsp_mfcc_plan *plan, const float *d_signal, long n_clips,
+                          int samples_per_clip, long clip_stride, float *d_out,
+                          int max_frames, void *stream);
+
+/* --- host-pointer conveniences: copy in, run, copy out, synchronise. -------- */
+int dsp_mfcc_frames_host(dsp_mfcc_plan *plan, const float *frames, long n_frames, float *out);
+int dsp_mfcc_clips_host(dsp_mfcc_plan *plan, const float *signal, long n_clips,
+                        int samples_per_clip, long clip_stride, float *out, int max_frames);
+
+/* Launch geometry knobs for tuning / profiling (0 = library default). */
+int dsp_mfcc_plan_set_launch(dsp_mfcc_plan *plan, int blocks_per_cu, int frames_per_chunk);
+
+/* --- Butterworth band-pass (donut-classifier/classifier.c:319-446) ---------- */
+
+/* Literal 9-tap tables of classifier.c:342-360 / 383-401; returns 1, or 0 for
+ * any other band (the reference prints "invalid bandpass range").              */
+int dsp_butter_bandpass(double lowcut, double highcut, double *b, double *a);
+
+/* Reference-layout constant tables for a configuration (what mfcc_params.h holds
+ * for the reference config): window[frame_length], mel[n_mels][n_fft/2+1],
+ * dct[n_mfcc][n_mels].  Host-only, no GPU needed; any pointer may be NULL.      */
+int dsp_mfcc_tables(const dsp_mfcc_config *cfg, float *window, float *mel, float *dct);
+
+/* --- misc -------------------------------------------------------------------- */
+const char *dsp_last_error(void);   /* thread-local, "" when none */
+int dsp_device_count(void);
+const char *dsp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSP_AMD_H */

@@ -1,0 +1,95 @@
+"""CPU: the C-ABI library loads, exports every symbol include/dsp_amd.h declares,
+and its host-only logic (config defaults, frame counting, tables, error paths)
+matches the reference.  No compute call is made here (no GPU in this tier)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import dsp_amd
+from dsp_amd import lib as dl
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dsp_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(compute_mfcc|classify\w*|dsp_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    L = dsp_amd.load()
+    names = _declared_symbols()
+    assert "compute_mfcc" in names and len(names) >= 12
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/dsp_amd.h but not exported"
+    assert sorted(dl.SYMBOLS) == names
+
+
+def test_default_config_is_the_reference():
+    c = dsp_amd.default_config()
+    assert (c.sample_rate, c.n_fft, c.frame_length, c.hop_length, c.n_mels, c.n_mfcc) == (16000, 512, 400, 160, 40, 13)
+    assert c.amin == np.float32(1e-10) and c.top_db == 80.0 and c.fmin == 0.0 and c.fmax == 8000.0
+
+
+@pytest.mark.parametrize("n,mx,want", [(399, 500, 0), (400, 500, 1), (559, 500, 1), (560, 500, 2), (16000, 500, 98),
+                                       (24029, 500, 148), (96000, 500, 500), (16000, 0, 0), (16000, -3, 0), (16000, 7, 7)])
+def test_frame_count_rule(n, mx, want):
+    assert dsp_amd.frames_for(dsp_amd.default_config(), n, mx) == want
+
+
+def test_tables_equal_the_oracle_tables():
+    cfg = dsp_amd.default_config()
+    w, m, d = dsp_amd.tables(cfg)
+    assert np.array_equal(w, O.window(O.WINDOW_HANN, 400))
+    assert np.array_equal(m, O.mel_filterbank())
+    assert np.array_equal(d, O.dct_ortho())
+    cfg2 = dsp_amd.default_config(n_mels=32, n_mfcc=20, mel_norm=dl.MELNORM_SLANEY, window=dl.WINDOW_HAMMING, fmin=50.0, fmax=7000.0)
+    w, m, d = dsp_amd.tables(cfg2)
+    assert np.array_equal(w, O.window(O.WINDOW_HAMMING, 400))
+    assert np.array_equal(m, O.mel_filterbank(16000, 512, 32, 50.0, 7000.0, O.MELNORM_SLANEY))
+    assert np.array_equal(d, O.dct_ortho(20, 32))
+
+
+def test_butter_bandpass_tables_and_rejection():
+    L = dsp_amd.load()
+    b = (C.c_double * 9)(); a = (C.c_double * 9)()
+    for lo, hi in ((1000, 3000), (3000, 7500)):
+        assert L.dsp_butter_bandpass(lo, hi, b, a) == 1
+        ok, ob, oa = O.butter_bandpass(lo, hi)
+        assert list(b) == list(ob) and list(a) == list(oa)
+    assert L.dsp_butter_bandpass(2000, 6000, b, a) == 0      # classifier.c:402-407
+    assert "invalid bandpass range" in dl.last_error()
+
+
+def test_bad_configs_are_rejected_before_touching_a_device():
+    L = dsp_amd.load()
+    h = C.c_void_p()
+    for over, msg in ((dict(n_fft=256), "n_fft"), (dict(frame_length=401), "even"), (dict(hop_length=0), "hop"),
+                      (dict(n_mels=100), "n_mels"), (dict(log_mode=dl.LOG_GLOBAL_REF1), "LOG")):
+        cfg = dsp_amd.default_config(**over)
+        assert L.dsp_mfcc_plan_create(C.byref(cfg), 0, C.byref(h)) == -1
+        assert msg.lower() in dl.last_error().lower()
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(dsp_amd.DspError, match="no HIP device"):
+        dsp_amd.MfccPlan()
+    # the reference entry point keeps its return convention: 0 frames, reason via dsp_last_error()
+    out = dsp_amd.compute_mfcc(np.zeros(16000, np.float32), 500)
+    assert out.shape[0] == 0 and "no HIP device" in dl.last_error()
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "dsp_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"

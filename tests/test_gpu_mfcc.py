@@ -1,0 +1,175 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C ABI, against (1) goldens from the reference's compiled mfcc.c, (2) the CPU
+oracle on seeded inputs, (3) size-independent properties at BASELINE's full size.
+
+Gate (BASELINE.md / SURVEY 8c): |gpu - ref| <= 1e-4 * max(|ref|, ||ref frame||_inf).
+"""
+import numpy as np
+import pytest
+
+from tests import signals as S
+from tests.conftest import frame_linf_close
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def dsp():
+    import dsp_amd
+    return dsp_amd
+
+
+def _cases(g):
+    c = S.mfcc_cases()
+    c["chirp"] = g["input__chirp"]
+    bird = g["birdq_pcm"]
+    c["birdq_ch0"] = (bird[:, 0] / np.float32(32768.0)).astype(np.float32)
+    c["birdq_avg"] = (np.float32(0.5) * (bird[:, 0] / np.float32(32768.0) + bird[:, 1] / np.float32(32768.0))).astype(np.float32)
+    c["stop_121417"] = (g["stop_pcm"] / np.float32(32768.0)).astype(np.float32)
+    return c
+
+
+ALL = ["noise0", "noise1", "noise2", "chirp", "silence", "tiny", "dc", "impulse", "half_silent",
+       "len399", "len400", "len559", "len560", "long", "birdq_ch0", "birdq_avg", "stop_121417"]
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_compute_mfcc_entry_point_vs_reference_goldens(dsp, golden, name):
+    """`int compute_mfcc(signal, n, out, max_frames)` exactly as the reference's callers use it."""
+    g = golden("mfcc_ref.npz")
+    ref = g["mfcc__" + name]
+    got = dsp.compute_mfcc(_cases(g)[name], 500)
+    assert got.shape == ref.shape
+    ok, worst = frame_linf_close(got, ref, RTOL)
+    assert ok, f"{name}: worst {worst:.3e}"
+
+
+def test_max_frames_and_degenerate_arguments(dsp, golden):
+    g = golden("mfcc_ref.npz")
+    x = S.mfcc_cases()["noise0"]
+    got = dsp.compute_mfcc(x, 7)
+    assert got.shape == (7, 13)
+    assert frame_linf_close(got, g["mfcc__noise0_max7"], RTOL)[0]
+    assert dsp.compute_mfcc(x, 0).shape[0] == 0
+    assert dsp.compute_mfcc(x[:399], 500).shape[0] == 0
+
+
+def test_silence_is_exactly_zero(dsp):
+    out = dsp.compute_mfcc(np.zeros(16000, np.float32), 500)
+    assert out.shape == (98, 13) and not out.any()
+
+
+def test_birdq_is_config_one(dsp, golden):
+    """BASELINE config 1: birdQ_stereo_16k.wav channel 0 -> 148 frames."""
+    g = golden("mfcc_ref.npz")
+    got = dsp.compute_mfcc(_cases(g)["birdq_ch0"], 500)
+    assert got.shape == (148, 13)
+    assert frame_linf_close(got, g["mfcc__birdq_ch0"], RTOL)[0]
+
+
+def test_clips_device_path_vs_goldens(dsp, torch_cuda, golden):
+    """HBM-resident clips -> [n_clips][T][13]; strided batch incl. a silent clip."""
+    torch = torch_cuda
+    g = golden("mfcc_ref.npz")
+    names = ["noise0", "noise1", "silence", "chirp", "stop_121417", "noise2"]
+    clips = np.stack([_cases(g)[n] for n in names])
+    plan = dsp.MfccPlan()
+    out = plan.clips(torch.from_numpy(clips).cuda(), 500).cpu().numpy()
+    assert out.shape == (6, 98, 13)
+    for i, n in enumerate(names):
+        ok, worst = frame_linf_close(out[i], g["mfcc__" + n], RTOL)
+        assert ok, (n, worst)
+    # strided view: clips embedded in a wider buffer
+    wide = torch.zeros((6, 16000 + 64), device="cuda")
+    wide[:, :16000] = torch.from_numpy(clips).cuda()
+    out2 = plan.clips(wide[:, :16000], 500).cpu().numpy()
+    assert np.array_equal(out, out2)
+    # host convenience path gives the same bits
+    assert np.array_equal(plan.clips_host(clips, 500), out)
+
+
+@pytest.mark.parametrize("n_frames", [1, 3, 63, 64, 65, 1000, 4099])
+def test_frames_path_vs_oracle(dsp, torch_cuda, n_frames):
+    """BASELINE config 2 shape (512-sample frames, Hann(512)) at oracle-friendly sizes, ragged counts."""
+    from oracle import oracle as O
+    torch = torch_cuda
+    cfg = dsp.default_config(frame_length=512, hop_length=512)
+    plan = dsp.MfccPlan(cfg)
+    fr = S.uniform_pm1(512 * n_frames, 100 + n_frames).reshape(n_frames, 512)
+    if n_frames >= 64:
+        fr[::37] = 0.0                           # 1 % silent frames in the correctness set
+        fr[5] *= 1e-6                            # energies near amin
+    out = plan.frames(torch.from_numpy(fr).cuda()).cpu().numpy()
+    ref = O.mfcc_frames(fr, O.default_cfg(frame_length=512, hop_length=512), threads=4)
+    ok, worst = frame_linf_close(out, ref, RTOL)
+    assert ok, worst
+    assert np.array_equal(plan.frames_host(fr), out)
+
+
+def test_empty_batch(dsp, torch_cuda):
+    torch = torch_cuda
+    plan = dsp.MfccPlan(dsp.default_config(frame_length=512, hop_length=512))
+    out = plan.frames(torch.empty((0, 512), device="cuda"))
+    assert tuple(out.shape) == (0, 13)
+    assert plan.clips(torch.empty((0, 16000), device="cuda"), 500).shape[0] == 0
+
+
+@pytest.mark.parametrize("over", [dict(n_mels=32), dict(n_mfcc=20), dict(n_mfcc=8, n_mels=24),
+                                  dict(window=1), dict(mel_norm=1), dict(fmin=100.0, fmax=6000.0),
+                                  dict(frame_length=256, hop_length=128), dict(top_db=40.0)])
+def test_other_configurations_vs_oracle(dsp, torch_cuda, over):
+    from oracle import oracle as O
+    torch = torch_cuda
+    cfg = dsp.default_config(**over)
+    ocfg = O.default_cfg(**over)
+    x = np.stack([S.uniform_pm1(8000, 40), S.chirp(8000, 200.0, 7500.0), S.uniform_pm1(8000, 41) * np.float32(1e-3)])
+    plan = dsp.MfccPlan(cfg)
+    out = plan.clips(torch.from_numpy(x).cuda(), 500).cpu().numpy()
+    for i in range(3):
+        ref = O.compute_mfcc(x[i], 500, ocfg)
+        assert out[i].shape == ref.shape
+        ok, worst = frame_linf_close(out[i], ref, RTOL)
+        assert ok, (over, i, worst)
+
+
+def test_full_size_properties(dsp, torch_cuda):
+    """BASELINE config 2 at full size (1 M x 512): properties that need no oracle pass,
+    plus an oracle spot check on a random sample of frames."""
+    from oracle import oracle as O
+    torch = torch_cuda
+    n = 1_000_000
+    cfg = dsp.default_config(frame_length=512, hop_length=512)
+    plan = dsp.MfccPlan(cfg)
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.rand((n, 512), device="cuda", generator=gen) * 2 - 1
+    x[::101] = 0.0
+    a = plan.frames(x)
+    b = plan.frames(x)
+    assert torch.equal(a, b)                                   # deterministic
+    # power-of-two gain leaves every coefficient bit-identical (per-frame max reference)
+    c = plan.frames(x * 4.0)
+    assert torch.equal(a, c)
+    # frames are independent: permuting the input permutes the output
+    perm = torch.randperm(n, device="cuda", generator=gen)
+    d = plan.frames(x[perm].contiguous())
+    assert torch.equal(d, a[perm])
+    # silent frames -> exact zeros, nothing non-finite anywhere
+    assert not a[::101].any() and bool(torch.isfinite(a).all())
+    # different launch geometry -> same bits
+    plan.set_launch(2, 7)
+    assert torch.equal(plan.frames(x), a)
+    plan.set_launch(0, 0)
+    # oracle spot check
+    idx = torch.randint(0, n, (3000,), device="cuda", generator=gen)
+    ref = O.mfcc_frames(x[idx].cpu().numpy(), O.default_cfg(frame_length=512, hop_length=512), threads=8)
+    ok, worst = frame_linf_close(a[idx].cpu().numpy(), ref, RTOL)
+    assert ok, worst
