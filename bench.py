@@ -36,6 +36,18 @@ BYTES_PER_FRAME = FRAME * 4 + N_MFCC * 4      # 2100 algorithmic by
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def host_cpu_share() -> int:
+    """Host threads this process may really use: cgroup quota if set, else affinity, capped."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(sample_frames: int, seconds_budget: float = 25.0):
     """Time the CPU path on this host.  Only bench.py's baseline leg touches oracle/."""
     import numpy as np
@@ -43,7 +55,7 @@ def cpu_baseline(sample_frames: int, seconds_budget: float = 25.0):
 
     rng = np.random.default_rng(7)
     res = {}
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncpu = host_cpu_share()
     # (a) the reference's own compute_mfcc (400/160 framing over one long clip: the same
     #     512-point FFT / 40-mel / 13-coef work per frame), single thread: it keeps
     #     static scratch (mfcc.c:21-22) and is not re-entrant.

@@ -215,7 +215,7 @@ static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames,
     long blocks = (long)p->n_cu * per_cu;
     const long chunks = (n_frames + a.chunk - 1) / a.chunk;
     blocks = std::max(1L, std::min(blocks, (chunks + 3) / 4));
-    DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, (int)blocks, (hipStream_t)stream));
+    DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
     return DSP_OK;
 }
 

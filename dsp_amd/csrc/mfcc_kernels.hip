@@ -152,8 +152,9 @@ __device__ __forceinline__ void load_frame(const float *__restrict__ src, int la
 }  // namespace
 
 // DCT_SPLIT lanes per coefficient, DCT_LEN log-mel values per lane.
-// FULL: frame_length == 512 (no tail predicate on the loads).
-template <int DCT_SPLIT, int DCT_LEN, bool FULL>
+// GATHER: partial sums per mel filter.  FULL: frame_length == 512 (no tail
+// predicate on the loads).
+template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL>
 __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args args)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,9 +185,9 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
 #pragma unroll
     for (int i = 0; i < kMelChunk; ++i) melw[i] = T->mel_w[i][lane];
     const float *mel_rd = pbuf + T->mel_k0[lane];
-    const float *gat0 = part + T->mel_src[0][lane];
-    const float *gat1 = part + T->mel_src[1][lane];
-    const float *gat2 = part + T->mel_src[2][lane];
+    const float *gat[GATHER];
+#pragma unroll
+    for (int g = 0; g < GATHER; ++g) gat[g] = part + T->mel_src[g][lane];
     float dctw[DCT_LEN];
 #pragma unroll
     for (int i = 0; i < DCT_LEN; ++i) dctw[i] = T->dct_w[i][lane];
@@ -308,14 +309,19 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
         for (int i = 0; i < kMelChunk; ++i) acc = fmaf(melw[i], mel_rd[i], acc);
         part[lane] = acc;
         wave_lds_sync();
-        float e = (*gat0 + *gat1) + *gat2;
+        float e = *gat[0];
+#pragma unroll
+        for (int g = 1; g < GATHER; ++g) e += *gat[g];
         if (lane >= n_mels) e = 0.0f;
 
         // ---- 10 log10 with per-frame reference (mfcc.c:169-206) ---------------
+        // 10 log10(max(e,amin)) - 10 log10(ref) evaluated as one log of the ratio: no
+        // cancellation between two ~-100 dB terms, and exactly invariant to a
+        // power-of-two gain on the input.
         const float ref = fmaxf(wave_max(e), amin);
         const float k10 = 3.01029995663981195f;            // 10 * log10(2)
-        float db = k10 * (__builtin_amdgcn_logf(fmaxf(e, amin)) - __builtin_amdgcn_logf(ref));
-        db = fmaxf(db, neg_top_db);                         // max over the frame is exactly 0
+        float db = k10 * __builtin_amdgcn_logf(fmaxf(e, amin) * __builtin_amdgcn_rcpf(ref));
+        db = fminf(fmaxf(db, neg_top_db), 0.0f);            // max over the frame is exactly 0
         if (lane < n_mels) lmel[lane] = db;
         wave_lds_sync();
 
@@ -338,20 +344,23 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
 
 // -----------------------------------------------------------------------------
 
-hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int blocks,
+hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks,
                           hipStream_t stream)
 {
     const bool full = args.frame_len == 512;
     const size_t lds = 4 * (size_t)LDS_WAVE_BYTES;
-#define DSP_LAUNCH(S, L)                                                                      \
-    do {                                                                                      \
-        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, true>), dim3(blocks), dim3(256), lds, stream, args);  \
-        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, false>), dim3(blocks), dim3(256), lds, stream, args); \
-        return hipGetLastError();                                                             \
-    } while (0)
-    if (dct_split == 4 && dct_len == 10) DSP_LAUNCH(4, 10);
-    if (dct_split == 4 && dct_len == 16) DSP_LAUNCH(4, 16);
-    if (dct_split == 2 && dct_len == 20) DSP_LAUNCH(2, 20);
+#define DSP_LAUNCH(S, L, G)                                                                                          \
+    if (dct_split == S && dct_len == L && gather == G) {                                                             \
+        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true>), dim3(blocks), dim3(256), lds, stream, args);   \
+        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false>), dim3(blocks), dim3(256), lds, stream, args);  \
+        return hipGetLastError();                                                                                    \
+    }
+    DSP_LAUNCH(4, 10, 3)
+    DSP_LAUNCH(4, 10, 6)
+    DSP_LAUNCH(4, 16, 3)
+    DSP_LAUNCH(4, 16, 6)
+    DSP_LAUNCH(2, 20, 3)
+    DSP_LAUNCH(2, 20, 6)
 #undef DSP_LAUNCH
     return hipErrorInvalidConfiguration;
 }

@@ -21,7 +21,7 @@ struct Mfcc512Args {
     float amin, top_db;
 };
 
-hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int blocks,
+hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks,
                           hipStream_t stream);
 int mfcc512_lds_bytes_per_block();
 

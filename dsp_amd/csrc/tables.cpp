@@ -125,7 +125,7 @@ bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::st
             if (row[k] == 0.0f) { /* interior zero is fine: weight 0 */ }
         int g = 0;
         for (int k = first; k <= last; k += kMelChunk, ++g) {
-            if (g >= kMelGather) { why = "a mel filter spans more than 36 bins"; return false; }
+            if (g >= kMelGather) { why = "a mel filter spans more than 72 bins"; return false; }
             if (next >= kLanes) { why = "mel filterbank needs more than 64 chunks of 12 bins"; return false; }
             const int len = std::min(kMelChunk, last - k + 1);
             const int k0 = std::min(k, n_bins - kMelChunk);  // keep every read inside [0, 256]
@@ -136,8 +136,10 @@ bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::st
             }
             t.mel_src[g][m] = next;
             ++next;
+            if (g + 1 > t.mel_gather) t.mel_gather = g + 1;
         }
     }
+    t.mel_gather = t.mel_gather <= 3 ? 3 : 6;
 
     // DCT: split the n_mels-long dot product over 4 (or 2) neighbouring lanes.
     t.dct_split = cfg.n_mfcc <= 16 ? 4 : 2;

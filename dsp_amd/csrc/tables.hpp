@@ -25,7 +25,7 @@ std::vector<float> make_dct_ortho(int n_mfcc, int n_mels);                      
 // dword load per lane.
 constexpr int kLanes = 64;
 constexpr int kMelChunk = 12;   // bins per lane in the sparse mel product
-constexpr int kMelGather = 3;   // max chunks per filter
+constexpr int kMelGather = 6;   // max chunks per filter (kernels are instantiated for 3 and 6)
 constexpr int kDctMaxLen = 20;  // log-mel values per lane in the DCT (n_mels / split, padded even)
 constexpr int kZeroSlot = 64;   // LDS partial slot that always reads 0
 
@@ -40,8 +40,9 @@ struct LaneTables512 {
     // sparse mel: lane owns bins [k0, k0+12) of one filter
     int32_t mel_k0[kLanes];
     float mel_w[kMelChunk][kLanes];
-    // filter m (lane m) = sum of up to 3 partial slots
+    // filter m (lane m) = sum of up to mel_gather partial slots
     int32_t mel_src[kMelGather][kLanes];
+    int32_t mel_gather;        // 3 or 6: chunks the widest filter needs, rounded up
     // DCT: `split` lanes cooperate on one coefficient; lane = split*c + q
     // multiplies log-mel [q*len, (q+1)*len)
     float dct_w[kDctMaxLen][kLanes];

@@ -53,6 +53,15 @@ def load() -> C.CDLL:
         except Exception as e:  # noqa: BLE001
             if not os.path.exists(path):
                 raise DspError(f"libdsp_amd.so is missing and could not be built: {e}") from e
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own
+    # libamdhip64.so (SONAME libamdhip64.so.7, the same as /opt/rocm's).  If torch is
+    # going to share streams and HBM buffers with this library it must be loaded
+    # first, so that our DT_NEEDED libamdhip64.so.7 binds to the runtime torch
+    # already brought in instead of a second copy from /opt/rocm.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001  (pure C-ABI use without torch is fine)
+        pass
     try:
         L = C.CDLL(path)
     except OSError as e:

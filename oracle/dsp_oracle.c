@@ -184,19 +184,27 @@ static void fft_radix2_reference_order(float *re, float *im, int n)
 
 static void dft_float64(const float *x, int frame_length, int n, float *out)
 {
-    /* exact-ish reference: O(n^2) in float64, only used at test sizes */
+    /* exact-ish reference: O(n^2) in float64 over a table of the n-th roots of
+     * unity (phase reduced mod n so it stays accurate); only used at test sizes */
+    double *cs = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *sn = cs + n;
+    for (int i = 0; i < n; ++i) {
+        cs[i] = cos(-2.0 * ORC_PI * (double)i / (double)n);
+        sn[i] = sin(-2.0 * ORC_PI * (double)i / (double)n);
+    }
     for (int k = 0; k < n; ++k) {
         double sr = 0.0, si = 0.0;
+        int ph = 0;
         for (int t = 0; t < frame_length; ++t) {
-            /* reduce k*t mod n before scaling so the phase stays accurate */
-            int ph = (int)(((long)k * (long)t) % (long)n);
-            double a = -2.0 * ORC_PI * (double)ph / (double)n;
-            sr += (double)x[t] * cos(a);
-            si += (double)x[t] * sin(a);
+            sr += (double)x[t] * cs[ph];
+            si += (double)x[t] * sn[ph];
+            ph += k;
+            if (ph >= n) ph -= n;
         }
         out[2 * k] = (float)sr;
         out[2 * k + 1] = (float)si;
     }
+    free(cs);
 }
 
 void orc_fft_real_forward(const float *in_time, int frame_length, int n_fft,
