@@ -7,10 +7,14 @@
 //   load      4 x global_load_dwordx2 per lane: z[l+64a] = x[2n] + i x[2n+1]
 //   window    8 v_mul (window pre-scaled by 1/2, tables.cpp)           mfcc.c:142-144
 //   FFT       512-point real FFT as a 256-point complex radix-4 DIF:    mfcc.c:16-95
-//             stage 1 in registers; exchange 1 = v_permlane32/16_swap;
-//             exchanges 2,3 through a 2 KiB per-wave LDS tile with XOR
-//             swizzles (bank-conflict free, tools/emulate_wave_fft.py)
-//   untangle  conjugate-pair split with ds_bpermute from lane 64-l      (packed real FFT)
+//             every butterfly stage in registers; inter-stage exchanges:
+//             1: v_permlane32/16_swap (lane bits 5:4); 2 and 3 (lane bits 3:2,
+//             1:0): a 2 KiB per-wave LDS tile with XOR swizzles (bank-conflict
+//             free; the last one also restores natural bin order).
+//             DSP_X2_LDS / DSP_X3_LDS = 0 switch 2 / 3 to DPP register moves
+//             (measured slower: DPP and v_cndmask issue at ~half rate, see
+//             DESIGN.md; dataflow model of all forms: tools/emulate_wave_fft.py)
+//   untangle  conjugate-pair split with ds_bpermute from the partner lane (packed real FFT)
 //   power     |X[k]|^2, k = 0..256                                     mfcc.c:151-155
 //   mel       sparse HTK triangles: <= 12 bins per lane + 3-way gather  mfcc.c:158-164
 //   log       per-frame ref = max, amin, top_db (v_log_f32)            mfcc.c:169-206
@@ -23,11 +27,25 @@
 
 #include "mfcc_kernels.hpp"
 
+// Timing-only diagnostic builds (never shipped), -DDSP_DIAG_MODE=<bit mask>:
+//   1 loads + store only, no arithmetic      2 arithmetic only, loads just the first frame
+//   4 skip the FFT       8 skip mel/log/DCT (store a power-spectrum value instead)
+//   32 wave-uniform constants (SGPRs)
+// Outputs are wrong in all of them; only the time is read.
+#ifndef DSP_DIAG_MODE
+#define DSP_DIAG_MODE 0
+#endif
+// frames in flight per wave (each costs 8 VGPRs)
+#ifndef DSP_PREFETCH
+#define DSP_PREFETCH 2
+#endif
+
 namespace dsp {
 
 namespace {
 
 struct c32 { float x, y; };
+typedef float f2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ c32 cadd(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ c32 csub(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
@@ -69,32 +87,77 @@ __device__ __forceinline__ void swap_odd16(float &a, float &b)
     b = __uint_as_float(r[1]);
 }
 
+// 2x2 block transposes between a register pair (a: slot bit 0, b: slot bit 1) and
+// one lane bit: afterwards a[bit=1] holds the partner lane's old b, b[bit=0] the
+// partner lane's old a.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_into(float old, float src);
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v);
+__device__ __forceinline__ void swap_lane8(float &a, float &b);
+__device__ __forceinline__ void swap_lane4(float &a, float &b);
+
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+// masked DPP move: lanes whose bank (lane%16/4) is in BANKS take src[perm], others keep old
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_into(float old, float src)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xF, BANKS, false));
+}
+constexpr int DPP_ROW_SHL4 = 0x104, DPP_ROW_SHR4 = 0x114, DPP_ROW_ROR8 = 0x128;
 constexpr int DPP_QUAD_1032 = 0xB1;   // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_2301 = 0x4E;   // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;
 constexpr int DPP_ROW_MIRROR = 0x140;
 
-__device__ __forceinline__ float wave_max(float v)
+__device__ __forceinline__ void swap_lane8(float &a, float &b)
+{   // lane ^ 8 = rotate the 16-lane row by 8; banks 0,1 have bit3 = 0, banks 2,3 bit3 = 1
+    const float nb = dpp_into<DPP_ROW_ROR8, 0x3>(b, a);
+    a = dpp_into<DPP_ROW_ROR8, 0xC>(a, b);
+    b = nb;
+}
+__device__ __forceinline__ void swap_lane4(float &a, float &b)
+{   // lane ^ 4: banks 0,2 (bit2 = 0) read lane+4, banks 1,3 read lane-4
+    const float nb = dpp_into<DPP_ROW_SHL4, 0x5>(b, a);
+    a = dpp_into<DPP_ROW_SHR4, 0xA>(a, b);
+    b = nb;
+}
+// lane bits 1 and 0 have no DPP write mask: quad permute + select on the lane bit
+template <int CTRL>
+__device__ __forceinline__ void swap_quad(float &a, float &b, bool bit_set)
 {
-    v = fmaxf(v, dpp<DPP_QUAD_1032>(v));
-    v = fmaxf(v, dpp<DPP_QUAD_2301>(v));
-    v = fmaxf(v, dpp<DPP_ROW_HALF_MIRROR>(v));
-    v = fmaxf(v, dpp<DPP_ROW_MIRROR>(v));           // every lane: max of its 16-lane row
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    const float pa = dpp<CTRL>(a), pb = dpp<CTRL>(b);
+    b = bit_set ? b : pa;
+    a = bit_set ? pb : a;
+}
+
+// max over the wave of NON-NEGATIVE floats: their bit patterns order like
+// unsigned integers, so the reduction runs on v_max_u32 (fuses with DPP, needs no
+// NaN canonicalisation moves).
+template <int CTRL>
+__device__ __forceinline__ unsigned dppu(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float wave_max_nonneg(float f)
+{
+    unsigned v = __float_as_uint(f);
+    v = max(v, dppu<DPP_QUAD_1032>(v));
+    v = max(v, dppu<DPP_QUAD_2301>(v));
+    v = max(v, dppu<DPP_ROW_HALF_MIRROR>(v));
+    v = max(v, dppu<DPP_ROW_MIRROR>(v));            // every lane: max of its 16-lane row
+    const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return __uint_as_float(max(max(r0, r1), max(r2, r3)));
 }
 
 // per-wave LDS carve (bytes)
-constexpr int LDS_XCHG = 0;                 // 256 x float2 exchange tile, later P[0..256] (+pad)
-constexpr int LDS_PART = 2048 + 64;         // 65 partial sums (+ zero slot), after P[256] spill room
+constexpr int LDS_XCHG = 0;                 // 256 x float2 exchange tile, later P[0..256]
+constexpr int LDS_PART = 2048 + 64;         // 65 partial sums (+ zero slot)
 constexpr int LDS_LOGMEL = LDS_PART + 320;  // up to 80 log-mel values
 constexpr int LDS_WAVE_BYTES = LDS_LOGMEL + 320;
 static_assert(LDS_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
@@ -104,28 +167,34 @@ static_assert(LDS_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
 // 52-byte outputs land in consecutive cache lines.
 struct FrameCursor {
     long f, chunk_end, chunk_first, stride, n;
-    long clip;      // clip mode: f = clip * fpc + t
-    int t, fpc, chunk;
-    __device__ __forceinline__ void locate()
-    {
-        chunk_end = f + chunk < n ? f + chunk : n;
-        if (fpc > 0 && f < n) { clip = f / fpc; t = (int)(f - clip * fpc); }
-    }
+    long clip;              // clip mode: f = clip * fpc + t
+    long jump_clips;        // stride = jump_clips * fpc + jump_t
+    int t, t0, fpc, chunk, jump_t;
+    long clip0;             // (clip0, t0): position of chunk_first
     __device__ __forceinline__ void init(long wave, long n_waves, int chunk_, long n_, int fpc_)
     {
-        chunk = chunk_; n = n_; fpc = fpc_; clip = 0; t = 0;
+        chunk = chunk_; n = n_; fpc = fpc_;
         stride = n_waves * chunk;
         chunk_first = wave * chunk;
         f = chunk_first;
-        locate();
+        chunk_end = f + chunk < n ? f + chunk : n;
+        clip0 = 0; t0 = 0; jump_clips = 0; jump_t = 0;
+        if (fpc > 0) {          // the only divisions: once per wave, not per frame
+            clip0 = f / fpc; t0 = (int)(f - clip0 * fpc);
+            jump_clips = stride / fpc; jump_t = (int)(stride - jump_clips * fpc);
+        }
+        clip = clip0; t = t0;
     }
     __device__ __forceinline__ bool valid() const { return f < n; }
     __device__ __forceinline__ void next()
     {
-        if (++f >= chunk_end) {           // one 64-bit divide per chunk, not per frame
+        if (++f >= chunk_end) {
             chunk_first += stride;
             f = chunk_first;
-            locate();
+            chunk_end = f + chunk < n ? f + chunk : n;
+            clip0 += jump_clips; t0 += jump_t;
+            if (t0 >= fpc) { t0 -= fpc; ++clip0; }
+            clip = clip0; t = t0;
         } else if (++t == fpc) {
             t = 0; ++clip;
         }
@@ -139,7 +208,8 @@ __device__ __forceinline__ void load_frame(const float *__restrict__ src, int la
     for (int a = 0; a < 4; ++a) {
         const int i = 2 * (lane + 64 * a);
         if (FULL || i + 1 < frame_len) {
-            const float2 v = *reinterpret_cast<const float2 *>(src + i);
+            // streamed once: nontemporal keeps the frames from displacing anything in L2
+            const f2v v = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));
             z[a] = {v.x, v.y};
         } else if (i < frame_len) {
             z[a] = {src[i], 0.0f};
@@ -169,6 +239,9 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
     const LaneTables512 *__restrict__ T = args.tables;
 
     // ---- per-lane constants (one coalesced dword per field) -----------------
+#if DSP_DIAG_MODE & 32   // timing probe: wave-uniform constants (SGPRs) to see what fewer VGPRs would buy
+#define lane 0
+#endif
     float win[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) win[i] = T->win[i][lane];
@@ -184,6 +257,9 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
     float melw[kMelChunk];
 #pragma unroll
     for (int i = 0; i < kMelChunk; ++i) melw[i] = T->mel_w[i][lane];
+#if DSP_DIAG_MODE & 32
+#undef lane
+#endif
     const float *mel_rd = pbuf + T->mel_k0[lane];
     const float *gat[GATHER];
 #pragma unroll
@@ -196,13 +272,17 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
     const int dct_c = lane / DCT_SPLIT;
     const bool dct_store = (lane % DCT_SPLIT == 0) && dct_c < n_mfcc;
 
-    // exchange addresses (float2 units), see tools/emulate_wave_fft.py
+    // LDS exchange addresses (float2 units), see tools/emulate_wave_fft.py
     //   A2(beta,p,r=4c+d) = 64p + 16beta + 4(c^p) + d : writer lane (beta,c,d) slot p, reader lane (beta,p,d) slot c
     //   A3(beta,p,o,d)    = 64beta + 16o + 4(d^beta) + p : writer lane (beta,p,d) slot o, reader lane (o,p,beta) slot d
     const int d0 = lane & 3, d1 = (lane >> 2) & 3, d2 = lane >> 4;
     const int w3base = 64 * d2 + 4 * (d0 ^ d2) + d1;        // + 16 o
     const int r3base = 64 * d0 + 16 * d2 + d1;              // + 4 (d ^ beta),  beta = d0
-    const int partner = ((64 - lane) & 63) << 2;
+    (void)xchg; (void)w3base; (void)r3base;
+    const bool bit1 = lane & 2, bit0 = lane & 1;
+    const int kap = T->kappa[lane];                 // this lane ends up with bins 64 t + kap
+    const int partner = T->partner[lane] << 2;      // byte index for ds_bpermute
+    const bool self_paired = kap == 0;              // bins 0/256, 64/192 and 128 pair inside lane 0
 
     // zero the slots that are only ever read
     if (lane == 0) part[kZeroSlot] = 0.0f;
@@ -220,24 +300,42 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
     const float neg_top_db = -args.top_db;
     const int frame_len = args.frame_len;
 
-    auto frame_src = [&]() -> const float * {
-        if (args.frames_per_clip <= 0) return args.in + cur.f * (long)frame_len;
-        return args.in + cur.clip * args.clip_stride + (long)cur.t * args.hop;
+    auto frame_src_of = [&](const FrameCursor &c) -> const float * {
+        if (args.frames_per_clip <= 0) return args.in + c.f * (long)frame_len;
+        return args.in + c.clip * args.clip_stride + (long)c.t * args.hop;
     };
 
-    c32 nxt[4];
-    load_frame<FULL>(frame_src(), lane, frame_len, nxt);
+    // Software prefetch, DSP_PREFETCH frames deep: `pre` runs ahead of `cur` and
+    // each frame buffer is refilled right after its frame has been consumed.
+    FrameCursor pre = cur;
+    auto frame_src = [&]() -> const float * { return frame_src_of(pre); };
+    c32 ring[DSP_PREFETCH][4];
+#pragma unroll
+    for (int d = 0; d < DSP_PREFETCH; ++d) {
+        if (pre.valid()) { load_frame<FULL>(frame_src(), lane, frame_len, ring[d]); pre.next(); }
+    }
 
-    while (true) {
+    auto step = [&](c32 (&nxt)[4]) -> bool {
         const long f = cur.f;
         c32 s[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) s[a] = {nxt[a].x * win[2 * a], nxt[a].y * win[2 * a + 1]};
         cur.next();
         const bool more = cur.valid();
-        if (more) load_frame<FULL>(frame_src(), lane, frame_len, nxt);   // prefetch, hidden by the FFT below
+#if !(DSP_DIAG_MODE & 2)
+        if (pre.valid()) { load_frame<FULL>(frame_src(), lane, frame_len, nxt); pre.next(); }   // hidden by the work below
+#endif
+#if DSP_DIAG_MODE == 1
+        {
+            float c = ((s[0].x + s[0].y) + (s[1].x + s[1].y)) + ((s[2].x + s[2].y) + (s[3].x + s[3].y));
+            c += dpp<DPP_QUAD_1032>(c);
+            if (dct_store) args.out[f * n_mfcc + dct_c] = c;
+            return more;
+        }
+#endif
 
         // ---- 256-point complex FFT, radix-4 DIF --------------------------------
+#if !(DSP_DIAG_MODE & 4)
         radix4(s);                                          // digit a (bits 7:6)
 #pragma unroll
         for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw1[q - 1]);
@@ -249,6 +347,7 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
         radix4(s);                                          // digit b (bits 5:4)
 #pragma unroll
         for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw2[q - 1]);
+#if DSP_X2_LDS
         // exchange 2: slot <-> lane bits 3:2, through LDS
 #pragma unroll
         for (int p = 0; p < 4; ++p) xchg[(lane ^ (4 * p)) + 64 * p] = {s[p].x, s[p].y};
@@ -259,9 +358,17 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
             s[c] = {v.x, v.y};
         }
         wave_lds_sync();
+#else
+        // exchange 2: slot <-> lane bits 3:2, DPP row moves
+        swap_lane8(s[0].x, s[2].x); swap_lane8(s[0].y, s[2].y);
+        swap_lane8(s[1].x, s[3].x); swap_lane8(s[1].y, s[3].y);
+        swap_lane4(s[0].x, s[1].x); swap_lane4(s[0].y, s[1].y);
+        swap_lane4(s[2].x, s[3].x); swap_lane4(s[2].y, s[3].y);
+#endif
         radix4(s);                                          // digit c (bits 3:2)
 #pragma unroll
         for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw3[q - 1]);
+#if DSP_X3_LDS
         // exchange 3: slot <-> lane bits 1:0, through LDS; reader lane = k mod 64
 #pragma unroll
         for (int o = 0; o < 4; ++o) xchg[w3base + 16 * o] = {s[o].x, s[o].y};
@@ -272,17 +379,25 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
             s[dd] = {v.x, v.y};
         }
         wave_lds_sync();
-        radix4(s);                                          // digit d: s[t] = Z[lane + 64 t] / 2
+#else
+        // exchange 3: slot <-> lane bits 1:0, DPP quad permutes
+        swap_quad<DPP_QUAD_2301>(s[0].x, s[2].x, bit1); swap_quad<DPP_QUAD_2301>(s[0].y, s[2].y, bit1);
+        swap_quad<DPP_QUAD_2301>(s[1].x, s[3].x, bit1); swap_quad<DPP_QUAD_2301>(s[1].y, s[3].y, bit1);
+        swap_quad<DPP_QUAD_1032>(s[0].x, s[1].x, bit0); swap_quad<DPP_QUAD_1032>(s[0].y, s[1].y, bit0);
+        swap_quad<DPP_QUAD_1032>(s[2].x, s[3].x, bit0); swap_quad<DPP_QUAD_1032>(s[2].y, s[3].y, bit0);
+#endif
+        radix4(s);                                          // digit d: s[t] = Z[64 t + kap] / 2
+#endif
 
         // ---- packed-real untangling + power spectrum -------------------------
-        // lane l pairs Z[l] with Z[256-l] and Z[l+64] with Z[192-l]; both partners
-        // live in lane 64-l (slots 3 and 2).  Lane 0 pairs inside itself.
+        // the lane with bins kap, kap+64 pairs them with 256-kap and 192-kap; both live
+        // in the partner lane (slots 3 and 2).  Lane 0 (kap = 0) pairs inside itself.
         c32 b, d;
         b.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[3].x)));
         b.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[3].y)));
         d.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[2].x)));
         d.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[2].y)));
-        if (lane == 0) { b = s[0]; d = s[3]; }
+        if (self_paired) { b = s[0]; d = s[3]; }
         float P[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -296,12 +411,18 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
             P[2 * h + 1] = mr * mr + mi * mi;
         }
         const float p128 = 4.0f * (s[2].x * s[2].x + s[2].y * s[2].y);   // lane 0: |Z[128]|^2 un-halved
-        pbuf[lane] = P[0];
-        pbuf[256 - lane] = P[1];
-        pbuf[64 + lane] = P[2];
-        pbuf[192 - lane] = P[3];
-        if (lane == 0) pbuf[128] = p128;
+        pbuf[kap] = P[0];
+        pbuf[256 - kap] = P[1];
+        pbuf[64 + kap] = P[2];
+        pbuf[192 - kap] = P[3];
+        if (self_paired) pbuf[128] = p128;
         wave_lds_sync();
+#if DSP_DIAG_MODE & 8
+        {
+            if (dct_store) args.out[f * n_mfcc + dct_c] = (P[0] + P[1]) + (P[2] + P[3]);
+            return more;
+        }
+#endif
 
         // ---- sparse mel filterbank -------------------------------------------
         float acc = 0.0f;
@@ -318,10 +439,14 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
         // 10 log10(max(e,amin)) - 10 log10(ref) evaluated as one log of the ratio: no
         // cancellation between two ~-100 dB terms, and exactly invariant to a
         // power-of-two gain on the input.
-        const float ref = fmaxf(wave_max(e), amin);
+        // (e, amin, ref are non-negative: their max is an unsigned-integer max of the
+        // bit patterns, which needs no NaN canonicalisation.)
+        const unsigned amin_u = __float_as_uint(amin);
+        const float ref = __uint_as_float(max(__float_as_uint(wave_max_nonneg(e)), amin_u));
+        const float ec = __uint_as_float(max(__float_as_uint(e), amin_u));
         const float k10 = 3.01029995663981195f;            // 10 * log10(2)
-        float db = k10 * __builtin_amdgcn_logf(fmaxf(e, amin) * __builtin_amdgcn_rcpf(ref));
-        db = fminf(fmaxf(db, neg_top_db), 0.0f);            // max over the frame is exactly 0
+        float db = k10 * __builtin_amdgcn_logf(ec * __builtin_amdgcn_rcpf(ref));
+        db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f); // clamp to [-top_db, 0]: the frame max is exactly 0
         if (lane < n_mels) lmel[lane] = db;
         wave_lds_sync();
 
@@ -337,8 +462,14 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
         if (DCT_SPLIT == 4) c += dpp<DPP_QUAD_2301>(c);
         if (dct_store) args.out[f * n_mfcc + dct_c] = c;
         wave_lds_sync();
+        return more;
+    };
 
-        if (!more) break;
+    static_assert(DSP_PREFETCH >= 1 && DSP_PREFETCH <= 3, "prefetch ring depth");
+    while (true) {
+        if (!step(ring[0])) return;
+        if (DSP_PREFETCH > 1 && !step(ring[DSP_PREFETCH > 1 ? 1 : 0])) return;
+        if (DSP_PREFETCH > 2 && !step(ring[DSP_PREFETCH > 2 ? 2 : 0])) return;
     }
 }
 
@@ -366,5 +497,26 @@ hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, i
 }
 
 int mfcc512_lds_bytes_per_block() { return 4 * LDS_WAVE_BYTES; }
+
+// resident 256-thread blocks per CU for the instantiation a plan will launch
+int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full)
+{
+    int n = 0;
+    const size_t lds = 4 * (size_t)LDS_WAVE_BYTES;
+#define DSP_OCC(S, L, G)                                                                                   \
+    if (dct_split == S && dct_len == L && gather == G) {                                                   \
+        hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, true>, 256, lds)   \
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, false>, 256, lds); \
+        return e == hipSuccess && n > 0 ? n : 4;                                                           \
+    }
+    DSP_OCC(4, 10, 3)
+    DSP_OCC(4, 10, 6)
+    DSP_OCC(4, 16, 3)
+    DSP_OCC(4, 16, 6)
+    DSP_OCC(2, 20, 3)
+    DSP_OCC(2, 20, 6)
+#undef DSP_OCC
+    return 4;
+}
 
 }  // namespace dsp

@@ -104,8 +104,20 @@ bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::st
             unit((double)((l & 15) * q) / 64.0, t.tw2[2 * (q - 1)][l], t.tw2[2 * (q - 1) + 1][l]);
             unit((double)((l & 3) * q) / 16.0, t.tw3[2 * (q - 1)][l], t.tw3[2 * (q - 1) + 1][l]);
         }
-        unit((double)l / 512.0, t.twp[0][l], t.twp[1][l]);
-        unit((double)(l + 64) / 512.0, t.twp[2][l], t.twp[3][l]);
+    }
+    // After the FFT lane l holds bins 64 t + kappa(l).  With exchange 3 through LDS
+    // the reader lanes are chosen so that kappa = l; with the register-only (DPP)
+    // exchange lane l = (beta, p, o) (base-4 digits) ends with kappa = 16 o + 4 p + beta.  The
+    // conjugate partner of bin k is bin 256 - k, i.e. kappa' = (64 - kappa) mod 64.
+    int lane_of[kLanes];
+    for (int l = 0; l < kLanes; ++l) {
+        t.kappa[l] = DSP_X3_LDS ? l : 16 * (l & 3) + 4 * ((l >> 2) & 3) + (l >> 4);
+        lane_of[t.kappa[l]] = l;
+    }
+    for (int l = 0; l < kLanes; ++l) {
+        t.partner[l] = lane_of[(64 - t.kappa[l]) & 63];
+        unit((double)t.kappa[l] / 512.0, t.twp[0][l], t.twp[1][l]);
+        unit((double)(t.kappa[l] + 64) / 512.0, t.twp[2][l], t.twp[3][l]);
     }
 
     // sparse mel: every filter's non-zero run is cut into chunks of <= 12 bins,
@@ -114,32 +126,95 @@ bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::st
                                                       cfg.fmax, cfg.mel_norm);
     for (int g = 0; g < kMelGather; ++g)
         for (int l = 0; l < kLanes; ++l) t.mel_src[g][l] = kZeroSlot;
-    int next = 0;
+    struct Chunk { int m, g, first, len, lo, hi; };
+    std::vector<Chunk> chunks;
     for (int m = 0; m < cfg.n_mels; ++m) {
         const float *row = &fb[(size_t)m * n_bins];
         int first = -1, last = -1;
         for (int k = 0; k < n_bins; ++k)
             if (row[k] != 0.0f) { if (first < 0) first = k; last = k; }
         if (first < 0) continue;  // empty filter -> energy 0 (all sources = zero slot)
-        for (int k = first; k <= last; ++k)
-            if (row[k] == 0.0f) { /* interior zero is fine: weight 0 */ }
         int g = 0;
         for (int k = first; k <= last; k += kMelChunk, ++g) {
             if (g >= kMelGather) { why = "a mel filter spans more than 72 bins"; return false; }
-            if (next >= kLanes) { why = "mel filterbank needs more than 64 chunks of 12 bins"; return false; }
             const int len = std::min(kMelChunk, last - k + 1);
-            const int k0 = std::min(k, n_bins - kMelChunk);  // keep every read inside [0, 256]
-            t.mel_k0[next] = k0;
-            for (int i = 0; i < kMelChunk; ++i) {
-                const int kk = k0 + i;
-                t.mel_w[i][next] = (kk >= k && kk < k + len) ? row[kk] : 0.0f;
-            }
-            t.mel_src[g][m] = next;
-            ++next;
+            // the 12-bin read window [k0, k0+12) may slide as long as it covers the
+            // chunk and stays inside [0, 256]
+            const int lo = std::max(0, k + len - kMelChunk), hi = std::min(k, n_bins - kMelChunk);
+            chunks.push_back({m, g, k, len, lo, hi});
             if (g + 1 > t.mel_gather) t.mel_gather = g + 1;
         }
     }
     t.mel_gather = t.mel_gather <= 3 ? 3 : 6;
+    if ((int)chunks.size() > kLanes) { why = "mel filterbank needs more than 64 chunks of 12 bins"; return false; }
+
+    // Placement: ds_read_b32 serves lanes 0-31 and 32-63 in separate passes over 32
+    // banks, so the 12 window reads are conflict free iff the windows of each half
+    // start at distinct addresses mod 32.  Split the chunks over the two halves and
+    // pick each start by bipartite matching (chunk -> residue).
+    const int nc = (int)chunks.size();
+    std::vector<int> half(nc), k0(nc, -1);
+    auto match_half = [&](int h, std::vector<int> &start) -> bool {
+        int owner[32];
+        for (int &o : owner) o = -1;
+        std::vector<int> mine;
+        for (int i = 0; i < nc; ++i) if (half[i] == h) mine.push_back(i);
+        if ((int)mine.size() > 32) return false;
+        std::vector<char> seen;
+        // Kuhn's augmenting paths
+        struct Rec { static bool go(int i, const std::vector<Chunk> &c, int *owner, std::vector<char> &seen,
+                                    std::vector<int> &start) {
+            for (int k = c[i].lo; k <= c[i].hi; ++k) {
+                const int r = k & 31;
+                if (seen[r]) continue;
+                seen[r] = 1;
+                if (owner[r] < 0 || go(owner[r], c, owner, seen, start)) { owner[r] = i; start[i] = k; return true; }
+            }
+            return false; } };
+        for (int i : mine) {
+            seen.assign(32, 0);
+            if (!Rec::go(i, chunks, owner, seen, start)) return false;
+        }
+        return true;
+    };
+    bool placed = false;
+    unsigned rng = 12345u;
+    for (int attempt = 0; attempt < 64 && !placed; ++attempt) {
+        for (int i = 0; i < nc; ++i) {
+            if (attempt == 0) half[i] = i & 1;
+            else { rng = rng * 1664525u + 1013904223u; half[i] = (rng >> 16) & 1; }
+        }
+        std::vector<int> start(nc, -1);
+        if (match_half(0, start) && match_half(1, start)) { k0 = start; placed = true; }
+    }
+    if (!placed) {   // still correct, just not conflict free
+        for (int i = 0; i < nc; ++i) { half[i] = i < 32 ? 0 : 1; k0[i] = chunks[i].hi; }
+    }
+    int used[2] = {0, 0};
+    for (int i = 0; i < nc; ++i) {
+        const Chunk &c = chunks[i];
+        const int lane = 32 * half[i] + used[half[i]]++;
+        const float *row = &fb[(size_t)c.m * n_bins];
+        t.mel_k0[lane] = k0[i];
+        for (int j = 0; j < kMelChunk; ++j) {
+            const int kk = k0[i] + j;
+            t.mel_w[j][lane] = (kk >= c.first && kk < c.first + c.len) ? row[kk] : 0.0f;
+        }
+        t.mel_src[c.g][c.m] = lane;
+    }
+    t.mel_conflict_free = placed ? 1 : 0;
+    // idle lanes (weights all 0) still issue the 12 reads: park them on residues
+    // no live window of their half uses
+    for (int h = 0; h < 2; ++h) {
+        bool taken[32] = {false};
+        for (int l = 0; l < used[h]; ++l) taken[t.mel_k0[32 * h + l] & 31] = true;
+        int r = 0;
+        for (int l = used[h]; l < 32; ++l) {
+            while (r < 32 && taken[r]) ++r;
+            t.mel_k0[32 * h + l] = r < 32 ? r : 0;
+            if (r < 32) taken[r] = true;
+        }
+    }
 
     // DCT: split the n_mels-long dot product over 4 (or 2) neighbouring lanes.
     t.dct_split = cfg.n_mfcc <= 16 ? 4 : 2;

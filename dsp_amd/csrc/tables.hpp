@@ -12,6 +12,16 @@
 
 #include "../../include/dsp_amd.h"
 
+// Exchange implementation of the last two FFT stage boundaries (A/B switches,
+// see DESIGN.md "FFT exchanges"): 1 = through the per-wave LDS tile with XOR
+// swizzles, 0 = DPP register moves.  The final lane -> bin map depends on exchange 3.
+#ifndef DSP_X2_LDS
+#define DSP_X2_LDS 1
+#endif
+#ifndef DSP_X3_LDS
+#define DSP_X3_LDS 1
+#endif
+
 namespace dsp {
 
 // ---- plain tables (reference layouts) --------------------------------------
@@ -36,13 +46,16 @@ struct LaneTables512 {
     float tw1[6][kLanes];   // W256^(l q)
     float tw2[6][kLanes];   // W64^((l%16) q)
     float tw3[6][kLanes];   // W16^((l%4) q)
-    float twp[4][kLanes];   // W512^l, W512^(l+64)
+    float twp[4][kLanes];   // W512^kappa, W512^(kappa+64); kappa(l) = the bin (mod 64) lane l ends up with
+    int32_t kappa[kLanes];  // l (exchange 3 through LDS) or 16*(l&3) + 4*((l>>2)&3) + (l>>4) (DPP)
+    int32_t partner[kLanes];// lane that holds bin (64 - kappa) mod 64
     // sparse mel: lane owns bins [k0, k0+12) of one filter
     int32_t mel_k0[kLanes];
     float mel_w[kMelChunk][kLanes];
     // filter m (lane m) = sum of up to mel_gather partial slots
     int32_t mel_src[kMelGather][kLanes];
     int32_t mel_gather;        // 3 or 6: chunks the widest filter needs, rounded up
+    int32_t mel_conflict_free; // 1 when the window starts of each 32-lane half are distinct mod 32
     // DCT: `split` lanes cooperate on one coefficient; lane = split*c + q
     // multiplies log-mel [q*len, (q+1)*len)
     float dct_w[kDctMaxLen][kLanes];

@@ -47,7 +47,7 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if _build.is_stale():
+    if not os.environ.get("DSP_AMD_LIB") and _build.is_stale():   # an explicit DSP_AMD_LIB is loaded as is
         try:
             _build.build()
         except Exception as e:  # noqa: BLE001

@@ -107,3 +107,112 @@ if __name__ == "__main__":
     P = untangle_power(S * 0.5)
     Pref = np.abs(np.fft.rfft(x)) ** 2
     print("power max rel err", (np.abs(P - Pref) / Pref.max()).max())
+
+
+# ----------------------------------------------------------------------------
+# Register-only variant: exchanges 2 and 3 as DPP moves (no LDS at all in the FFT).
+# update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl) semantics, gfx9:
+# a lane is written when its row / bank is enabled and the source lane exists.
+
+def update_dpp(old, src, ctrl, row_mask=0xF, bank_mask=0xF, bound_ctrl=False):
+    out = old.copy()
+    for lane in range(64):
+        row, within = lane >> 4, lane & 15
+        bank = within >> 2
+        if not (row_mask >> row) & 1 or not (bank_mask >> bank) & 1:
+            continue
+        if ctrl < 0x100:                                   # quad_perm
+            sel = (ctrl >> (2 * (lane & 3))) & 3
+            s = (lane & ~3) | sel
+        elif 0x101 <= ctrl <= 0x10F:                       # row_shl:n  dst[i] = src[i+n]
+            w = within + (ctrl - 0x100)
+            s = None if w > 15 else (row << 4) | w
+        elif 0x111 <= ctrl <= 0x11F:                       # row_shr:n  dst[i] = src[i-n]
+            w = within - (ctrl - 0x110)
+            s = None if w < 0 else (row << 4) | w
+        elif 0x121 <= ctrl <= 0x12F:                       # row_ror:n  dst[i] = src[(i-n) mod 16]
+            s = (row << 4) | ((within - (ctrl - 0x120)) & 15)
+        else:
+            raise ValueError(hex(ctrl))
+        if s is None:
+            if bound_ctrl:
+                out[lane] = 0
+            continue
+        out[lane] = src[s]
+    return out
+
+
+def swap_block(A, B, bit):
+    """2x2 block transpose between register pair (A: slot bit 0, B: slot bit 1) and lane bit `bit`."""
+    lane_bit = (L >> bit) & 1
+    if bit == 3:       # partner lane^8: row_ror:8 either way
+        Bn = update_dpp(B, A, 0x128, 0xF, 0x3)             # lanes with bit3 = 0 (banks 0,1)
+        An = update_dpp(A, B, 0x128, 0xF, 0xC)             # lanes with bit3 = 1 (banks 2,3)
+    elif bit == 2:     # partner lane^4
+        Bn = update_dpp(B, A, 0x104, 0xF, 0x5)             # bit2 = 0 (banks 0,2) read lane+4
+        An = update_dpp(A, B, 0x114, 0xF, 0xA)             # bit2 = 1 (banks 1,3) read lane-4
+    else:              # bits 1, 0: quad_perm + v_cndmask on the lane bit
+        ctrl = 0x4E if bit == 1 else 0xB1                  # [2,3,0,1] / [1,0,3,2]
+        Ap = update_dpp(A, A, ctrl)
+        Bp = update_dpp(B, B, ctrl)
+        Bn = np.where(lane_bit == 0, Ap, B)
+        An = np.where(lane_bit == 1, Bp, A)
+    return An, Bn
+
+
+def wave_fft256_regs(z):
+    """All-register dataflow; returns slots[t][lane] with lane (beta,p,o) holding
+    Z[64 t + kappa(lane)], kappa = 16 o + 4 p + beta."""
+    W = lambda n, k: np.exp(-2j * np.pi * k / n)
+    s = np.stack([z[L + 64 * a] for a in range(4)])
+    s = radix4(s) * np.stack([W(256, L * q) for q in range(4)])
+    beta, r = L >> 4, L & 15
+    s = np.stack([s[beta, 16 * b + r] for b in range(4)])          # exchange 1 (permlane swaps)
+    s = radix4(s) * np.stack([W(64, r * p) for p in range(4)])
+    s = list(s)
+    s[0], s[2] = swap_block(s[0], s[2], 3)                          # exchange 2: slot bit1 <-> lane bit3
+    s[1], s[3] = swap_block(s[1], s[3], 3)
+    s[0], s[1] = swap_block(s[0], s[1], 2)                          #             slot bit0 <-> lane bit2
+    s[2], s[3] = swap_block(s[2], s[3], 2)
+    d = L & 3
+    s = radix4(np.stack(s)) * np.stack([W(16, d * o) for o in range(4)])
+    s = list(s)
+    s[0], s[2] = swap_block(s[0], s[2], 1)                          # exchange 3: slot bit1 <-> lane bit1
+    s[1], s[3] = swap_block(s[1], s[3], 1)
+    s[0], s[1] = swap_block(s[0], s[1], 0)                          #             slot bit0 <-> lane bit0
+    s[2], s[3] = swap_block(s[2], s[3], 0)
+    return radix4(np.stack(s))
+
+
+def kappa(lane):
+    return 16 * (lane & 3) + 4 * ((lane >> 2) & 3) + (lane >> 4)
+
+
+def untangle_power_regs(S):
+    """S[t][lane] = Z[64 t + kappa(lane)] / 2 -> P[0..256]; partner lane holds kappa' = (64 - kappa) % 64."""
+    P = np.zeros(257)
+    kap = kappa(L)
+    inv = np.zeros(64, int); inv[kap] = L
+    partner = inv[(64 - kap) % 64]
+    a, c = S[0], S[1]
+    b = np.where(kap == 0, S[0], S[3][partner])
+    dd = np.where(kap == 0, S[3], S[2][partner])
+    for (u, v, k) in ((a, b, kap), (c, dd, kap + 64)):
+        w = np.exp(-2j * np.pi * k / 512)
+        E, O = u + np.conj(v), u - np.conj(v)
+        T = w * O
+        P[k] = np.abs(E - 1j * T) ** 2
+        P[256 - k] = np.abs(np.conj(E) - 1j * np.conj(T)) ** 2
+    P[128] = np.abs(2 * S[2][0]) ** 2
+    return P, partner
+
+
+if __name__ == "__main__":
+    S2 = wave_fft256_regs(z)
+    got = np.zeros(256, complex)
+    for t in range(4):
+        got[64 * t + kappa(L)] = S2[t]
+    print("register-only fft256 max err", np.abs(got - Z).max())
+    P2, partner = untangle_power_regs(S2 * 0.5)
+    print("register-only power max rel err", (np.abs(P2 - Pref) / Pref.max()).max())
+    print("partner lanes:", partner[:8], "...")

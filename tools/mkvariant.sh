@@ -1,0 +1,10 @@
+#!/bin/bash
+# tools/mkvariant.sh NAME [extra hipcc flags...] -> variants/NAME.so (A/B builds for tools/ab.py)
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+NAME=$1; shift
+mkdir -p "$ROOT/variants"
+cd "$ROOT/dsp_amd/csrc"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -Wno-unused-value \
+    -Rpass-analysis=kernel-resource-usage "$@" -o "$ROOT/variants/$NAME.so" capi.cpp tables.cpp mfcc_kernels.hip 2>&1 \
+    | grep -E "error|VGPRs:|Occupancy \[|ScratchSize" | head -3
