@@ -48,6 +48,21 @@ def host_cpu_share() -> int:
     return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
 
 
+def pmc_traffic(frames_per_launch: int):
+    """HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 x2 read correction), as condensed by tools/summarize_profile.py into profiles/."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+            if d.get("frames_per_launch") == frames_per_launch:
+                best = d
+        except Exception:  # noqa: BLE001
+            pass
+    return best
+
+
 def cpu_baseline(sample_frames: int, seconds_budget: float = 25.0):
     """Time the CPU path on this host.  Only bench.py's baseline leg touches oracle/."""
     import numpy as np
@@ -126,12 +141,13 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     frames = torch.rand((n, FRAME), device=dev, generator=gen) * 2 - 1    # synthetic PCM in [-1, 1)
     out = torch.empty((n, N_MFCC), device=dev)
-    gathered = torch.empty((world * n, N_MFCC), device=dev) if (args.gather and world > 1) else None
+    do_gather = bool(args.gather and world > 1)
+    from dsp_amd.dist import gather_features
 
     def step():
         plan.frames(frames, out)
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered, out)
+        if do_gather:
+            gather_features(out, world * n)      # one RCCL all-gather of the per-rank feature blocks
 
     def sync():
         if world > 1:
@@ -177,12 +193,16 @@ def main():
                                    "Hann(512) -> 512-pt FFT -> 40 HTK mel -> per-frame dB -> 13 DCT-II coeffs, "
                                    "inputs resident in HBM",
                        "frames_per_gpu": n, "frame_length": FRAME, "n_fft": 512, "n_mels": 40, "n_mfcc": N_MFCC,
-                       "gather": bool(gathered is not None), "parallelism": f"frames sharded over {world} rank(s)"},
+                       "gather": do_gather, "parallelism": f"frames sharded over {world} rank(s)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "mfcc512_wave_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_FRAME * n},
         }
+        tr = pmc_traffic(n)
+        if tr:
+            line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/" + tr["source"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(600_000)
         print(json.dumps(line), flush=True)

@@ -1,0 +1,76 @@
+"""CPU, world_size 2, gloo: the N>1 path's sharding + single all-gather.  The
+compute step on CPU is the oracle (tests may use it as a stand-in; the product's
+kernels need a GPU), so this checks partitioning, padding and gather order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dsp_amd import dist as D
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 9, 100, 100_000):
+        for w in (1, 2, 3, 8):
+            spans = [D.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b and c <= d
+            per = -(-n // w) if n else 0
+            assert all(b - a <= per for a, b in spans)
+    # BASELINE config 4: 100 000 clips over 8 GPUs -> 12 500 each
+    assert D.shard_range(100_000, 3, 8) == (37_500, 50_000)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_clips, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from tests import signals as S
+        clips = torch.from_numpy(np.stack([S.uniform_pm1(1200, 50 + i) for i in range(n_clips)]))
+
+        def compute(shard):
+            rows = [O.compute_mfcc(c.numpy(), 500) for c in shard]
+            return torch.from_numpy(np.stack(rows)) if rows else torch.zeros((0, 6, 13))
+
+        got = D.sharded_map(compute, clips)
+        lo, hi = D.shard_range(n_clips, rank, world)
+        q.put((rank, lo, hi, got.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [5, 4, 1])
+def test_two_rank_gather_matches_single_process(n_clips):
+    from oracle import oracle as O
+    from tests import signals as S
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_clips, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([O.compute_mfcc(S.uniform_pm1(1200, 50 + i), 500) for i in range(n_clips)])
+    for rank, lo, hi, got in res:
+        assert got.shape == want.shape            # every rank holds the full, trimmed result
+        assert np.array_equal(got, want)
+    spans = sorted((lo, hi) for _, lo, hi, _ in res)
+    assert spans[0][0] == 0 and spans[-1][1] == n_clips
