@@ -121,6 +121,19 @@ int dsp_mfcc_tables(const dsp_mfcc_config *cfg, float *window, float *mel, float
     return DSP_OK;
 }
 
+int dsp_mfcc_lane_tables(const dsp_mfcc_config *cfg, void *out, int size)
+{
+    if (!cfg) return fail(DSP_EINVAL, "cfg is NULL");
+    if (!out) return (int)sizeof(dsp::LaneTables512);
+    if (size != (int)sizeof(dsp::LaneTables512)) return fail(DSP_EINVAL, "size != sizeof(LaneTables512)");
+    std::string why;
+    auto *t = new dsp::LaneTables512;
+    const bool ok = valid_cfg(*cfg, why) && dsp::build_lane_tables_512(*cfg, *t, why);
+    if (ok) std::memcpy(out, t, sizeof(*t));
+    delete t;
+    return ok ? DSP_OK : fail(DSP_EINVAL, why);
+}
+
 int dsp_butter_bandpass(double lowcut, double highcut, double *b, double *a)
 {
     // donut-classifier/classifier.c:342-360, 383-401: the 16 kHz literal tables
@@ -207,7 +220,9 @@ static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames,
     a.frames_per_clip = frames_per_clip;
     a.hop = p->cfg.hop_length;
     a.frame_len = p->cfg.frame_length;
+    const int nf = dsp::mfcc512_frames_per_item();
     a.chunk = p->chunk > 0 ? p->chunk : 8;
+    a.chunk = ((a.chunk + nf - 1) / nf) * nf;   // whole items per chunk
     a.n_mels = p->cfg.n_mels;
     a.n_mfcc = p->cfg.n_mfcc;
     a.amin = p->cfg.amin;

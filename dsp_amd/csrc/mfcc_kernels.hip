@@ -29,15 +29,17 @@
 
 // Timing-only diagnostic builds (never shipped), -DDSP_DIAG_MODE=<bit mask>:
 //   1 loads + store only, no arithmetic      2 arithmetic only, loads just the first frame
-//   4 skip the FFT       8 skip mel/log/DCT (store a power-spectrum value instead)
-//   32 wave-uniform constants (SGPRs)
 // Outputs are wrong in all of them; only the time is read.
 #ifndef DSP_DIAG_MODE
 #define DSP_DIAG_MODE 0
 #endif
-// frames in flight per wave (each costs 8 VGPRs)
+// items (NF frames each) in flight per wave; each costs 8*NF VGPRs
 #ifndef DSP_PREFETCH
 #define DSP_PREFETCH 2
+#endif
+// frames one wave carries through the pipeline together
+#ifndef DSP_NF
+#define DSP_NF 1
 #endif
 
 namespace dsp {
@@ -161,7 +163,6 @@ constexpr int LDS_PART = 2048 + 64;         // 65 partial sums (+ zero slot)
 constexpr int LDS_LOGMEL = LDS_PART + 320;  // up to 80 log-mel values
 constexpr int LDS_WAVE_BYTES = LDS_LOGMEL + 320;
 static_assert(LDS_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
-
 // wave-uniform cursor over the frames this wave owns: chunks of `chunk`
 // consecutive frames dealt round-robin to the waves of the grid, so one wave's
 // 52-byte outputs land in consecutive cache lines.
@@ -186,17 +187,20 @@ struct FrameCursor {
         clip = clip0; t = t0;
     }
     __device__ __forceinline__ bool valid() const { return f < n; }
-    __device__ __forceinline__ void next()
+    // advance by `step` frames (step divides chunk)
+    __device__ __forceinline__ void next(int step)
     {
-        if (++f >= chunk_end) {
+        f += step;
+        if (f >= chunk_end) {
             chunk_first += stride;
             f = chunk_first;
             chunk_end = f + chunk < n ? f + chunk : n;
             clip0 += jump_clips; t0 += jump_t;
             if (t0 >= fpc) { t0 -= fpc; ++clip0; }
             clip = clip0; t = t0;
-        } else if (++t == fpc) {
-            t = 0; ++clip;
+        } else if (fpc > 0) {
+            t += step;
+            while (t >= fpc) { t -= fpc; ++clip; }
         }
     }
 };
@@ -221,27 +225,34 @@ __device__ __forceinline__ void load_frame(const float *__restrict__ src, int la
 
 }  // namespace
 
-// DCT_SPLIT lanes per coefficient, DCT_LEN log-mel values per lane.
-// GATHER: partial sums per mel filter.  FULL: frame_length == 512 (no tail
-// predicate on the loads).
-template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL>
+// DCT_SPLIT lanes per coefficient, DCT_LEN log-mel values per lane.  GATHER: partial
+// sums per mel filter.  FULL: frame_length == 512 (no tail predicate on the loads).
+// NF: frames one wave carries through the pipeline together.  NF = 2 pays every LDS
+// round trip once per PAIR of frames and lets two independent dependency chains fill
+// each other's latency while the 52 per-lane constants are held once; measured no
+// faster than NF = 1 (the kernel is issue-bound, not latency-bound) and the two
+// unrolled copies may contract FMAs differently, so NF = 1 is the default: every
+// frame runs the same instructions and results do not depend on a frame's position.
+template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL, int NF>
 __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args args)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char *wl = smem + wib * LDS_WAVE_BYTES;
-    float2 *xchg = reinterpret_cast<float2 *>(wl + LDS_XCHG);
-    float *pbuf = reinterpret_cast<float *>(wl + LDS_XCHG);
-    float *part = reinterpret_cast<float *>(wl + LDS_PART);
-    float *lmel = reinterpret_cast<float *>(wl + LDS_LOGMEL);
+    char *wl = smem + wib * (NF * LDS_WAVE_BYTES);
+    float2 *xchg[NF];
+    float *pbuf[NF], *part[NF], *lmel[NF];
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+        xchg[u] = reinterpret_cast<float2 *>(wl + u * LDS_WAVE_BYTES + LDS_XCHG);
+        pbuf[u] = reinterpret_cast<float *>(wl + u * LDS_WAVE_BYTES + LDS_XCHG);
+        part[u] = reinterpret_cast<float *>(wl + u * LDS_WAVE_BYTES + LDS_PART);
+        lmel[u] = reinterpret_cast<float *>(wl + u * LDS_WAVE_BYTES + LDS_LOGMEL);
+    }
 
     const LaneTables512 *__restrict__ T = args.tables;
 
     // ---- per-lane constants (one coalesced dword per field) -----------------
-#if DSP_DIAG_MODE & 32   // timing probe: wave-uniform constants (SGPRs) to see what fewer VGPRs would buy
-#define lane 0
-#endif
     float win[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) win[i] = T->win[i][lane];
@@ -257,18 +268,19 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
     float melw[kMelChunk];
 #pragma unroll
     for (int i = 0; i < kMelChunk; ++i) melw[i] = T->mel_w[i][lane];
-#if DSP_DIAG_MODE & 32
-#undef lane
-#endif
-    const float *mel_rd = pbuf + T->mel_k0[lane];
-    const float *gat[GATHER];
+    const int mel_k0 = T->mel_k0[lane];
+    int gat[GATHER];
 #pragma unroll
-    for (int g = 0; g < GATHER; ++g) gat[g] = part + T->mel_src[g][lane];
-    float dctw[DCT_LEN];
+    for (int g = 0; g < GATHER; ++g) gat[g] = T->mel_src[g][lane];
+    float dctw[(DCT_LEN + 3) & ~3];
 #pragma unroll
     for (int i = 0; i < DCT_LEN; ++i) dctw[i] = T->dct_w[i][lane];
     const int n_mels = args.n_mels, n_mfcc = args.n_mfcc;
-    const float *dct_rd = lmel + (lane % DCT_SPLIT) * DCT_LEN;
+    // log-mel parts are stored 16-byte aligned (stride DCT_STRIDE floats) so each DCT lane
+    // fetches its DCT_LEN values with ds_read_b128 (+ one b64)
+    constexpr int DCT_STRIDE = (DCT_LEN + 3) & ~3;
+    const int dct_rd = (lane % DCT_SPLIT) * DCT_STRIDE;
+    const int lmel_wr = (lane / DCT_LEN) * DCT_STRIDE + lane % DCT_LEN;
     const int dct_c = lane / DCT_SPLIT;
     const bool dct_store = (lane % DCT_SPLIT == 0) && dct_c < n_mfcc;
 
@@ -278,16 +290,20 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
     const int d0 = lane & 3, d1 = (lane >> 2) & 3, d2 = lane >> 4;
     const int w3base = 64 * d2 + 4 * (d0 ^ d2) + d1;        // + 16 o
     const int r3base = 64 * d0 + 16 * d2 + d1;              // + 4 (d ^ beta),  beta = d0
-    (void)xchg; (void)w3base; (void)r3base;
+    (void)w3base; (void)r3base;
     const bool bit1 = lane & 2, bit0 = lane & 1;
+    (void)bit1; (void)bit0;
     const int kap = T->kappa[lane];                 // this lane ends up with bins 64 t + kap
     const int partner = T->partner[lane] << 2;      // byte index for ds_bpermute
     const bool self_paired = kap == 0;              // bins 0/256, 64/192 and 128 pair inside lane 0
 
     // zero the slots that are only ever read
-    if (lane == 0) part[kZeroSlot] = 0.0f;
-    if (lane < 16) lmel[64 + lane] = 0.0f;
-    if (lane < 64) lmel[lane] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+        if (lane == 0) part[u][kZeroSlot] = 0.0f;
+        if (lane < 16) lmel[u][64 + lane] = 0.0f;
+        lmel[u][lane] = 0.0f;
+    }
     wave_lds_sync();
 
     const long wave = (long)blockIdx.x * 4 + wib;
@@ -296,171 +312,219 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
     cur.init(wave, n_waves, args.chunk, args.n_frames, args.frames_per_clip);
     if (!cur.valid()) return;
 
-    const float amin = args.amin;
+    const unsigned amin_u = __float_as_uint(args.amin);
     const float neg_top_db = -args.top_db;
     const int frame_len = args.frame_len;
+    const long n_frames = args.n_frames;
 
-    auto frame_src_of = [&](const FrameCursor &c) -> const float * {
-        if (args.frames_per_clip <= 0) return args.in + c.f * (long)frame_len;
-        return args.in + c.clip * args.clip_stride + (long)c.t * args.hop;
+    // source of frame c.f + u (u < NF)
+    auto frame_src_of = [&](const FrameCursor &c, int u) -> const float * {
+        if (args.frames_per_clip <= 0) return args.in + (c.f + u) * (long)frame_len;
+        long clip = c.clip;
+        int t = c.t + u;
+        while (t >= c.fpc) { t -= c.fpc; ++clip; }
+        return args.in + clip * args.clip_stride + (long)t * args.hop;
+    };
+    auto load_item = [&](const FrameCursor &c, c32 (&z)[NF][4]) {
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            if (u == 0 || c.f + u < n_frames) load_frame<FULL>(frame_src_of(c, u), lane, frame_len, z[u]);
+        }
     };
 
-    // Software prefetch, DSP_PREFETCH frames deep: `pre` runs ahead of `cur` and
-    // each frame buffer is refilled right after its frame has been consumed.
+    // Software prefetch, DSP_PREFETCH items deep: `pre` runs ahead of `cur` and each
+    // buffer is refilled right after its frames have been consumed.
     FrameCursor pre = cur;
-    auto frame_src = [&]() -> const float * { return frame_src_of(pre); };
-    c32 ring[DSP_PREFETCH][4];
+    c32 ring[DSP_PREFETCH][NF][4] = {};
 #pragma unroll
     for (int d = 0; d < DSP_PREFETCH; ++d) {
-        if (pre.valid()) { load_frame<FULL>(frame_src(), lane, frame_len, ring[d]); pre.next(); }
+        if (pre.valid()) { load_item(pre, ring[d]); pre.next(NF); }
     }
 
-    auto step = [&](c32 (&nxt)[4]) -> bool {
+    auto step = [&](c32 (&nxt)[NF][4]) -> bool {
         const long f = cur.f;
-        c32 s[4];
+        c32 s[NF][4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) s[a] = {nxt[a].x * win[2 * a], nxt[a].y * win[2 * a + 1]};
-        cur.next();
+        for (int u = 0; u < NF; ++u)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s[u][a] = {nxt[u][a].x * win[2 * a], nxt[u][a].y * win[2 * a + 1]};
+        cur.next(NF);
         const bool more = cur.valid();
 #if !(DSP_DIAG_MODE & 2)
-        if (pre.valid()) { load_frame<FULL>(frame_src(), lane, frame_len, nxt); pre.next(); }   // hidden by the work below
+        if (pre.valid()) { load_item(pre, nxt); pre.next(NF); }   // hidden by the work below
 #endif
 #if DSP_DIAG_MODE == 1
-        {
-            float c = ((s[0].x + s[0].y) + (s[1].x + s[1].y)) + ((s[2].x + s[2].y) + (s[3].x + s[3].y));
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            float c = ((s[u][0].x + s[u][0].y) + (s[u][1].x + s[u][1].y)) + ((s[u][2].x + s[u][2].y) + (s[u][3].x + s[u][3].y));
             c += dpp<DPP_QUAD_1032>(c);
-            if (dct_store) args.out[f * n_mfcc + dct_c] = c;
-            return more;
+            if (dct_store && f + u < n_frames) args.out[(f + u) * n_mfcc + dct_c] = c;
         }
+        return more;
 #endif
 
         // ---- 256-point complex FFT, radix-4 DIF --------------------------------
-#if !(DSP_DIAG_MODE & 4)
-        radix4(s);                                          // digit a (bits 7:6)
 #pragma unroll
-        for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw1[q - 1]);
-        // exchange 1: slot <-> lane bits 5:4, in registers
-        swap_hi32(s[0].x, s[2].x); swap_hi32(s[0].y, s[2].y);
-        swap_hi32(s[1].x, s[3].x); swap_hi32(s[1].y, s[3].y);
-        swap_odd16(s[0].x, s[1].x); swap_odd16(s[0].y, s[1].y);
-        swap_odd16(s[2].x, s[3].x); swap_odd16(s[2].y, s[3].y);
-        radix4(s);                                          // digit b (bits 5:4)
+        for (int u = 0; u < NF; ++u) {
+            radix4(s[u]);                                          // digit a (bits 7:6)
 #pragma unroll
-        for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw2[q - 1]);
+            for (int q = 1; q < 4; ++q) s[u][q] = cmul(s[u][q], tw1[q - 1]);
+            // exchange 1: slot <-> lane bits 5:4, in registers
+            swap_hi32(s[u][0].x, s[u][2].x); swap_hi32(s[u][0].y, s[u][2].y);
+            swap_hi32(s[u][1].x, s[u][3].x); swap_hi32(s[u][1].y, s[u][3].y);
+            swap_odd16(s[u][0].x, s[u][1].x); swap_odd16(s[u][0].y, s[u][1].y);
+            swap_odd16(s[u][2].x, s[u][3].x); swap_odd16(s[u][2].y, s[u][3].y);
+            radix4(s[u]);                                          // digit b (bits 5:4)
+#pragma unroll
+            for (int q = 1; q < 4; ++q) s[u][q] = cmul(s[u][q], tw2[q - 1]);
+        }
 #if DSP_X2_LDS
         // exchange 2: slot <-> lane bits 3:2, through LDS
 #pragma unroll
-        for (int p = 0; p < 4; ++p) xchg[(lane ^ (4 * p)) + 64 * p] = {s[p].x, s[p].y};
+        for (int u = 0; u < NF; ++u)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) xchg[u][(lane ^ (4 * p)) + 64 * p] = {s[u][p].x, s[u][p].y};
         wave_lds_sync();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float2 v = xchg[64 * d1 + 16 * d2 + 4 * (c ^ d1) + d0];
-            s[c] = {v.x, v.y};
-        }
+        for (int u = 0; u < NF; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float2 v = xchg[u][64 * d1 + 16 * d2 + 4 * (c ^ d1) + d0];
+                s[u][c] = {v.x, v.y};
+            }
         wave_lds_sync();
 #else
         // exchange 2: slot <-> lane bits 3:2, DPP row moves
-        swap_lane8(s[0].x, s[2].x); swap_lane8(s[0].y, s[2].y);
-        swap_lane8(s[1].x, s[3].x); swap_lane8(s[1].y, s[3].y);
-        swap_lane4(s[0].x, s[1].x); swap_lane4(s[0].y, s[1].y);
-        swap_lane4(s[2].x, s[3].x); swap_lane4(s[2].y, s[3].y);
-#endif
-        radix4(s);                                          // digit c (bits 3:2)
 #pragma unroll
-        for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw3[q - 1]);
+        for (int u = 0; u < NF; ++u) {
+            swap_lane8(s[u][0].x, s[u][2].x); swap_lane8(s[u][0].y, s[u][2].y);
+            swap_lane8(s[u][1].x, s[u][3].x); swap_lane8(s[u][1].y, s[u][3].y);
+            swap_lane4(s[u][0].x, s[u][1].x); swap_lane4(s[u][0].y, s[u][1].y);
+            swap_lane4(s[u][2].x, s[u][3].x); swap_lane4(s[u][2].y, s[u][3].y);
+        }
+#endif
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            radix4(s[u]);                                          // digit c (bits 3:2)
+#pragma unroll
+            for (int q = 1; q < 4; ++q) s[u][q] = cmul(s[u][q], tw3[q - 1]);
+        }
 #if DSP_X3_LDS
         // exchange 3: slot <-> lane bits 1:0, through LDS; reader lane = k mod 64
 #pragma unroll
-        for (int o = 0; o < 4; ++o) xchg[w3base + 16 * o] = {s[o].x, s[o].y};
+        for (int u = 0; u < NF; ++u)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) xchg[u][w3base + 16 * o] = {s[u][o].x, s[u][o].y};
         wave_lds_sync();
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-            const float2 v = xchg[r3base + 4 * (dd ^ d0)];
-            s[dd] = {v.x, v.y};
-        }
+        for (int u = 0; u < NF; ++u)
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const float2 v = xchg[u][r3base + 4 * (dd ^ d0)];
+                s[u][dd] = {v.x, v.y};
+            }
         wave_lds_sync();
 #else
         // exchange 3: slot <-> lane bits 1:0, DPP quad permutes
-        swap_quad<DPP_QUAD_2301>(s[0].x, s[2].x, bit1); swap_quad<DPP_QUAD_2301>(s[0].y, s[2].y, bit1);
-        swap_quad<DPP_QUAD_2301>(s[1].x, s[3].x, bit1); swap_quad<DPP_QUAD_2301>(s[1].y, s[3].y, bit1);
-        swap_quad<DPP_QUAD_1032>(s[0].x, s[1].x, bit0); swap_quad<DPP_QUAD_1032>(s[0].y, s[1].y, bit0);
-        swap_quad<DPP_QUAD_1032>(s[2].x, s[3].x, bit0); swap_quad<DPP_QUAD_1032>(s[2].y, s[3].y, bit0);
-#endif
-        radix4(s);                                          // digit d: s[t] = Z[64 t + kap] / 2
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            swap_quad<DPP_QUAD_2301>(s[u][0].x, s[u][2].x, bit1); swap_quad<DPP_QUAD_2301>(s[u][0].y, s[u][2].y, bit1);
+            swap_quad<DPP_QUAD_2301>(s[u][1].x, s[u][3].x, bit1); swap_quad<DPP_QUAD_2301>(s[u][1].y, s[u][3].y, bit1);
+            swap_quad<DPP_QUAD_1032>(s[u][0].x, s[u][1].x, bit0); swap_quad<DPP_QUAD_1032>(s[u][0].y, s[u][1].y, bit0);
+            swap_quad<DPP_QUAD_1032>(s[u][2].x, s[u][3].x, bit0); swap_quad<DPP_QUAD_1032>(s[u][2].y, s[u][3].y, bit0);
+        }
 #endif
 
-        // ---- packed-real untangling + power spectrum -------------------------
+        // ---- last butterfly, packed-real untangling, power spectrum ----------------
         // the lane with bins kap, kap+64 pairs them with 256-kap and 192-kap; both live
         // in the partner lane (slots 3 and 2).  Lane 0 (kap = 0) pairs inside itself.
-        c32 b, d;
-        b.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[3].x)));
-        b.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[3].y)));
-        d.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[2].x)));
-        d.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[2].y)));
-        if (self_paired) { b = s[0]; d = s[3]; }
-        float P[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const c32 u = s[h], v = h == 0 ? b : d;
-            const c32 E = {u.x + v.x, u.y - v.y};           // Z[k] + conj(Z[N-k])
-            const c32 O = {u.x - v.x, u.y + v.y};           // Z[k] - conj(Z[N-k])
-            const c32 Tw = cmul(O, twp[h]);                 // W512^k * O
-            const float xr = E.x + Tw.y, xi = E.y - Tw.x;   // X[k]
-            const float mr = E.x - Tw.y, mi = E.y + Tw.x;   // X[256-k] (conjugated)
-            P[2 * h] = xr * xr + xi * xi;
-            P[2 * h + 1] = mr * mr + mi * mi;
+        for (int u = 0; u < NF; ++u) {
+            radix4(s[u]);                                          // digit d: s[t] = Z[64 t + kap] / 2
+            c32 b, d;
+            b.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[u][3].x)));
+            b.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[u][3].y)));
+            d.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[u][2].x)));
+            d.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[u][2].y)));
+            if (self_paired) { b = s[u][0]; d = s[u][3]; }
+            float P[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const c32 x = s[u][h], v = h == 0 ? b : d;
+                const c32 E = {x.x + v.x, x.y - v.y};           // Z[k] + conj(Z[N-k])
+                const c32 O = {x.x - v.x, x.y + v.y};           // Z[k] - conj(Z[N-k])
+                const c32 Tw = cmul(O, twp[h]);                 // W512^k * O
+                const float xr = E.x + Tw.y, xi = E.y - Tw.x;   // X[k]
+                const float mr = E.x - Tw.y, mi = E.y + Tw.x;   // X[256-k] (conjugated)
+                P[2 * h] = xr * xr + xi * xi;
+                P[2 * h + 1] = mr * mr + mi * mi;
+            }
+            const float p128 = 4.0f * (s[u][2].x * s[u][2].x + s[u][2].y * s[u][2].y);   // lane 0: |Z[128]|^2 un-halved
+            pbuf[u][kap] = P[0];
+            pbuf[u][256 - kap] = P[1];
+            pbuf[u][64 + kap] = P[2];
+            pbuf[u][192 - kap] = P[3];
+            if (self_paired) pbuf[u][128] = p128;
         }
-        const float p128 = 4.0f * (s[2].x * s[2].x + s[2].y * s[2].y);   // lane 0: |Z[128]|^2 un-halved
-        pbuf[kap] = P[0];
-        pbuf[256 - kap] = P[1];
-        pbuf[64 + kap] = P[2];
-        pbuf[192 - kap] = P[3];
-        if (self_paired) pbuf[128] = p128;
         wave_lds_sync();
-#if DSP_DIAG_MODE & 8
-        {
-            if (dct_store) args.out[f * n_mfcc + dct_c] = (P[0] + P[1]) + (P[2] + P[3]);
-            return more;
-        }
-#endif
 
         // ---- sparse mel filterbank -------------------------------------------
-        float acc = 0.0f;
 #pragma unroll
-        for (int i = 0; i < kMelChunk; ++i) acc = fmaf(melw[i], mel_rd[i], acc);
-        part[lane] = acc;
+        for (int u = 0; u < NF; ++u) {
+            const float *rd = pbuf[u] + mel_k0;
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kMelChunk; ++i) acc = fmaf(melw[i], rd[i], acc);
+            part[u][lane] = acc;
+        }
         wave_lds_sync();
-        float e = *gat[0];
+        float e[NF];
 #pragma unroll
-        for (int g = 1; g < GATHER; ++g) e += *gat[g];
-        if (lane >= n_mels) e = 0.0f;
+        for (int u = 0; u < NF; ++u) {
+            e[u] = part[u][gat[0]];
+#pragma unroll
+            for (int g = 1; g < GATHER; ++g) e[u] += part[u][gat[g]];
+            if (lane >= n_mels) e[u] = 0.0f;
+        }
 
         // ---- 10 log10 with per-frame reference (mfcc.c:169-206) ---------------
         // 10 log10(max(e,amin)) - 10 log10(ref) evaluated as one log of the ratio: no
         // cancellation between two ~-100 dB terms, and exactly invariant to a
-        // power-of-two gain on the input.
-        // (e, amin, ref are non-negative: their max is an unsigned-integer max of the
-        // bit patterns, which needs no NaN canonicalisation.)
-        const unsigned amin_u = __float_as_uint(amin);
-        const float ref = __uint_as_float(max(__float_as_uint(wave_max_nonneg(e)), amin_u));
-        const float ec = __uint_as_float(max(__float_as_uint(e), amin_u));
-        const float k10 = 3.01029995663981195f;            // 10 * log10(2)
-        float db = k10 * __builtin_amdgcn_logf(ec * __builtin_amdgcn_rcpf(ref));
-        db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f); // clamp to [-top_db, 0]: the frame max is exactly 0
-        if (lane < n_mels) lmel[lane] = db;
+        // power-of-two gain on the input.  (e, amin, ref are non-negative: their max
+        // is an unsigned-integer max of the bit patterns, no NaN canonicalisation.)
+#pragma unroll
+        for (int u = 0; u < NF; ++u) {
+            const float ref = __uint_as_float(max(__float_as_uint(wave_max_nonneg(e[u])), amin_u));
+            const float ec = __uint_as_float(max(__float_as_uint(e[u]), amin_u));
+            const float k10 = 3.01029995663981195f;            // 10 * log10(2)
+            float db = k10 * __builtin_amdgcn_logf(ec * __builtin_amdgcn_rcpf(ref));
+            db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f); // clamp to [-top_db, 0]: the frame max is exactly 0
+            if (lane < n_mels) lmel[u][lmel_wr] = db;
+        }
         wave_lds_sync();
 
         // ---- DCT-II ------------------------------------------------------------
-        float c = 0.0f;
 #pragma unroll
-        for (int i = 0; i < DCT_LEN; i += 2) {
-            const float2 v = *reinterpret_cast<const float2 *>(dct_rd + i);
-            c = fmaf(dctw[i], v.x, c);
-            c = fmaf(dctw[i + 1], v.y, c);
+        for (int u = 0; u < NF; ++u) {
+            const float *rd = lmel[u] + dct_rd;
+            float c = 0.0f;
+#pragma unroll
+            for (int i = 0; i + 4 <= DCT_LEN; i += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(rd + i);
+                c = fmaf(dctw[i], v.x, c);
+                c = fmaf(dctw[i + 1], v.y, c);
+                c = fmaf(dctw[i + 2], v.z, c);
+                c = fmaf(dctw[i + 3], v.w, c);
+            }
+            if (DCT_LEN % 4) {
+                const float2 v = *reinterpret_cast<const float2 *>(rd + (DCT_LEN & ~3));
+                c = fmaf(dctw[DCT_LEN & ~3], v.x, c);
+                c = fmaf(dctw[(DCT_LEN & ~3) + 1], v.y, c);
+            }
+            c += dpp<DPP_QUAD_1032>(c);
+            if (DCT_SPLIT == 4) c += dpp<DPP_QUAD_2301>(c);
+            if (dct_store && (u == 0 || f + u < n_frames)) args.out[(f + u) * n_mfcc + dct_c] = c;
         }
-        c += dpp<DPP_QUAD_1032>(c);
-        if (DCT_SPLIT == 4) c += dpp<DPP_QUAD_2301>(c);
-        if (dct_store) args.out[f * n_mfcc + dct_c] = c;
         wave_lds_sync();
         return more;
     };
@@ -479,11 +543,11 @@ hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, i
                           hipStream_t stream)
 {
     const bool full = args.frame_len == 512;
-    const size_t lds = 4 * (size_t)LDS_WAVE_BYTES;
+    const size_t lds = (size_t)4 * DSP_NF * LDS_WAVE_BYTES;
 #define DSP_LAUNCH(S, L, G)                                                                                          \
     if (dct_split == S && dct_len == L && gather == G) {                                                             \
-        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true>), dim3(blocks), dim3(256), lds, stream, args);   \
-        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false>), dim3(blocks), dim3(256), lds, stream, args);  \
+        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true, DSP_NF>), dim3(blocks), dim3(256), lds, stream, args);   \
+        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false, DSP_NF>), dim3(blocks), dim3(256), lds, stream, args);  \
         return hipGetLastError();                                                                                    \
     }
     DSP_LAUNCH(4, 10, 3)
@@ -496,17 +560,18 @@ hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, i
     return hipErrorInvalidConfiguration;
 }
 
-int mfcc512_lds_bytes_per_block() { return 4 * LDS_WAVE_BYTES; }
+int mfcc512_lds_bytes_per_block() { return 4 * DSP_NF * LDS_WAVE_BYTES; }
+int mfcc512_frames_per_item() { return DSP_NF; }
 
 // resident 256-thread blocks per CU for the instantiation a plan will launch
 int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full)
 {
     int n = 0;
-    const size_t lds = 4 * (size_t)LDS_WAVE_BYTES;
+    const size_t lds = (size_t)4 * DSP_NF * LDS_WAVE_BYTES;
 #define DSP_OCC(S, L, G)                                                                                   \
     if (dct_split == S && dct_len == L && gather == G) {                                                   \
-        hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, true>, 256, lds)   \
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, false>, 256, lds); \
+        hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, true, DSP_NF>, 256, lds)   \
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, false, DSP_NF>, 256, lds); \
         return e == hipSuccess && n > 0 ? n : 4;                                                           \
     }
     DSP_OCC(4, 10, 3)

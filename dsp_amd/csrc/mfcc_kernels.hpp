@@ -24,6 +24,7 @@ struct Mfcc512Args {
 hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks,
                           hipStream_t stream);
 int mfcc512_lds_bytes_per_block();
+int mfcc512_frames_per_item();   // frames a wave processes together; chunk must be a multiple
 int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full);
 
 }  // namespace dsp

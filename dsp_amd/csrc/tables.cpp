@@ -134,15 +134,19 @@ bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::st
         for (int k = 0; k < n_bins; ++k)
             if (row[k] != 0.0f) { if (first < 0) first = k; last = k; }
         if (first < 0) continue;  // empty filter -> energy 0 (all sources = zero slot)
-        int g = 0;
-        for (int k = first; k <= last; k += kMelChunk, ++g) {
-            if (g >= kMelGather) { why = "a mel filter spans more than 72 bins"; return false; }
-            const int len = std::min(kMelChunk, last - k + 1);
-            // the 12-bin read window [k0, k0+12) may slide as long as it covers the
-            // chunk and stays inside [0, 256]
+        // cut the run into the fewest chunks of <= 12 bins, lengths as even as possible:
+        // shorter-than-12 chunks leave their 12-bin read window room to slide
+        const int run = last - first + 1;
+        const int pieces = (run + kMelChunk - 1) / kMelChunk;
+        if (pieces > kMelGather) { why = "a mel filter spans more than 72 bins"; return false; }
+        int k = first;
+        for (int g = 0; g < pieces; ++g) {
+            const int len = run / pieces + (g < run % pieces ? 1 : 0);
+            // the window [k0, k0+12) must cover the chunk and stay inside [0, 256]
             const int lo = std::max(0, k + len - kMelChunk), hi = std::min(k, n_bins - kMelChunk);
             chunks.push_back({m, g, k, len, lo, hi});
             if (g + 1 > t.mel_gather) t.mel_gather = g + 1;
+            k += len;
         }
     }
     t.mel_gather = t.mel_gather <= 3 ? 3 : 6;
@@ -150,42 +154,30 @@ bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::st
 
     // Placement: ds_read_b32 serves lanes 0-31 and 32-63 in separate passes over 32
     // banks, so the 12 window reads are conflict free iff the windows of each half
-    // start at distinct addresses mod 32.  Split the chunks over the two halves and
-    // pick each start by bipartite matching (chunk -> residue).
+    // start at distinct addresses mod 32.  One bipartite matching (Kuhn): chunk ->
+    // slot (half, start mod 32), 64 slots.
     const int nc = (int)chunks.size();
-    std::vector<int> half(nc), k0(nc, -1);
-    auto match_half = [&](int h, std::vector<int> &start) -> bool {
-        int owner[32];
-        for (int &o : owner) o = -1;
-        std::vector<int> mine;
-        for (int i = 0; i < nc; ++i) if (half[i] == h) mine.push_back(i);
-        if ((int)mine.size() > 32) return false;
-        std::vector<char> seen;
-        // Kuhn's augmenting paths
-        struct Rec { static bool go(int i, const std::vector<Chunk> &c, int *owner, std::vector<char> &seen,
-                                    std::vector<int> &start) {
+    std::vector<int> half(nc, 0), k0(nc, -1);
+    int owner[64];
+    for (int &o : owner) o = -1;
+    std::vector<char> seen;
+    struct Rec { static bool go(int i, const std::vector<Chunk> &c, int *owner, std::vector<char> &seen,
+                                std::vector<int> &half, std::vector<int> &k0) {
+        for (int h = 0; h < 2; ++h)
             for (int k = c[i].lo; k <= c[i].hi; ++k) {
-                const int r = k & 31;
-                if (seen[r]) continue;
-                seen[r] = 1;
-                if (owner[r] < 0 || go(owner[r], c, owner, seen, start)) { owner[r] = i; start[i] = k; return true; }
+                const int slot = 32 * h + (k & 31);
+                if (seen[slot]) continue;
+                seen[slot] = 1;
+                if (owner[slot] < 0 || go(owner[slot], c, owner, seen, half, k0)) {
+                    owner[slot] = i; half[i] = h; k0[i] = k;
+                    return true;
+                }
             }
-            return false; } };
-        for (int i : mine) {
-            seen.assign(32, 0);
-            if (!Rec::go(i, chunks, owner, seen, start)) return false;
-        }
-        return true;
-    };
-    bool placed = false;
-    unsigned rng = 12345u;
-    for (int attempt = 0; attempt < 64 && !placed; ++attempt) {
-        for (int i = 0; i < nc; ++i) {
-            if (attempt == 0) half[i] = i & 1;
-            else { rng = rng * 1664525u + 1013904223u; half[i] = (rng >> 16) & 1; }
-        }
-        std::vector<int> start(nc, -1);
-        if (match_half(0, start) && match_half(1, start)) { k0 = start; placed = true; }
+        return false; } };
+    bool placed = true;
+    for (int i = 0; i < nc && placed; ++i) {
+        seen.assign(64, 0);
+        placed = Rec::go(i, chunks, owner, seen, half, k0);
     }
     if (!placed) {   // still correct, just not conflict free
         for (int i = 0; i < nc; ++i) { half[i] = i < 32 ? 0 : 1; k0[i] = chunks[i].hi; }

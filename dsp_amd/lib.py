@@ -24,6 +24,20 @@ class MfccConfig(C.Structure):
     ]
 
 
+class LaneTables512(C.Structure):
+    """dsp::LaneTables512 (dsp_amd/csrc/tables.hpp): the per-lane kernel layout of the constant tables."""
+
+    _fields_ = [
+        ("win", (C.c_float * 64) * 8), ("tw1", (C.c_float * 64) * 6), ("tw2", (C.c_float * 64) * 6),
+        ("tw3", (C.c_float * 64) * 6), ("twp", (C.c_float * 64) * 4),
+        ("kappa", C.c_int32 * 64), ("partner", C.c_int32 * 64),
+        ("mel_k0", C.c_int32 * 64), ("mel_w", (C.c_float * 64) * 12), ("mel_src", (C.c_int32 * 64) * 6),
+        ("mel_gather", C.c_int32), ("mel_conflict_free", C.c_int32),
+        ("dct_w", (C.c_float * 64) * 20), ("dct_split", C.c_int32), ("dct_len", C.c_int32),
+        ("n_mels", C.c_int32), ("n_mfcc", C.c_int32),
+    ]
+
+
 WINDOW_HANN, WINDOW_HAMMING, WINDOW_RECT = 0, 1, 2
 MELNORM_NONE, MELNORM_SLANEY = 0, 1
 LOG_PER_FRAME_MAX, LOG_GLOBAL_REF1 = 0, 1
@@ -34,7 +48,7 @@ SYMBOLS = [
     "compute_mfcc",
     "dsp_mfcc_default_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
     "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",
-    "dsp_mfcc_clips_host", "dsp_mfcc_plan_set_launch", "dsp_butter_bandpass", "dsp_mfcc_tables",
+    "dsp_mfcc_clips_host", "dsp_mfcc_plan_set_launch", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables",
     "dsp_last_error", "dsp_device_count", "dsp_version",
 ]
 
@@ -82,6 +96,7 @@ def load() -> C.CDLL:
     L.dsp_butter_bandpass.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dsp_butter_bandpass.restype = ip
     L.dsp_mfcc_tables.argtypes = [cfgp, vp, vp, vp]; L.dsp_mfcc_tables.restype = ip
+    L.dsp_mfcc_lane_tables.argtypes = [cfgp, vp, ip]; L.dsp_mfcc_lane_tables.restype = ip
     L.dsp_last_error.argtypes = []; L.dsp_last_error.restype = C.c_char_p
     L.dsp_device_count.argtypes = []; L.dsp_device_count.restype = ip
     L.dsp_version.argtypes = []; L.dsp_version.restype = C.c_char_p

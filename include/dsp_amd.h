@@ -120,6 +120,11 @@ int dsp_butter_bandpass(double lowcut, double highcut, double *b, double *a);
  * dct[n_mfcc][n_mels].  Host-only, no GPU needed; any pointer may be NULL.      */
 int dsp_mfcc_tables(const dsp_mfcc_config *cfg, float *window, float *mel, float *dct);
 
+/* Per-lane kernel layout of the same tables (struct dsp::LaneTables512 of
+ * dsp_amd/csrc/tables.hpp, `size` must equal its sizeof; returns that size when
+ * out is NULL).  Host-only introspection used by the CPU tests of the planner. */
+int dsp_mfcc_lane_tables(const dsp_mfcc_config *cfg, void *out, int size);
+
 /* --- misc -------------------------------------------------------------------- */
 const char *dsp_last_error(void);   /* thread-local, "" when none */
 int dsp_device_count(void);
