@@ -1,0 +1,86 @@
+"""Host-side mirror of the donut classifier interface (sync/lib/classifier.h:14-19,
+donut-classifier/classifier.c:319-592) over the C ABI: same function names and
+argument meaning; numpy arrays stand in for the caller-owned / malloc'd C buffers.
+All arithmetic runs in the HIP kernels of dsp_amd/csrc/classify_kernels.hip.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+
+
+def butter_bandpass(lowcut: float, highcut: float):
+    """-> (ok, b[9], a[9]) float64; ok False for any band but (1000,3000) / (3000,7500)
+    (classifier.c:402-407)."""
+    b = (C.c_double * 9)()
+    a = (C.c_double * 9)()
+    ok = _lib.load().dsp_butter_bandpass(float(lowcut), float(highcut), b, a)
+    return bool(ok), np.array(b[:], np.float64), np.array(a[:], np.float64)
+
+
+def butter_bandpass_filter(data: np.ndarray, b, a) -> np.ndarray:
+    """Direct form II from zero state along the last axis; float32 input runs the fp32
+    firmware arithmetic (classifier.cpp:193-219), float64 the fp64 one (classifier.c:420-446)."""
+    data = np.asarray(data)
+    dt = np.float64 if data.dtype == np.float64 else np.float32
+    x = np.ascontiguousarray(np.atleast_2d(data), dt)
+    y = np.empty_like(x)
+    bb = np.ascontiguousarray(b, dt)
+    aa = np.ascontiguousarray(a, dt)
+    fn = _lib.load().dsp_butter_bandpass_filter_f64 if dt == np.float64 else _lib.load().dsp_butter_bandpass_filter_f32
+    _lib.check(fn(x.ctypes.data, x.shape[0], x.shape[1], x.shape[1], bb.ctypes.data, aa.ctypes.data, y.ctypes.data),
+               "dsp_butter_bandpass_filter")
+    return y.reshape(data.shape)
+
+
+def compute_spectrogram(signal: np.ndarray, fs: int = 16000):
+    """-> (frequencies[129], times[T], Sxx[129][T]) float32 (classifier.cpp:221-368)."""
+    signal = np.ascontiguousarray(signal, np.float32)
+    t_max = max(1, (signal.size - 256) // 224 + 1) if signal.size >= 256 else 1
+    freqs = np.empty(129, np.float32)
+    times = np.empty(t_max, np.float32)
+    sxx = np.empty((129, t_max), np.float32)
+    t = _lib.check(_lib.load().dsp_compute_spectrogram_f32(signal.ctypes.data, signal.size, int(fs), freqs.ctypes.data,
+                                                            times.ctypes.data, sxx.ctypes.data), "dsp_compute_spectrogram_f32")
+    return freqs, times[:t], sxx.reshape(-1)[: 129 * t].reshape(129, t)
+
+
+def classify(data: np.ndarray) -> int:
+    """`int classify(float *data, int data_size)` (sync/lib/classifier.h:19) through the C ABI."""
+    data = np.ascontiguousarray(data, np.float32)
+    return int(_lib.load().dsp_classify(data.ctypes.data, data.size))
+
+
+def classify_batch(clips: np.ndarray, with_trace: bool = False):
+    """clips [n_clips][n] float32 (host) -> labels int32 [n_clips] (+ per-clip midpoints / band sums)."""
+    clips = np.ascontiguousarray(np.atleast_2d(clips), np.float32)
+    n_clips, n = clips.shape
+    labels = np.zeros(n_clips, np.int32)
+    tr = (_lib.ClassifyTrace * n_clips)() if with_trace else None
+    _lib.check(_lib.load().dsp_classify_batch_host(clips.ctypes.data, n_clips, n, n, labels.ctypes.data,
+                                                    C.byref(tr) if with_trace else None), "dsp_classify_batch_host")
+    if not with_trace:
+        return labels
+    out = []
+    for t in tr:
+        k = t.n_midpoints
+        out.append((np.array(t.midpoints[:k], np.float32),
+                    np.array([[t.sums[i][j] for j in range(3)] for i in range(k)], np.float32).reshape(-1, 3)))
+    return labels, out
+
+
+def classify_device(clips, labels=None):
+    """clips: cuda float32 [n_clips][n] -> cuda int32 labels; runs on torch's current stream."""
+    import torch
+    if not (clips.is_cuda and clips.dtype == torch.float32 and clips.dim() == 2 and clips.stride(1) == 1):
+        raise ValueError("clips must be a float32 CUDA tensor [n_clips][n] with unit inner stride")
+    n_clips, n = clips.shape
+    if labels is None:
+        labels = torch.empty(n_clips, dtype=torch.int32, device=clips.device)
+    st = C.c_void_p(torch.cuda.current_stream(clips.device).cuda_stream)
+    _lib.check(_lib.load().dsp_classify_batch_device(clips.data_ptr(), n_clips, n, clips.stride(0), labels.data_ptr(), st),
+               "dsp_classify_batch_device")
+    return labels

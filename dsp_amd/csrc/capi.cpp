@@ -14,6 +14,7 @@
 #include <string>
 
 #include "../../include/dsp_amd.h"
+#include "classify_kernels.hpp"
 #include "mfcc_kernels.hpp"
 #include "tables.hpp"
 
@@ -307,6 +308,227 @@ int dsp_mfcc_clips_host(dsp_mfcc_plan *p, const float *signal, long n_clips, int
     DSP_HIP(hipStreamSynchronize(nullptr));
     return t;
 }
+
+// ---- donut classifier path ------------------------------------------------------------
+
+namespace {
+
+struct ClassifyCtx {
+    int device = -1;
+    dsp::SpecTables *d_tab = nullptr;
+    // workspace for one sub-batch
+    float *d_x = nullptr, *d_bp = nullptr, *d_mp = nullptr, *d_sbp = nullptr, *d_smp = nullptr;
+    int *d_labels = nullptr;
+    dsp::ClassifyTrace *d_trace = nullptr;
+    long cap_clips = 0;
+    int cap_n = 0;
+    std::mutex mu;
+};
+ClassifyCtx g_cls;
+
+static_assert(sizeof(dsp::ClassifyTrace) == sizeof(dsp_classify_trace), "trace layouts must match");
+
+int cls_init()
+{
+    if (g_cls.d_tab) return DSP_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback");
+    const char *dev = std::getenv("DSP_AMD_DEVICE");
+    g_cls.device = dev ? std::atoi(dev) : 0;
+    DSP_HIP(hipSetDevice(g_cls.device));
+    dsp::SpecTables t;
+    dsp::build_spec_tables(16000, t);
+    DSP_HIP(hipMalloc(&g_cls.d_tab, sizeof(t)));
+    DSP_HIP(hipMemcpy(g_cls.d_tab, &t, sizeof(t), hipMemcpyHostToDevice));
+    return DSP_OK;
+}
+
+int spec_bins(int n) { return n < dsp::kSpecSeg ? 0 : (n - dsp::kSpecSeg) / dsp::kSpecHop + 1; }
+
+int cls_reserve(long clips, int n)
+{
+    if (clips <= g_cls.cap_clips && n <= g_cls.cap_n) return DSP_OK;
+    for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_bp, (void *)g_cls.d_mp, (void *)g_cls.d_sbp, (void *)g_cls.d_smp,
+                    (void *)g_cls.d_labels, (void *)g_cls.d_trace})
+        if (p) hipFree(p);
+    g_cls.d_x = g_cls.d_bp = g_cls.d_mp = g_cls.d_sbp = g_cls.d_smp = nullptr;
+    g_cls.d_labels = nullptr; g_cls.d_trace = nullptr;
+    g_cls.cap_clips = 0; g_cls.cap_n = 0;
+    const size_t sig = (size_t)clips * n * sizeof(float);
+    const size_t spec = (size_t)clips * dsp::kSpecBins * std::max(1, spec_bins(n)) * sizeof(float);
+    DSP_HIP(hipMalloc(&g_cls.d_x, sig));
+    DSP_HIP(hipMalloc(&g_cls.d_bp, sig));
+    DSP_HIP(hipMalloc(&g_cls.d_mp, sig));
+    DSP_HIP(hipMalloc(&g_cls.d_sbp, spec));
+    DSP_HIP(hipMalloc(&g_cls.d_smp, spec));
+    DSP_HIP(hipMalloc(&g_cls.d_labels, (size_t)clips * sizeof(int)));
+    DSP_HIP(hipMalloc(&g_cls.d_trace, (size_t)clips * sizeof(dsp::ClassifyTrace)));
+    g_cls.cap_clips = clips; g_cls.cap_n = n;
+    return DSP_OK;
+}
+
+dsp::IirCoef coef_f32(double lo, double hi)
+{
+    double b[9], a[9];
+    dsp_butter_bandpass(lo, hi, b, a);
+    dsp::IirCoef c;
+    for (int i = 0; i < 9; ++i) { c.b[i] = (float)b[i]; c.a[i] = (float)a[i]; }   // classifier.cpp:140-183: float literals
+    return c;
+}
+
+// one sub-batch already resident at d_x (row stride n): labels (+ trace) into the workspace
+int cls_run(const float *d_x, long clips, int n, long stride, hipStream_t st)
+{
+    const dsp::IirCoef bp = coef_f32(3000, 7500), mp = coef_f32(1000, 3000);   // classifier.cpp:14-19, 438-442
+    DSP_HIP(dsp::launch_iir_f32(d_x, clips, n, stride, bp, g_cls.d_bp, mp, g_cls.d_mp, st));
+    // the IIR kernel writes with the input's row stride; the workspace rows are n long
+    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_bp, clips, n, stride, g_cls.d_tab, g_cls.d_sbp, st));
+    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_mp, clips, n, stride, g_cls.d_tab, g_cls.d_smp, st));
+    DSP_HIP(dsp::launch_classify_tail(g_cls.d_sbp, g_cls.d_smp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, st));
+    return DSP_OK;
+}
+
+constexpr long kClsSubBatch = 2048;
+
+}  // namespace
+
+extern "C" {
+
+int dsp_butter_bandpass_filter_f32(const float *data, long n_clips, int n, long stride, const float *b,
+                                   const float *a, float *output)
+{
+    if (!data || !output || !b || !a || n_clips < 0 || n < 0 || (n_clips > 1 && stride < n)) return fail(DSP_EINVAL, "bad argument");
+    if (n_clips == 0 || n == 0) return DSP_OK;
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    int rc = cls_init();
+    if (rc < 0) return rc;
+    DSP_HIP(hipSetDevice(g_cls.device));
+    float *dx = nullptr, *dy = nullptr;
+    const size_t bytes = (size_t)n_clips * n * sizeof(float);
+    DSP_HIP(hipMalloc(&dx, bytes));
+    if (hipMalloc(&dy, bytes) != hipSuccess) { hipFree(dx); return fail(DSP_ENOMEM, "hipMalloc"); }
+    dsp::IirCoef c;
+    for (int i = 0; i < 9; ++i) { c.b[i] = b[i]; c.a[i] = a[i]; }
+    hipError_t e = hipMemcpy2D(dx, (size_t)n * sizeof(float), data, (size_t)stride * sizeof(float), (size_t)n * sizeof(float), n_clips, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dsp::launch_iir_f32(dx, n_clips, n, n, c, dy, c, nullptr, nullptr);
+    if (e == hipSuccess) e = hipMemcpy2D(output, (size_t)stride * sizeof(float), dy, (size_t)n * sizeof(float), (size_t)n * sizeof(float), n_clips, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dy);
+    if (e != hipSuccess) return fail(DSP_EHIP, hipGetErrorString(e));
+    return DSP_OK;
+}
+
+int dsp_butter_bandpass_filter_f64(const double *data, long n_clips, int n, long stride, const double *b,
+                                   const double *a, double *output)
+{
+    if (!data || !output || !b || !a || n_clips < 0 || n < 0 || (n_clips > 1 && stride < n)) return fail(DSP_EINVAL, "bad argument");
+    if (n_clips == 0 || n == 0) return DSP_OK;
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    int rc = cls_init();
+    if (rc < 0) return rc;
+    DSP_HIP(hipSetDevice(g_cls.device));
+    double *dx = nullptr, *dy = nullptr;
+    const size_t bytes = (size_t)n_clips * n * sizeof(double);
+    DSP_HIP(hipMalloc(&dx, bytes));
+    if (hipMalloc(&dy, bytes) != hipSuccess) { hipFree(dx); return fail(DSP_ENOMEM, "hipMalloc"); }
+    dsp::IirCoefD c;
+    for (int i = 0; i < 9; ++i) { c.b[i] = b[i]; c.a[i] = a[i]; }
+    hipError_t e = hipMemcpy2D(dx, (size_t)n * sizeof(double), data, (size_t)stride * sizeof(double), (size_t)n * sizeof(double), n_clips, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dsp::launch_iir_f64(dx, n_clips, n, n, c, dy, nullptr);
+    if (e == hipSuccess) e = hipMemcpy2D(output, (size_t)stride * sizeof(double), dy, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n_clips, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dy);
+    if (e != hipSuccess) return fail(DSP_EHIP, hipGetErrorString(e));
+    return DSP_OK;
+}
+
+int dsp_compute_spectrogram_f32(const float *signal, int n, int fs, float *frequencies, float *times, float *sxx)
+{
+    if (!signal || !sxx || n < 0) return fail(DSP_EINVAL, "bad argument");
+    if (fs != 16000) return fail(DSP_EINVAL, "only fs = 16000 (the reference's samplingFreq) is tabulated");
+    const int T = spec_bins(n);
+    if (frequencies)
+        for (int k = 0; k < dsp::kSpecBins; ++k) frequencies[k] = (float)k * (float)fs / (float)dsp::kSpecSeg;   // classifier.cpp:248-251
+    if (times)
+        for (int t = 0; t < T; ++t) times[t] = ((float)(t * dsp::kSpecHop + dsp::kSpecSeg / 2)) / (float)fs;     // :254-258
+    if (T == 0) return 0;
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    int rc = cls_init();
+    if (rc < 0) return rc;
+    DSP_HIP(hipSetDevice(g_cls.device));
+    float *dx = nullptr, *ds = nullptr;
+    DSP_HIP(hipMalloc(&dx, (size_t)n * sizeof(float)));
+    const size_t sb = (size_t)dsp::kSpecBins * T * sizeof(float);
+    if (hipMalloc(&ds, sb) != hipSuccess) { hipFree(dx); return fail(DSP_ENOMEM, "hipMalloc"); }
+    hipError_t e = hipMemcpy(dx, signal, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dsp::launch_spectrogram_f32(dx, 1, n, n, g_cls.d_tab, ds, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(sxx, ds, sb, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(ds);
+    if (e != hipSuccess) return fail(DSP_EHIP, hipGetErrorString(e));
+    return T;
+}
+
+int dsp_classify_batch_host(const float *signal, long n_clips, int n, long stride, int *labels,
+                            dsp_classify_trace *trace)
+{
+    if (!signal || !labels || n_clips < 0 || n < 0 || (n_clips > 1 && stride < n)) return fail(DSP_EINVAL, "bad argument");
+    if (spec_bins(n) > 1024) return fail(DSP_EINVAL, "clip too long (more than 1024 spectrogram columns)");
+    if (spec_bins(n) == 0) {      // clips shorter than one segment cannot fire the rule
+        for (long c = 0; c < n_clips; ++c) labels[c] = 0;
+        if (trace) std::memset(trace, 0, sizeof(*trace) * (size_t)n_clips);
+        return DSP_OK;
+    }
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    int rc = cls_init();
+    if (rc < 0) return rc;
+    DSP_HIP(hipSetDevice(g_cls.device));
+    for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
+        const long cnt = std::min(kClsSubBatch, n_clips - c0);
+        if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n)) < 0) return rc;
+        DSP_HIP(hipMemcpy2DAsync(g_cls.d_x, (size_t)n * sizeof(float), signal + c0 * stride, (size_t)stride * sizeof(float),
+                                 (size_t)n * sizeof(float), cnt, hipMemcpyHostToDevice, nullptr));
+        if ((rc = cls_run(g_cls.d_x, cnt, n, n, nullptr)) < 0) return rc;
+        DSP_HIP(hipMemcpyAsync(labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+        if (trace) DSP_HIP(hipMemcpyAsync(trace + c0, g_cls.d_trace, (size_t)cnt * sizeof(dsp::ClassifyTrace), hipMemcpyDeviceToHost, nullptr));
+        DSP_HIP(hipStreamSynchronize(nullptr));
+    }
+    return DSP_OK;
+}
+
+int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long stride, int *d_labels, void *stream)
+{
+    if (!d_signal || !d_labels || n_clips < 0 || n < 0 || (n_clips > 1 && stride < n)) return fail(DSP_EINVAL, "bad argument");
+    if (spec_bins(n) > 1024) return fail(DSP_EINVAL, "clip too long (more than 1024 spectrogram columns)");
+    if (n_clips == 0) return DSP_OK;
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    int rc = cls_init();
+    if (rc < 0) return rc;
+    DSP_HIP(hipSetDevice(g_cls.device));
+    hipStream_t st = (hipStream_t)stream;
+    if (spec_bins(n) == 0) { DSP_HIP(hipMemsetAsync(d_labels, 0, (size_t)n_clips * sizeof(int), st)); DSP_HIP(hipStreamSynchronize(st)); return DSP_OK; }
+    for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
+        const long cnt = std::min(kClsSubBatch, n_clips - c0);
+        // the kernels write filtered rows with the input's stride: size the workspace for it
+        if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), (int)std::max<long>(n, stride))) < 0) return rc;
+        if ((rc = cls_run(d_signal + c0 * stride, cnt, n, stride, st)) < 0) return rc;
+        DSP_HIP(hipMemcpyAsync(d_labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, st));
+        DSP_HIP(hipStreamSynchronize(st));
+    }
+    return DSP_OK;
+}
+
+// sync/lib/classifier.h:19.  Same contract: 0/1, 0 also on failure (reason in dsp_last_error()).
+int dsp_classify(float *data, int data_size)
+{
+    int label = 0;
+    if (!data || data_size <= 0) { fail(DSP_EINVAL, "bad argument"); return 0; }
+    const int rc = dsp_classify_batch_host(data, 1, data_size, data_size, &label, nullptr);
+    if (rc < 0) {
+        std::fprintf(stderr, "libdsp_amd: classify: %s\n", dsp_last_error());
+        return 0;
+    }
+    return label;
+}
+
+}  // extern "C"
 
 // ---- the reference's entry point ------------------------------------------------
 

@@ -1,0 +1,50 @@
+// classify_kernels.hpp -- launch interface of classify_kernels.hip (Butterworth IIR,
+// scipy-default spectrogram, scrub-jay rule; reference sync/lib/classifier.cpp and
+// donut-classifier/classifier.c).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+namespace dsp {
+
+constexpr int kSpecSeg = 256;    // nperseg            classifier.cpp:223
+constexpr int kSpecHop = 224;    // nperseg - nperseg/8 classifier.cpp:224-225
+constexpr int kSpecBins = 129;   // nfft/2 + 1         classifier.cpp:235
+constexpr int kMaxMidpoints = 64;
+
+struct SpecTables {
+    float window[kSpecSeg];      // periodic Tukey(0.25), evaluated on the host like classifier.cpp:259-293
+    float U;                     // fs * sum(window^2), classifier.cpp:296-301
+    // PlainFFT twiddles: (u1,u2) for level l (8 levels) and column m < 2^l, produced by the
+    // reference's own recurrence (PlainFFT.cpp:52-84) so every butterfly sees the same bits
+    float tw_re[255], tw_im[255];   // level l starts at (1<<l) - 1
+};
+
+struct IirCoef { float b[9], a[9]; };
+struct IirCoefD { double b[9], a[9]; };
+
+// y[c][i] for n_clips clips of n samples (row stride `stride` floats), direct form II from
+// zero state per clip.  Two filters are run in one pass over x when y2 != nullptr.
+hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, const IirCoef &c1, float *y1,
+                          const IirCoef &c2, float *y2, hipStream_t stream);
+hipError_t launch_iir_f64(const double *x, long n_clips, int n, long stride, const IirCoefD &c, double *y,
+                          hipStream_t stream);
+
+// sxx[c][129][T] (T = (n-256)/224+1) of clip rows y[c][0..n)
+hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
+                                  float *sxx, hipStream_t stream);
+
+struct ClassifyTrace {           // per clip, for parity tests
+    int n_midpoints;
+    float midpoints[kMaxMidpoints];
+    float sums[kMaxMidpoints][3];
+};
+
+// labels[c] from the two spectrograms (band-pass 3000-7500 and 1000-3000), classifier.cpp:35-135.
+// Both sxx buffers are overwritten with their dB maps.  trace may be nullptr.
+hipError_t launch_classify_tail(float *sxx_bp, float *sxx_mp, long n_clips, int n, int fs, int *labels,
+                                ClassifyTrace *trace, hipStream_t stream);
+
+void build_spec_tables(int fs, SpecTables &t);
+
+}  // namespace dsp

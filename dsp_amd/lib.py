@@ -38,6 +38,12 @@ class LaneTables512(C.Structure):
     ]
 
 
+class ClassifyTrace(C.Structure):
+    """dsp_classify_trace (include/dsp_amd.h)."""
+
+    _fields_ = [("n_midpoints", C.c_int), ("midpoints", C.c_float * 64), ("sums", (C.c_float * 3) * 64)]
+
+
 WINDOW_HANN, WINDOW_HAMMING, WINDOW_RECT = 0, 1, 2
 MELNORM_NONE, MELNORM_SLANEY = 0, 1
 LOG_PER_FRAME_MAX, LOG_GLOBAL_REF1 = 0, 1
@@ -45,7 +51,9 @@ PREFILTER_NONE, PREFILTER_BUTTER_1000_3000, PREFILTER_BUTTER_3000_7500 = 0, 1, 2
 
 # every symbol include/dsp_amd.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "compute_mfcc",
+    "compute_mfcc", "dsp_classify",
+    "dsp_butter_bandpass_filter_f32", "dsp_butter_bandpass_filter_f64", "dsp_compute_spectrogram_f32",
+    "dsp_classify_batch_host", "dsp_classify_batch_device",
     "dsp_mfcc_default_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
     "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",
     "dsp_mfcc_clips_host", "dsp_mfcc_plan_set_launch", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables",
@@ -97,6 +105,12 @@ def load() -> C.CDLL:
     L.dsp_butter_bandpass.restype = ip
     L.dsp_mfcc_tables.argtypes = [cfgp, vp, vp, vp]; L.dsp_mfcc_tables.restype = ip
     L.dsp_mfcc_lane_tables.argtypes = [cfgp, vp, ip]; L.dsp_mfcc_lane_tables.restype = ip
+    L.dsp_classify.argtypes = [vp, ip]; L.dsp_classify.restype = ip
+    L.dsp_butter_bandpass_filter_f32.argtypes = [vp, C.c_long, ip, C.c_long, vp, vp, vp]; L.dsp_butter_bandpass_filter_f32.restype = ip
+    L.dsp_butter_bandpass_filter_f64.argtypes = [vp, C.c_long, ip, C.c_long, vp, vp, vp]; L.dsp_butter_bandpass_filter_f64.restype = ip
+    L.dsp_compute_spectrogram_f32.argtypes = [vp, ip, ip, vp, vp, vp]; L.dsp_compute_spectrogram_f32.restype = ip
+    L.dsp_classify_batch_host.argtypes = [vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_batch_host.restype = ip
+    L.dsp_classify_batch_device.argtypes = [vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_batch_device.restype = ip
     L.dsp_last_error.argtypes = []; L.dsp_last_error.restype = C.c_char_p
     L.dsp_device_count.argtypes = []; L.dsp_device_count.restype = ip
     L.dsp_version.argtypes = []; L.dsp_version.restype = C.c_char_p

@@ -36,6 +36,14 @@ extern "C" {
  * Caller owns both buffers (host memory); out_mfcc holds max_frames*13 floats. */
 int compute_mfcc(const float *signal, int num_samples, float *out_mfcc, int max_frames);
 
+/* Replaces sync/lib/classifier.h:19 (definition classifier.cpp:9-136; fp32 firmware
+ * twin of donut-classifier/classifier.c:30-212).  16 kHz mono clip -> 1 if the scrub-jay
+ * rule fires, else 0 (also 0 on internal failure, classifier.cpp:87-91).  The reference
+ * header is C++ without extern "C": this C symbol is `dsp_classify`; INTEGRATION.md
+ * shows the one-line C++ shim that gives sync.cpp its `classify`.  Caller owns `data`
+ * (host memory); unlike the reference nothing is printed.                          */
+int dsp_classify(float *data, int data_size);
+
 /* ===================================================================== */
 /* 2. Extensions                                                          */
 /* ===================================================================== */
@@ -114,6 +122,38 @@ int dsp_mfcc_plan_set_launch(dsp_mfcc_plan *plan, int blocks_per_cu, int frames_
 /* Literal 9-tap tables of classifier.c:342-360 / 383-401; returns 1, or 0 for
  * any other band (the reference prints "invalid bandpass range").              */
 int dsp_butter_bandpass(double lowcut, double highcut, double *b, double *a);
+
+/* butter_bandpass_filter (sync/lib/classifier.cpp:193-219 fp32, donut-classifier/
+ * classifier.c:420-446 fp64): direct form II from zero state over n_clips rows of n
+ * samples (row stride in elements), bit-identical to the reference's operation order.
+ * Host pointers; b and a hold 9 taps each.                                        */
+int dsp_butter_bandpass_filter_f32(const float *data, long n_clips, int n, long stride,
+                                   const float *b, const float *a, float *output);
+int dsp_butter_bandpass_filter_f64(const double *data, long n_clips, int n, long stride,
+                                   const double *b, const double *a, double *output);
+
+/* compute_spectrogram (sync/lib/classifier.cpp:221-368): nperseg 256, hop 224, detrend,
+ * periodic Tukey(0.25), PSD.  Flat outputs instead of the reference's malloc'd rows:
+ * frequencies[129], times[T], sxx[129][T]; returns T = (n-256)/224+1 (0 if n < 256).
+ * Host pointers; frequencies / times may be NULL.                                 */
+int dsp_compute_spectrogram_f32(const float *signal, int signal_length, int fs,
+                                float *frequencies, float *times, float *sxx);
+
+/* Per-clip trace of classify() for parity tests: midpoints (classifier.cpp:433-598) and
+ * the three band sums per midpoint (classifier.cpp:99-101).                       */
+typedef struct dsp_classify_trace {
+    int n_midpoints;
+    float midpoints[64];
+    float sums[64][3];   /* above (5-7 kHz), middle (2.5-5 kHz), below (0.5-2.5 kHz) */
+} dsp_classify_trace;
+
+/* classify() over n_clips clips of n samples (row stride in floats).  labels[n_clips];
+ * trace may be NULL.  _host: host pointers; _device: HBM pointers, enqueued on `stream`
+ * and synchronised before returning (the workspace is reused across calls).       */
+int dsp_classify_batch_host(const float *signal, long n_clips, int n, long stride, int *labels,
+                            dsp_classify_trace *trace);
+int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long stride, int *d_labels,
+                              void *stream);
 
 /* Reference-layout constant tables for a configuration (what mfcc_params.h holds
  * for the reference config): window[frame_length], mel[n_mels][n_fft/2+1],
