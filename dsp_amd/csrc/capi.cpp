@@ -16,6 +16,7 @@
 #include "../../include/dsp_amd.h"
 #include "classify_kernels.hpp"
 #include "mfcc_kernels.hpp"
+#include "svm_kernels.hpp"
 #include "tables.hpp"
 
 namespace {
@@ -526,6 +527,68 @@ int dsp_classify(float *data, int data_size)
         return 0;
     }
     return label;
+}
+
+}  // extern "C"
+
+// ---- pooling + SVM ---------------------------------------------------------------------
+
+struct dsp_svm {
+    int device = 0;
+    dsp::SvmModelDev m{};
+    float *d_blob = nullptr;
+};
+
+extern "C" {
+
+int dsp_mfcc_stats_device(const float *d_mfcc, long n_clips, int n_frames, int n_coef, float *d_feat, void *stream)
+{
+    if (n_clips < 0 || n_frames <= 0 || n_coef <= 0 || n_coef > 64 || (n_clips > 0 && (!d_mfcc || !d_feat)))
+        return fail(DSP_EINVAL, "bad argument");
+    DSP_HIP(dsp::launch_mfcc_stats(d_mfcc, n_clips, n_frames, n_coef, d_feat, (hipStream_t)stream));
+    return DSP_OK;
+}
+
+int dsp_svm_create(int device, int n_features, int n_sv, const float *offset, const float *scale,
+                   const float *support_vectors, const float *coefficients, float gamma, float rho, float prob_a,
+                   float prob_b, dsp_svm **out)
+{
+    if (!out || !offset || !scale || !support_vectors || !coefficients || n_features <= 0 || n_features > 256 || n_sv <= 0)
+        return fail(DSP_EINVAL, "bad argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback");
+    if (device < 0 || device >= n) return fail(DSP_EINVAL, "device index out of range");
+    DSP_HIP(hipSetDevice(device));
+    auto *s = new dsp_svm;
+    s->device = device;
+    const size_t nf = n_features, ns = n_sv, total = 2 * nf + ns * nf + ns;
+    if (hipMalloc(&s->d_blob, total * sizeof(float)) != hipSuccess) { delete s; return fail(DSP_ENOMEM, "hipMalloc"); }
+    float *p = s->d_blob;
+    hipError_t e = hipMemcpy(p, offset, nf * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p + nf, scale, nf * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p + 2 * nf, support_vectors, ns * nf * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p + 2 * nf + ns * nf, coefficients, ns * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(s->d_blob); delete s; return fail(DSP_EHIP, hipGetErrorString(e)); }
+    s->m = {n_features, n_sv, gamma, rho, prob_a, prob_b, p, p + nf, p + 2 * nf, p + 2 * nf + ns * nf};
+    *out = s;
+    return DSP_OK;
+}
+
+void dsp_svm_destroy(dsp_svm *s)
+{
+    if (!s) return;
+    hipSetDevice(s->device);
+    if (s->d_blob) hipFree(s->d_blob);
+    delete s;
+}
+
+int dsp_svm_predict_device(dsp_svm *s, const float *d_feat, long n_clips, int *d_labels, float *d_decision,
+                           float *d_prob1, void *stream)
+{
+    if (!s || n_clips < 0 || (n_clips > 0 && (!d_feat || !d_labels))) return fail(DSP_EINVAL, "bad argument");
+    DSP_HIP(dsp::launch_svm_predict(s->m, d_feat, n_clips, d_labels, d_decision, d_prob1, (hipStream_t)stream));
+    return DSP_OK;
 }
 
 }  // extern "C"

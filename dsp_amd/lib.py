@@ -54,6 +54,7 @@ SYMBOLS = [
     "compute_mfcc", "dsp_classify",
     "dsp_butter_bandpass_filter_f32", "dsp_butter_bandpass_filter_f64", "dsp_compute_spectrogram_f32",
     "dsp_classify_batch_host", "dsp_classify_batch_device",
+    "dsp_mfcc_stats_device", "dsp_svm_create", "dsp_svm_destroy", "dsp_svm_predict_device",
     "dsp_mfcc_default_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
     "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",
     "dsp_mfcc_clips_host", "dsp_mfcc_plan_set_launch", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables",
@@ -111,6 +112,11 @@ def load() -> C.CDLL:
     L.dsp_compute_spectrogram_f32.argtypes = [vp, ip, ip, vp, vp, vp]; L.dsp_compute_spectrogram_f32.restype = ip
     L.dsp_classify_batch_host.argtypes = [vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_batch_host.restype = ip
     L.dsp_classify_batch_device.argtypes = [vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_batch_device.restype = ip
+    L.dsp_mfcc_stats_device.argtypes = [vp, C.c_long, ip, ip, vp, vp]; L.dsp_mfcc_stats_device.restype = ip
+    L.dsp_svm_create.argtypes = [ip, ip, ip, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(vp)]
+    L.dsp_svm_create.restype = ip
+    L.dsp_svm_destroy.argtypes = [vp]; L.dsp_svm_destroy.restype = None
+    L.dsp_svm_predict_device.argtypes = [vp, vp, C.c_long, vp, vp, vp, vp]; L.dsp_svm_predict_device.restype = ip
     L.dsp_last_error.argtypes = []; L.dsp_last_error.restype = C.c_char_p
     L.dsp_device_count.argtypes = []; L.dsp_device_count.restype = ip
     L.dsp_version.argtypes = []; L.dsp_version.restype = C.c_char_p

@@ -1,0 +1,82 @@
+"""Host-side mirror of cepstrum/scrubjay_infer.c: clip -> MFCC -> mean|std pooling
+(`mfcc_stats`, :19-77) -> Scaler + RBF-SVM (`ort_predict`, :105-141, graph
+cepstrum/scrubjay_svm.onnx) over the C ABI, all on HBM-resident tensors.
+
+The reference's MFCC front end is aubio (unvendored, unpinned) with a 2048/1024 framing;
+here the front end is this library's MFCC chain with `n_mfcc = 20`,
+so feature VALUES are not comparable with the reference's -- the pooling and the SVM
+arithmetic are.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .mfcc import MfccPlan, default_config
+
+
+class SvmModel:
+    """dsp_svm: Scaler + SVMClassifier attributes as decoded from the ONNX file."""
+
+    def __init__(self, attrs: dict, device: int = 0):
+        self._L = _lib.load()
+        a = {k: np.ascontiguousarray(attrs[k], np.float32) for k in ("offset", "scale", "sv", "coef")}
+        self.n_features = a["offset"].size
+        self.n_sv = a["coef"].size
+        assert a["sv"].shape == (self.n_sv, self.n_features)
+        h = C.c_void_p()
+        _lib.check(self._L.dsp_svm_create(device, self.n_features, self.n_sv, a["offset"].ctypes.data, a["scale"].ctypes.data,
+                                          a["sv"].ctypes.data, a["coef"].ctypes.data,
+                                          float(np.ravel(attrs["kernel_params"])[0]), float(np.ravel(attrs["rho"])[0]),
+                                          float(np.ravel(attrs["prob_a"])[0]), float(np.ravel(attrs["prob_b"])[0]), C.byref(h)),
+                   "dsp_svm_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dsp_svm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def predict(self, feat):
+        """feat: cuda float32 [n][n_features] -> (labels int32, decision float32, prob1 float32)."""
+        import torch
+        n = feat.shape[0]
+        labels = torch.empty(n, dtype=torch.int32, device=feat.device)
+        dec = torch.empty(n, dtype=torch.float32, device=feat.device)
+        p1 = torch.empty(n, dtype=torch.float32, device=feat.device)
+        st = C.c_void_p(torch.cuda.current_stream(feat.device).cuda_stream)
+        _lib.check(self._L.dsp_svm_predict_device(self._h, feat.contiguous().data_ptr(), n, labels.data_ptr(), dec.data_ptr(),
+                                                  p1.data_ptr(), st), "dsp_svm_predict_device")
+        return labels, dec, p1
+
+
+def mfcc_stats(mfcc):
+    """mfcc: cuda float32 [n_clips][T][n_coef] -> cuda float32 [n_clips][2*n_coef] (mean | std)."""
+    import torch
+    n, t, c = mfcc.shape
+    feat = torch.empty((n, 2 * c), dtype=torch.float32, device=mfcc.device)
+    st = C.c_void_p(torch.cuda.current_stream(mfcc.device).cuda_stream)
+    _lib.check(_lib.load().dsp_mfcc_stats_device(mfcc.contiguous().data_ptr(), n, t, c, feat.data_ptr(), st), "dsp_mfcc_stats_device")
+    return feat
+
+
+class ScrubJay:
+    """clips -> label / probability, the scrubjay_infer.c main loop (:158-177) for a batch in HBM."""
+
+    def __init__(self, svm_attrs: dict, device: int = 0, n_mfcc: int = 20):
+        self.plan = MfccPlan(default_config(n_mfcc=n_mfcc), device)
+        self.svm = SvmModel(svm_attrs, device)
+
+    def __call__(self, clips, max_frames: int = 1 << 20):
+        mfcc = self.plan.clips(clips, max_frames)
+        feat = mfcc_stats(mfcc)
+        return self.svm.predict(feat) + (feat,)

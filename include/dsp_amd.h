@@ -155,6 +155,24 @@ int dsp_classify_batch_host(const float *signal, long n_clips, int n, long strid
 int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long stride, int *d_labels,
                               void *stream);
 
+/* --- pooling + SVM (cepstrum/scrubjay_infer.c:36-66, 105-141; scrubjay_svm.onnx) ------ */
+
+/* mfcc_stats pooling: feat[c][2*n_coef] = per-coefficient mean | population std over the T
+ * frames of clip c, float64 accumulators in frame order.  HBM pointers.            */
+int dsp_mfcc_stats_device(const float *d_mfcc, long n_clips, int n_frames, int n_coef, float *d_feat, void *stream);
+
+typedef struct dsp_svm dsp_svm;   /* opaque: Scaler + RBF SVMClassifier + Platt on one GPU */
+/* Attributes as stored in the ONNX graph (Scaler.offset/scale, SVMClassifier.support_vectors
+ * [n_sv][n_features], coefficients[n_sv], kernel_params[0] = gamma, rho[0], prob_a[0], prob_b[0]). */
+int dsp_svm_create(int device, int n_features, int n_sv, const float *offset, const float *scale,
+                   const float *support_vectors, const float *coefficients, float gamma, float rho,
+                   float prob_a, float prob_b, dsp_svm **out);
+void dsp_svm_destroy(dsp_svm *svm);
+/* labels (0/1), decision values and P(label 1) for n_clips feature rows; HBM pointers,
+ * d_decision / d_prob1 may be NULL.                                               */
+int dsp_svm_predict_device(dsp_svm *svm, const float *d_feat, long n_clips, int *d_labels, float *d_decision,
+                           float *d_prob1, void *stream);
+
 /* Reference-layout constant tables for a configuration (what mfcc_params.h holds
  * for the reference config): window[frame_length], mel[n_mels][n_fft/2+1],
  * dct[n_mfcc][n_mels].  Host-only, no GPU needed; any pointer may be NULL.      */

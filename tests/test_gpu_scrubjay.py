@@ -1,0 +1,72 @@
+"""GPU: pooling (scrubjay_infer.c:36-66) and the decoded ONNX SVM through the C ABI against
+the CPU oracle; floating point -> tolerance 2e-5 on decision / probability, labels equal
+away from p = 0.5.  The aubio front end is unpinned: the features here come
+from this library's own MFCC chain with n_mfcc = 20."""
+import numpy as np
+import pytest
+
+from tests import signals as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(m):
+    model = {k: m[k] for k in ("offset", "scale", "sv", "coef")}
+    model.update(gamma=float(m["kernel_params"][0]), rho=float(m["rho"][0]), prob_a=float(m["prob_a"][0]), prob_b=float(m["prob_b"][0]))
+    return model
+
+
+def test_mfcc_stats_vs_oracle():
+    import torch
+    from dsp_amd import scrubjay
+    from oracle import oracle as O
+    for (n, t, c) in ((5, 98, 20), (3, 1, 13), (2, 148, 13), (70, 7, 20)):
+        m = (S.uniform_pm1(n * t * c, 300 + n).reshape(n, t, c) * np.float32(40.0)).astype(np.float32)
+        m[0, :, 0] = 3.25                               # constant column -> std exactly 0
+        got = scrubjay.mfcc_stats(torch.from_numpy(m).cuda()).cpu().numpy()
+        want = np.stack([O.mfcc_stats(m[i]) for i in range(n)])
+        assert np.array_equal(got, want)                # same float64 accumulation order -> bit exact
+        assert got[0, c] == 0.0
+
+
+def test_svm_vs_oracle(golden):
+    import torch
+    from dsp_amd import scrubjay
+    from oracle import oracle as O
+    m = golden("scrubjay_svm.npz")
+    svm = scrubjay.SvmModel({k: m[k] for k in m.files})
+    x = np.stack([(m["offset"] + S.uniform_pm1(40, 900 + i) * (2.5 / m["scale"])).astype(np.float32) for i in range(300)])
+    labels, dec, p1 = (a.cpu().numpy() for a in svm.predict(torch.from_numpy(x).cuda()))
+    seen = set()
+    for i in range(x.shape[0]):
+        lab, odec, op1 = O.svm_predict(_model(m), x[i])
+        assert abs(dec[i] - odec) <= 2e-5 * max(1.0, abs(odec))
+        assert abs(p1[i] - op1) <= 2e-5
+        if abs(op1 - 0.5) > 1e-4:
+            assert labels[i] == lab
+        seen.add(int(labels[i]))
+    assert seen == {0, 1}
+
+
+def test_clip_to_label_pipeline(golden):
+    """scrubjay_infer main loop: clips -> MFCC(20) -> mean|std -> SVM, against the oracle chain."""
+    import torch
+    from dsp_amd import scrubjay
+    from oracle import oracle as O
+    from tests.conftest import ATOL_DB, RTOL, frame_linf_close
+    m = golden("scrubjay_svm.npz")
+    sj = scrubjay.ScrubJay({k: m[k] for k in m.files})
+    clips = np.stack([S.uniform_pm1(16000, 70), S.chirp(16000, 300.0, 6000.0), S.uniform_pm1(16000, 71) * np.float32(0.01),
+                      S.classify_cases()["jay_like"]])
+    labels, dec, p1, feat = sj(torch.from_numpy(clips).cuda())
+    feat = feat.cpu().numpy()
+    ocfg = O.default_cfg(n_mfcc=20)
+    for i in range(clips.shape[0]):
+        omfcc = O.compute_mfcc(clips[i], 1 << 20, ocfg)
+        ofeat = O.mfcc_stats(omfcc)
+        # pooled features inherit the MFCC gate (mean / std of values that each meet it)
+        assert np.all(np.abs(feat[i] - ofeat) <= RTOL * np.abs(omfcc).max() + ATOL_DB)
+        lab, odec, op1 = O.svm_predict(_model(m), feat[i])          # SVM checked on the SAME features
+        assert abs(dec[i].item() - odec) <= 2e-5 * max(1.0, abs(odec)) and abs(p1[i].item() - op1) <= 2e-5
+        if abs(op1 - 0.5) > 1e-4:
+            assert labels[i].item() == lab
