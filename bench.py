@@ -101,6 +101,55 @@ def cpu_baseline(sample_frames: int, seconds_budget: float = 25.0):
     return res
 
 
+def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
+    """Secondary measurements (not the headline metric): same timing protocol, its own JSON line."""
+    gen = torch.Generator(device=dev).manual_seed(2000 + rank)
+    if args.workload == "clips":
+        n = args.clips or 12_500
+        clips = torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1
+        plan = dsp_amd.MfccPlan(dsp_amd.default_config(), local)
+        out = torch.empty((n, 98, 13), device=dev)
+        step = lambda: plan.clips(clips, 500, out)            # noqa: E731
+        units, unit, bytes_per = n * 98, "frames/s", 64_000 + 98 * 52    # SURVEY 8(d): 69 096 B per clip
+        what = f"BASELINE configs[3] per-GPU share: {n} x 1 s 16 kHz fp32 clips, frame 400 / hop 160 -> [98][13] per clip"
+        kernel = "mfcc512_wave_kernel"
+    else:
+        n = args.clips or 2048
+        clips = (torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1) * 0.05
+        labels = torch.empty(n, dtype=torch.int32, device=dev)
+        step = lambda: dsp_amd.classify_device(clips, labels)   # noqa: E731
+        units, unit, bytes_per = n, "clips/s", 64_000 + 4
+        what = f"{n} x 1 s 16 kHz fp32 clips through classify() (2 x IIR, 2 x spectrogram, rule); bit-exact path, not tuned"
+        kernel = "iir_kernel + spectrogram_kernel x2 + classify_tail_kernel"
+    for _ in range(max(1, args.warmup // 4)):
+        step()
+    torch.cuda.synchronize()
+    steps = max(1, args.steps // 10) if args.workload == "classify" else args.steps
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = ev0.elapsed_time(ev1) / steps
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        achieved = bytes_per * n / (ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": f"{args.workload}: {unit}", "value": world * units * steps / elapsed, "unit": unit, "n_gpus": world,
+            "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": what},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes_per_launch": bytes_per * n}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +157,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="all-gather the per-rank features every step (RCCL)")
+    ap.add_argument("--workload", choices=["frames", "clips", "classify"], default="frames",
+                    help="frames = BASELINE configs[1] (the headline metric, default); clips = configs[3] per-GPU share "
+                         "(12 500 x 1 s clips, reference framing 400/160); classify = the donut classifier on 1 s clips")
+    ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step for --workload clips / classify")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
@@ -136,6 +189,9 @@ def main():
     plan = dsp_amd.MfccPlan(cfg, local)
     if args.blocks_per_cu or args.chunk:
         plan.set_launch(args.blocks_per_cu, args.chunk)
+
+    if args.workload != "frames":
+        return side_workload(args, torch, dist, dsp_amd, dev, local, rank, world)
 
     n = args.frames
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)

@@ -182,3 +182,33 @@ def test_full_size_properties(dsp, torch_cuda):
     ref = O.mfcc_frames(x[idx].cpu().numpy(), O.default_cfg(frame_length=512, hop_length=512), threads=8)
     ok, worst = frame_linf_close(a[idx].cpu().numpy(), ref, RTOL, ATOL_DB)
     assert ok, worst
+
+
+def test_config4_clips_at_scale(dsp, torch_cuda):
+    """BASELINE config 4, one GPU's share: 12 500 clips x 16 000 samples -> [12500][98][13].
+    Properties (no oracle pass at this size) + oracle spot check of whole clips."""
+    from oracle import oracle as O
+    torch = torch_cuda
+    n = 12_500
+    plan = dsp.MfccPlan()
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    clips = torch.rand((n, 16000), device="cuda", generator=gen) * 2 - 1
+    clips[::500] = 0.0                                            # silent clips
+    out = plan.clips(clips, 500)
+    assert tuple(out.shape) == (n, 98, 13) and bool(torch.isfinite(out).all())
+    assert not out[::500].any()
+    assert torch.equal(out, plan.clips(clips, 500))               # deterministic
+    # a clip's features do not depend on its neighbours or position in the batch
+    perm = torch.randperm(n, device="cuda", generator=gen)
+    assert torch.equal(plan.clips(clips[perm].contiguous(), 500), out[perm])
+    # frame t of a clip == the same 400 samples presented as an independent frame
+    fplan = dsp.MfccPlan(dsp.default_config(frame_length=400, hop_length=400))
+    idx = torch.tensor([1, 777, 12_499], device="cuda")
+    frames = clips[idx].unfold(1, 400, 160).reshape(-1, 400).contiguous()
+    assert torch.equal(fplan.frames(frames).reshape(3, 98, 13), out[idx])
+    # max_frames clamp on a batch
+    assert torch.equal(plan.clips(clips[:64], 7), out[:64, :7])
+    for i in (1, 4242):
+        ref = O.compute_mfcc(clips[i].cpu().numpy(), 500)
+        ok, worst = frame_linf_close(out[i].cpu().numpy(), ref, RTOL, ATOL_DB)
+        assert ok, worst
