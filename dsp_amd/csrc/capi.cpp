@@ -60,6 +60,9 @@ struct dsp_mfcc_plan {
     int chunk = 0;           // 0 = default
     dsp::LaneTables512 host;
     dsp::LaneTables512 *d_tables = nullptr;
+    dsp::RowTables512 *d_row_tables = nullptr;
+    int kernel = DSP_KERNEL_WAVE;
+    int resident_blocks_row = 3;
     // staging for the host-pointer entry points
     float *d_in = nullptr, *d_out = nullptr;
     size_t in_cap = 0, out_cap = 0;
@@ -170,14 +173,25 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) e = hipMalloc(&p->d_tables, sizeof(dsp::LaneTables512));
     if (e == hipSuccess) e = hipMemcpy(p->d_tables, &p->host, sizeof(dsp::LaneTables512), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->d_row_tables, sizeof(dsp::RowTables512));
+    if (e == hipSuccess) {
+        auto *rt = new dsp::RowTables512;
+        dsp::build_row_tables_512(*cfg, *rt);
+        e = hipMemcpy(p->d_row_tables, rt, sizeof(*rt), hipMemcpyHostToDevice);
+        delete rt;
+    }
     if (e != hipSuccess) {
         if (p->d_tables) hipFree(p->d_tables);
+        if (p->d_row_tables) hipFree(p->d_row_tables);
         delete p;
         return fail(DSP_EHIP, std::string("plan_create: ") + hipGetErrorString(e));
     }
     p->n_cu = prop.multiProcessorCount;
     p->resident_blocks = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
                                                     cfg->frame_length == 512);
+    p->resident_blocks_row = dsp::mfcc512_row_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
+                                                            cfg->frame_length == 512);
+    if (const char *k = std::getenv("DSP_AMD_KERNEL")) p->kernel = std::atoi(k) == 1 ? DSP_KERNEL_ROW : DSP_KERNEL_WAVE;
     *out = p;
     return DSP_OK;
 }
@@ -187,6 +201,7 @@ void dsp_mfcc_plan_destroy(dsp_mfcc_plan *p)
     if (!p) return;
     hipSetDevice(p->device);
     if (p->d_tables) hipFree(p->d_tables);
+    if (p->d_row_tables) hipFree(p->d_row_tables);
     if (p->d_in) hipFree(p->d_in);
     if (p->d_out) hipFree(p->d_out);
     delete p;
@@ -196,6 +211,13 @@ int dsp_mfcc_plan_config(const dsp_mfcc_plan *p, dsp_mfcc_config *cfg)
 {
     if (!p || !cfg) return fail(DSP_EINVAL, "plan/cfg is NULL");
     *cfg = p->cfg;
+    return DSP_OK;
+}
+
+int dsp_mfcc_plan_set_kernel(dsp_mfcc_plan *p, int kernel)
+{
+    if (!p || (kernel != DSP_KERNEL_WAVE && kernel != DSP_KERNEL_ROW)) return fail(DSP_EINVAL, "bad kernel id");
+    p->kernel = kernel;
     return DSP_OK;
 }
 
@@ -222,7 +244,8 @@ static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames,
     a.frames_per_clip = frames_per_clip;
     a.hop = p->cfg.hop_length;
     a.frame_len = p->cfg.frame_length;
-    const int nf = dsp::mfcc512_frames_per_item();
+    const bool row = p->kernel == DSP_KERNEL_ROW;
+    const int nf = row ? 4 : dsp::mfcc512_frames_per_item();
     a.chunk = p->chunk > 0 ? p->chunk : 8;
     a.chunk = ((a.chunk + nf - 1) / nf) * nf;   // whole items per chunk
     a.n_mels = p->cfg.n_mels;
@@ -232,11 +255,15 @@ static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames,
     // persistent-style grid: exactly the 4-wave blocks the chip holds at once (one
     // extra block per CU would run as a second, mostly idle round: measured +14 %),
     // never more blocks than there are chunks of work
-    const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks;
+    const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : (row ? p->resident_blocks_row : p->resident_blocks);
     long blocks = (long)p->n_cu * per_cu;
     const long chunks = (n_frames + a.chunk - 1) / a.chunk;
     blocks = std::max(1L, std::min(blocks, (chunks + 3) / 4));
-    DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+    if (row)
+        DSP_HIP(dsp::launch_mfcc512_row(a, p->d_row_tables, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks,
+                                        (hipStream_t)stream));
+    else
+        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
     return DSP_OK;
 }
 

@@ -1,0 +1,174 @@
+// mfcc_device.hpp -- device helpers shared by the MFCC kernels (complex math, radix-4
+// butterfly, wave-scope LDS ordering, DPP / permlane moves, frame cursor).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "mfcc_kernels.hpp"
+
+namespace dsp {
+
+namespace {
+
+struct c32 { float x, y; };
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ c32 cmul(c32 a, c32 w) { return {a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+// multiply by -i
+__device__ __forceinline__ c32 cmul_mi(c32 a) { return {a.y, -a.x}; }
+
+// forward radix-4 butterfly, W4 = -i
+__device__ __forceinline__ void radix4(c32 (&s)[4])
+{
+    const c32 t0 = cadd(s[0], s[2]), t1 = csub(s[0], s[2]);
+    const c32 t2 = cadd(s[1], s[3]), t3 = cmul_mi(csub(s[1], s[3]));
+    s[0] = cadd(t0, t2);
+    s[1] = cadd(t1, t3);
+    s[2] = csub(t0, t2);
+    s[3] = csub(t1, t3);
+}
+
+// Orders this wave's LDS traffic for the compiler.  The hardware executes one
+// wave's DS instructions in order, so no s_barrier / waitcnt is needed between a
+// ds_write and a ds_read of another lane's data inside the same wave.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void swap_hi32(float &a, float &b)
+{   // a[lanes 32..63] <-> b[lanes 0..31]
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_odd16(float &a, float &b)
+{   // a[odd 16-lane rows] <-> b[even 16-lane rows]
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+// 2x2 block transposes between a register pair (a: slot bit 0, b: slot bit 1) and
+// one lane bit: afterwards a[bit=1] holds the partner lane's old b, b[bit=0] the
+// partner lane's old a.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_into(float old, float src);
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v);
+__device__ __forceinline__ void swap_lane8(float &a, float &b);
+__device__ __forceinline__ void swap_lane4(float &a, float &b);
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// masked DPP move: lanes whose bank (lane%16/4) is in BANKS take src[perm], others keep old
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_into(float old, float src)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xF, BANKS, false));
+}
+constexpr int DPP_ROW_SHL4 = 0x104, DPP_ROW_SHR4 = 0x114, DPP_ROW_ROR8 = 0x128;
+constexpr int DPP_QUAD_1032 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_2301 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+__device__ __forceinline__ void swap_lane8(float &a, float &b)
+{   // lane ^ 8 = rotate the 16-lane row by 8; banks 0,1 have bit3 = 0, banks 2,3 bit3 = 1
+    const float nb = dpp_into<DPP_ROW_ROR8, 0x3>(b, a);
+    a = dpp_into<DPP_ROW_ROR8, 0xC>(a, b);
+    b = nb;
+}
+__device__ __forceinline__ void swap_lane4(float &a, float &b)
+{   // lane ^ 4: banks 0,2 (bit2 = 0) read lane+4, banks 1,3 read lane-4
+    const float nb = dpp_into<DPP_ROW_SHL4, 0x5>(b, a);
+    a = dpp_into<DPP_ROW_SHR4, 0xA>(a, b);
+    b = nb;
+}
+// lane bits 1 and 0 have no DPP write mask: quad permute + select on the lane bit
+template <int CTRL>
+__device__ __forceinline__ void swap_quad(float &a, float &b, bool bit_set)
+{
+    const float pa = dpp<CTRL>(a), pb = dpp<CTRL>(b);
+    b = bit_set ? b : pa;
+    a = bit_set ? pb : a;
+}
+
+// max over the wave of NON-NEGATIVE floats: their bit patterns order like
+// unsigned integers, so the reduction runs on v_max_u32 (fuses with DPP, needs no
+// NaN canonicalisation moves).
+template <int CTRL>
+__device__ __forceinline__ unsigned dppu(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float wave_max_nonneg(float f)
+{
+    unsigned v = __float_as_uint(f);
+    v = max(v, dppu<DPP_QUAD_1032>(v));
+    v = max(v, dppu<DPP_QUAD_2301>(v));
+    v = max(v, dppu<DPP_ROW_HALF_MIRROR>(v));
+    v = max(v, dppu<DPP_ROW_MIRROR>(v));            // every lane: max of its 16-lane row
+    const unsigned r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const unsigned r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return __uint_as_float(max(max(r0, r1), max(r2, r3)));
+}
+
+// per-wave LDS carve (bytes)
+constexpr int LDS_XCHG = 0;                 // 256 x float2 exchange tile, later P[0..256]
+constexpr int LDS_PART = 2048 + 64;         // 65 partial sums (+ zero slot)
+constexpr int LDS_LOGMEL = LDS_PART + 320;  // up to 80 log-mel values
+constexpr int LDS_WAVE_BYTES = LDS_LOGMEL + 320;
+static_assert(LDS_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
+// wave-uniform cursor over the frames this wave owns: chunks of `chunk`
+// consecutive frames dealt round-robin to the waves of the grid, so one wave's
+// 52-byte outputs land in consecutive cache lines.
+struct FrameCursor {
+    long f, chunk_end, chunk_first, stride, n;
+    long clip;              // clip mode: f = clip * fpc + t
+    long jump_clips;        // stride = jump_clips * fpc + jump_t
+    int t, t0, fpc, chunk, jump_t;
+    long clip0;             // (clip0, t0): position of chunk_first
+    __device__ __forceinline__ void init(long wave, long n_waves, int chunk_, long n_, int fpc_)
+    {
+        chunk = chunk_; n = n_; fpc = fpc_;
+        stride = n_waves * chunk;
+        chunk_first = wave * chunk;
+        f = chunk_first;
+        chunk_end = f + chunk < n ? f + chunk : n;
+        clip0 = 0; t0 = 0; jump_clips = 0; jump_t = 0;
+        if (fpc > 0) {          // the only divisions: once per wave, not per frame
+            clip0 = f / fpc; t0 = (int)(f - clip0 * fpc);
+            jump_clips = stride / fpc; jump_t = (int)(stride - jump_clips * fpc);
+        }
+        clip = clip0; t = t0;
+    }
+    __device__ __forceinline__ bool valid() const { return f < n; }
+    // advance by `step` frames (step divides chunk)
+    __device__ __forceinline__ void next(int step)
+    {
+        f += step;
+        if (f >= chunk_end) {
+            chunk_first += stride;
+            f = chunk_first;
+            chunk_end = f + chunk < n ? f + chunk : n;
+            clip0 += jump_clips; t0 += jump_t;
+            if (t0 >= fpc) { t0 -= fpc; ++clip0; }
+            clip = clip0; t = t0;
+        } else if (fpc > 0) {
+            t += step;
+            while (t >= fpc) { t -= fpc; ++clip; }
+        }
+    }
+};
+
+}  // namespace
+
+}  // namespace dsp

@@ -76,6 +76,23 @@ static void unit(double turns, float &c, float &s)
     s = (float)std::sin(-2.0 * kPi * turns);
 }
 
+void build_row_tables_512(const dsp_mfcc_config &cfg, RowTables512 &t)
+{
+    std::memset(&t, 0, sizeof(t));
+    std::vector<float> win = make_window(cfg.window, cfg.frame_length);
+    win.resize(512, 0.0f);
+    for (int l = 0; l < kLanes; ++l) {
+        const int j = l & 15;
+        for (int k = 0; k < 16; ++k) {
+            const int n = j + 16 * k;
+            t.win[2 * k][l] = 0.5f * win[2 * n];          // x0.5: see build_lane_tables_512
+            t.win[2 * k + 1][l] = 0.5f * win[2 * n + 1];
+        }
+        for (int q = 1; q <= 15; ++q) unit((double)(j * q) / 256.0, t.tw[2 * (q - 1)][l], t.tw[2 * (q - 1) + 1][l]);
+        for (int m = 0; m < 8; ++m) unit((double)(j + 16 * m) / 512.0, t.twp[2 * m][l], t.twp[2 * m + 1][l]);
+    }
+}
+
 bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::string &why)
 {
     std::memset(&t, 0, sizeof(t));

@@ -64,6 +64,16 @@ struct LaneTables512 {
     int32_t n_mels, n_mfcc;
 };
 
+// ---- per-lane layout of the FFT front end of the row-per-frame kernel -------------
+// (4 frames per wave: lane = 16 g + j, row g = frame, 16 complex points per lane; the
+// tail -- mel, log, DCT -- reuses LaneTables512).
+struct RowTables512 {
+    float win[32][kLanes];   // x0.5 window for samples 2(j+16k), 2(j+16k)+1 at [2k], [2k+1]
+    float tw[30][kLanes];    // W256^(j q), q = 1..15: (cos, sin) at [2(q-1)], [2(q-1)+1]
+    float twp[16][kLanes];   // W512^(j+16m), m = 0..7: (cos, sin) at [2m], [2m+1]
+};
+void build_row_tables_512(const dsp_mfcc_config &cfg, RowTables512 &t);
+
 // Fills `t`; returns false (with a message) when the configuration does not
 // fit this kernel's layout.
 bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::string &why);

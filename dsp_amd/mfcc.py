@@ -71,6 +71,10 @@ class MfccPlan:
         except Exception:  # noqa: BLE001
             pass
 
+    def set_kernel(self, kernel: int):
+        """0 = one wavefront per frame, 1 = one 16-lane row per frame (4 frames per wavefront)."""
+        _lib.check(self._L.dsp_mfcc_plan_set_kernel(self._h, int(kernel)), "dsp_mfcc_plan_set_kernel")
+
     def set_launch(self, blocks_per_cu: int = 0, frames_per_chunk: int = 0):
         _lib.check(self._L.dsp_mfcc_plan_set_launch(self._h, blocks_per_cu, frames_per_chunk), "dsp_mfcc_plan_set_launch")
 

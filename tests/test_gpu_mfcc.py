@@ -212,3 +212,30 @@ def test_config4_clips_at_scale(dsp, torch_cuda):
         ref = O.compute_mfcc(clips[i].cpu().numpy(), 500)
         ok, worst = frame_linf_close(out[i].cpu().numpy(), ref, RTOL, ATOL_DB)
         assert ok, worst
+
+
+def test_row_per_frame_kernel_matches_wave_kernel(dsp, torch_cuda, golden):
+    """The alternative kernel form (one 16-lane row per frame, 4 frames per wave) meets the same
+    gates, handles ragged frame counts, and agrees with the default form to rounding."""
+    from oracle import oracle as O
+    torch = torch_cuda
+    g = golden("mfcc_ref.npz")
+    plan = dsp.MfccPlan()
+    plan.set_kernel(1)
+    for name in ("noise0", "chirp", "silence", "tiny", "len400", "len560", "birdq_ch0", "stop_121417"):
+        x = _cases(g)[name]
+        got = plan.clips_host(x, 500)[0]
+        ok, worst = frame_linf_close(got, g["mfcc__" + name], RTOL, ATOL_DB)
+        assert ok, (name, worst)
+    fcfg = dsp.default_config(frame_length=512, hop_length=512)
+    a, b = dsp.MfccPlan(fcfg), dsp.MfccPlan(fcfg)
+    b.set_kernel(1)
+    for n in (1, 2, 3, 4, 5, 63, 4099):
+        fr = S.uniform_pm1(512 * n, 500 + n).reshape(n, 512)
+        if n > 4:
+            fr[2] = 0.0
+        x = torch.from_numpy(fr).cuda()
+        ya, yb = a.frames(x).cpu().numpy(), b.frames(x).cpu().numpy()
+        assert np.abs(ya - yb).max() <= 2e-4
+        ref = O.mfcc_frames(fr, O.default_cfg(frame_length=512, hop_length=512), threads=4)
+        assert frame_linf_close(yb, ref, RTOL, ATOL_DB)[0]

@@ -2,7 +2,7 @@
 """A/B timing of libdsp_amd.so builds and launch geometries in ONE process,
 interleaved rounds (cdna_hip_programming.md 5.4 rule 24).
 
-    python tools/ab.py [--frames N] [--rounds R] lib1.so[:bpc:chunk] lib2.so[:bpc:chunk] ...
+    python tools/ab.py [--frames N] [--rounds R] lib1.so[:bpc:chunk[:kernel]] lib2.so[:bpc:chunk[:kernel]] ...
 
 Each variant: frames kernel on BASELINE config 2 (1 M x 512 by default); prints
 median / min ms, frames/s and algorithmic GB/s, and checks every variant's
@@ -38,6 +38,7 @@ def main():
         path = os.path.abspath(parts[0])
         bpc = int(parts[1]) if len(parts) > 1 else 0
         chunk = int(parts[2]) if len(parts) > 2 else 0
+        kern = int(parts[3]) if len(parts) > 3 else 0
         L = C.CDLL(path)
         cfg = MfccConfig()
         L.dsp_mfcc_default_config(C.byref(cfg))
@@ -48,6 +49,8 @@ def main():
         rc = L.dsp_mfcc_plan_create(C.byref(cfg), 0, C.byref(h))
         assert rc == 0, L.dsp_last_error()
         L.dsp_mfcc_plan_set_launch(h, bpc, chunk)
+        if kern:
+            assert L.dsp_mfcc_plan_set_kernel(h, kern) == 0
         L.dsp_mfcc_frames_device.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
         out = torch.empty((n, 13), device="cuda")
         plans.append((v, L, h, out))
@@ -79,7 +82,7 @@ def main():
     bytes_per = (fl * 4 + 52) * n
     for (v, *_), t in zip(plans, times):
         med, mn = statistics.median(t), min(t)
-        print(f"{v:50s} median {med:.4f} ms  min {mn:.4f} ms  {n / med / 1e6:8.1f} Mframes/s  {bytes_per / med / 1e6:7.1f} GB/s  ({bytes_per / med / 8e6 :.1%} of 8 TB/s)")
+        print(f"{v:50s} median {med:.4f} ms  min {mn:.4f} ms  {n / med / 1e6:8.3f} Gframes/s  {bytes_per / med / 1e6:7.1f} GB/s  ({bytes_per / med / 8e9 :.1%} of 8 TB/s)")
 
 
 if __name__ == "__main__":
