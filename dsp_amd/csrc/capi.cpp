@@ -45,7 +45,10 @@ bool valid_cfg(const dsp_mfcc_config &c, std::string &why)
     if (!(c.fmax > c.fmin) || c.fmin < 0) { why = "need 0 <= fmin < fmax"; return false; }
     if (!(c.amin > 0)) { why = "amin must be positive"; return false; }
     if (c.log_mode != DSP_LOG_PER_FRAME_MAX) { why = "only DSP_LOG_PER_FRAME_MAX is implemented"; return false; }
-    if (c.prefilter != DSP_PREFILTER_NONE) { why = "per-frame prefilter is not implemented yet"; return false; }
+    if (c.frame_length > c.n_fft) { why = "frame_length must not exceed n_fft"; return false; }
+    if (c.prefilter != DSP_PREFILTER_NONE && c.prefilter != DSP_PREFILTER_BUTTER_1000_3000 &&
+        c.prefilter != DSP_PREFILTER_BUTTER_3000_7500) { why = "unknown prefilter"; return false; }
+    if (c.n_fft != 512 && c.n_fft != 1024) { why = "n_fft must be 512 or 1024"; return false; }
     return true;
 }
 
@@ -61,6 +64,10 @@ struct dsp_mfcc_plan {
     dsp::LaneTables512 host;
     dsp::LaneTables512 *d_tables = nullptr;
     dsp::RowTables512 *d_row_tables = nullptr;
+    dsp::GenTables1024 *d_gen_tables = nullptr;   // n_fft = 1024
+    int resident_blocks_gen = 3;
+    float *d_filtered = nullptr;                  // per-frame prefilter output (sub-batch)
+    size_t filtered_cap = 0;
     int kernel = DSP_KERNEL_WAVE;
     int resident_blocks_row = 3;
     // staging for the host-pointer entry points
@@ -163,18 +170,27 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
     if (!valid_cfg(*cfg, why)) return fail(DSP_EINVAL, why);
     auto *p = new dsp_mfcc_plan;
     p->cfg = *cfg;
-    if (!dsp::build_lane_tables_512(*cfg, p->host, why)) { delete p; return fail(DSP_EINVAL, why); }
+    dsp::GenTables1024 *gen = nullptr;
+    if (cfg->n_fft == 1024) {
+        gen = new dsp::GenTables1024;
+        if (!dsp::build_gen_tables_1024(*cfg, *gen, why)) { delete gen; delete p; return fail(DSP_EINVAL, why); }
+    } else if (!dsp::build_lane_tables_512(*cfg, p->host, why)) { delete p; return fail(DSP_EINVAL, why); }
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { delete p; return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback"); }
-    if (device < 0 || device >= n) { delete p; return fail(DSP_EINVAL, "device index out of range"); }
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { delete gen; delete p; return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback"); }
+    if (device < 0 || device >= n) { delete gen; delete p; return fail(DSP_EINVAL, "device index out of range"); }
     p->device = device;
     hipError_t e = hipSetDevice(device);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) e = hipMalloc(&p->d_tables, sizeof(dsp::LaneTables512));
     if (e == hipSuccess) e = hipMemcpy(p->d_tables, &p->host, sizeof(dsp::LaneTables512), hipMemcpyHostToDevice);
+    if (e == hipSuccess && gen) {
+        e = hipMalloc(&p->d_gen_tables, sizeof(dsp::GenTables1024));
+        if (e == hipSuccess) e = hipMemcpy(p->d_gen_tables, gen, sizeof(*gen), hipMemcpyHostToDevice);
+    }
+    delete gen;
     if (e == hipSuccess) e = hipMalloc(&p->d_row_tables, sizeof(dsp::RowTables512));
-    if (e == hipSuccess) {
+    if (e == hipSuccess && cfg->n_fft == 512) {
         auto *rt = new dsp::RowTables512;
         dsp::build_row_tables_512(*cfg, *rt);
         e = hipMemcpy(p->d_row_tables, rt, sizeof(*rt), hipMemcpyHostToDevice);
@@ -187,10 +203,14 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
         return fail(DSP_EHIP, std::string("plan_create: ") + hipGetErrorString(e));
     }
     p->n_cu = prop.multiProcessorCount;
-    p->resident_blocks = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
-                                                    cfg->frame_length == 512);
-    p->resident_blocks_row = dsp::mfcc512_row_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
-                                                            cfg->frame_length == 512);
+    if (cfg->n_fft == 512) {
+        p->resident_blocks = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
+                                                        cfg->frame_length == 512);
+        p->resident_blocks_row = dsp::mfcc512_row_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
+                                                                cfg->frame_length == 512);
+    } else {
+        p->resident_blocks_gen = dsp::mfcc1024_blocks_per_cu(cfg->frame_length == 1024);
+    }
     if (const char *k = std::getenv("DSP_AMD_KERNEL")) p->kernel = std::atoi(k) == 1 ? DSP_KERNEL_ROW : DSP_KERNEL_WAVE;
     *out = p;
     return DSP_OK;
@@ -202,6 +222,8 @@ void dsp_mfcc_plan_destroy(dsp_mfcc_plan *p)
     hipSetDevice(p->device);
     if (p->d_tables) hipFree(p->d_tables);
     if (p->d_row_tables) hipFree(p->d_row_tables);
+    if (p->d_gen_tables) hipFree(p->d_gen_tables);
+    if (p->d_filtered) hipFree(p->d_filtered);
     if (p->d_in) hipFree(p->d_in);
     if (p->d_out) hipFree(p->d_out);
     delete p;
@@ -244,8 +266,9 @@ static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames,
     a.frames_per_clip = frames_per_clip;
     a.hop = p->cfg.hop_length;
     a.frame_len = p->cfg.frame_length;
-    const bool row = p->kernel == DSP_KERNEL_ROW;
-    const int nf = row ? 4 : dsp::mfcc512_frames_per_item();
+    const bool gen = p->cfg.n_fft == 1024;
+    const bool row = !gen && p->kernel == DSP_KERNEL_ROW;
+    const int nf = gen ? 1 : (row ? 4 : dsp::mfcc512_frames_per_item());
     a.chunk = p->chunk > 0 ? p->chunk : 8;
     a.chunk = ((a.chunk + nf - 1) / nf) * nf;   // whole items per chunk
     a.n_mels = p->cfg.n_mels;
@@ -255,34 +278,19 @@ static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames,
     // persistent-style grid: exactly the 4-wave blocks the chip holds at once (one
     // extra block per CU would run as a second, mostly idle round: measured +14 %),
     // never more blocks than there are chunks of work
-    const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : (row ? p->resident_blocks_row : p->resident_blocks);
+    const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu
+                       : (gen ? p->resident_blocks_gen : (row ? p->resident_blocks_row : p->resident_blocks));
     long blocks = (long)p->n_cu * per_cu;
     const long chunks = (n_frames + a.chunk - 1) / a.chunk;
     blocks = std::max(1L, std::min(blocks, (chunks + 3) / 4));
-    if (row)
+    if (gen)
+        DSP_HIP(dsp::launch_mfcc1024(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream));
+    else if (row)
         DSP_HIP(dsp::launch_mfcc512_row(a, p->d_row_tables, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks,
                                         (hipStream_t)stream));
     else
         DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
     return DSP_OK;
-}
-
-int dsp_mfcc_frames_device(dsp_mfcc_plan *p, const float *d_frames, long n_frames, float *d_out, void *stream)
-{
-    if (!p || n_frames < 0 || (n_frames > 0 && (!d_frames || !d_out))) return fail(DSP_EINVAL, "bad argument");
-    return run(p, d_frames, d_out, n_frames, 0, 0, stream);
-}
-
-int dsp_mfcc_clips_device(dsp_mfcc_plan *p, const float *d_signal, long n_clips, int samples_per_clip,
-                          long clip_stride, float *d_out, int max_frames, void *stream)
-{
-    if (!p || n_clips < 0) return fail(DSP_EINVAL, "bad argument");
-    const int t = dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
-    if (t == 0 || n_clips == 0) return 0;
-    if (!d_signal || !d_out) return fail(DSP_EINVAL, "NULL buffer");
-    if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
-    const int rc = run(p, d_signal, d_out, n_clips * (long)t, t, clip_stride, stream);
-    return rc < 0 ? rc : t;
 }
 
 static int reserve(float **buf, size_t *cap, size_t need)
@@ -292,6 +300,43 @@ static int reserve(float **buf, size_t *cap, size_t need)
     DSP_HIP(hipMalloc(buf, need));
     *cap = need;
     return DSP_OK;
+}
+
+int dsp_mfcc_frames_device(dsp_mfcc_plan *p, const float *d_frames, long n_frames, float *d_out, void *stream)
+{
+    if (!p || n_frames < 0 || (n_frames > 0 && (!d_frames || !d_out))) return fail(DSP_EINVAL, "bad argument");
+    if (p->cfg.prefilter == DSP_PREFILTER_NONE) return run(p, d_frames, d_out, n_frames, 0, 0, stream);
+    // BASELINE config 3: 8th-order Butterworth (donut-classifier/classifier.c:420-446, float64) over each
+    // frame from zero state, rounded to float, then the MFCC chain.  Filtered frames go through a
+    // bounded workspace (sub-batches of <= 1 Mi frames) instead of a second full-size buffer.
+    std::lock_guard<std::mutex> lock(p->mu);
+    DSP_HIP(hipSetDevice(p->device));
+    const int fl = p->cfg.frame_length;
+    const long sub = std::min<long>(n_frames, 1L << 20);
+    int rc;
+    if ((rc = reserve(&p->d_filtered, &p->filtered_cap, (size_t)sub * fl * sizeof(float))) < 0) return rc;
+    dsp::IirCoefD c;
+    dsp_butter_bandpass(p->cfg.prefilter == DSP_PREFILTER_BUTTER_1000_3000 ? 1000 : 3000,
+                        p->cfg.prefilter == DSP_PREFILTER_BUTTER_1000_3000 ? 3000 : 7500, c.b, c.a);
+    for (long f0 = 0; f0 < n_frames; f0 += sub) {
+        const long cnt = std::min(sub, n_frames - f0);
+        DSP_HIP(dsp::launch_iir_f64_on_f32(d_frames + f0 * fl, cnt, fl, fl, c, p->d_filtered, (hipStream_t)stream));
+        if ((rc = run(p, p->d_filtered, d_out + f0 * p->cfg.n_mfcc, cnt, 0, 0, stream)) < 0) return rc;
+    }
+    return DSP_OK;
+}
+
+int dsp_mfcc_clips_device(dsp_mfcc_plan *p, const float *d_signal, long n_clips, int samples_per_clip,
+                          long clip_stride, float *d_out, int max_frames, void *stream)
+{
+    if (!p || n_clips < 0) return fail(DSP_EINVAL, "bad argument");
+    if (p->cfg.prefilter != DSP_PREFILTER_NONE) return fail(DSP_EINVAL, "the per-frame prefilter applies to independent frames only");
+    const int t = dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
+    if (t == 0 || n_clips == 0) return 0;
+    if (!d_signal || !d_out) return fail(DSP_EINVAL, "NULL buffer");
+    if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
+    const int rc = run(p, d_signal, d_out, n_clips * (long)t, t, clip_stride, stream);
+    return rc < 0 ? rc : t;
 }
 
 int dsp_mfcc_frames_host(dsp_mfcc_plan *p, const float *frames, long n_frames, float *out)
@@ -306,6 +351,7 @@ int dsp_mfcc_frames_host(dsp_mfcc_plan *p, const float *frames, long n_frames, f
     if ((rc = reserve(&p->d_in, &p->in_cap, in_b)) < 0) return rc;
     if ((rc = reserve(&p->d_out, &p->out_cap, out_b)) < 0) return rc;
     DSP_HIP(hipMemcpyAsync(p->d_in, frames, in_b, hipMemcpyHostToDevice, nullptr));
+    if (p->cfg.prefilter != DSP_PREFILTER_NONE) return fail(DSP_EINVAL, "prefiltered plans take device buffers (dsp_mfcc_frames_device)");
     if ((rc = run(p, p->d_in, p->d_out, n_frames, 0, 0, nullptr)) < 0) return rc;
     DSP_HIP(hipMemcpyAsync(out, p->d_out, out_b, hipMemcpyDeviceToHost, nullptr));
     DSP_HIP(hipStreamSynchronize(nullptr));

@@ -45,13 +45,15 @@ __device__ __forceinline__ T iir_step(IirState<T> &s, const C &c, T x)
     return y;
 }
 
-template <typename T, typename C, bool TWO>
-__global__ __launch_bounds__(64) void iir_kernel(const T *__restrict__ x, long n_clips, int n, long stride,
-                                                 const C c1, T *__restrict__ y1, const C c2, T *__restrict__ y2)
+// T: arithmetic type of the recurrence; TIO: element type in HBM (float rows filtered in double
+// are converted on load and rounded once on store: BASELINE config 3's per-frame prefilter).
+template <typename T, typename C, bool TWO, typename TIO = T>
+__global__ __launch_bounds__(64) void iir_kernel(const TIO *__restrict__ x, long n_clips, int n, long stride,
+                                                 const C c1, TIO *__restrict__ y1, const C c2, TIO *__restrict__ y2)
 {
-    __shared__ T tin[64 * IIR_LD];
-    __shared__ T tout1[64 * IIR_LD];
-    __shared__ T tout2[TWO ? 64 * IIR_LD : 1];
+    __shared__ TIO tin[64 * IIR_LD];
+    __shared__ TIO tout1[64 * IIR_LD];
+    __shared__ TIO tout2[TWO ? 64 * IIR_LD : 1];
     const int lane = threadIdx.x;
     const long clip0 = (long)blockIdx.x * 64;
     const int rows = (int)((n_clips - clip0) < 64 ? (n_clips - clip0) : 64);
@@ -63,16 +65,16 @@ __global__ __launch_bounds__(64) void iir_kernel(const T *__restrict__ x, long n
         // coalesced load: 64 rows x IIR_TS columns, lane -> (row = e / TS, col = e % TS)
         for (int e = lane; e < 64 * IIR_TS; e += 64) {
             const int r = e / IIR_TS, cidx = e % IIR_TS;
-            T v = T(0);
+            TIO v = TIO(0);
             if (r < rows && cidx < cols) v = x[(clip0 + r) * stride + t0 + cidx];
             tin[r * IIR_LD + cidx] = v;
         }
         __syncthreads();
         if (lane < rows) {
             for (int i = 0; i < cols; ++i) {
-                const T xv = tin[lane * IIR_LD + i];
-                tout1[lane * IIR_LD + i] = iir_step<T, C>(s1, c1, xv);
-                if (TWO) tout2[lane * IIR_LD + i] = iir_step<T, C>(s2, c2, xv);
+                const T xv = (T)tin[lane * IIR_LD + i];
+                tout1[lane * IIR_LD + i] = (TIO)iir_step<T, C>(s1, c1, xv);
+                if (TWO) tout2[lane * IIR_LD + i] = (TIO)iir_step<T, C>(s2, c2, xv);
             }
         }
         __syncthreads();
@@ -94,6 +96,15 @@ hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, cons
     const int blocks = (int)((n_clips + 63) / 64);
     if (y2) hipLaunchKernelGGL((iir_kernel<float, IirCoef, true>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2);
     else hipLaunchKernelGGL((iir_kernel<float, IirCoef, false>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c1, y1, c1, y1);
+    return hipGetLastError();
+}
+
+hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long stride, const IirCoefD &c, float *y,
+                                 hipStream_t stream)
+{
+    if (n_clips <= 0 || n <= 0) return hipSuccess;
+    const int blocks = (int)((n_clips + 63) / 64);
+    hipLaunchKernelGGL((iir_kernel<double, IirCoefD, false, float>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c, y, c, y);
     return hipGetLastError();
 }
 

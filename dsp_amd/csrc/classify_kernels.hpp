@@ -29,6 +29,9 @@ hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, cons
                           const IirCoef &c2, float *y2, hipStream_t stream);
 hipError_t launch_iir_f64(const double *x, long n_clips, int n, long stride, const IirCoefD &c, double *y,
                           hipStream_t stream);
+// float rows, recurrence in double, one rounding on store (per-frame prefilter of BASELINE config 3)
+hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long stride, const IirCoefD &c, float *y,
+                                 hipStream_t stream);
 
 // sxx[c][129][T] (T = (n-256)/224+1) of clip rows y[c][0..n)
 hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,

@@ -26,6 +26,8 @@ hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, i
 hipError_t launch_mfcc512_row(const Mfcc512Args &args, const RowTables512 *row_tables, int dct_split, int dct_len,
                               int gather, int blocks, hipStream_t stream);
 int mfcc512_row_blocks_per_cu(int dct_split, int dct_len, int gather, bool full);
+hipError_t launch_mfcc1024(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream);
+int mfcc1024_blocks_per_cu(bool full);
 int mfcc512_lds_bytes_per_block();
 int mfcc512_frames_per_item();   // frames a wave processes together; chunk must be a multiple
 int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full);

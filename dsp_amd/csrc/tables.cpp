@@ -76,6 +76,68 @@ static void unit(double turns, float &c, float &s)
     s = (float)std::sin(-2.0 * kPi * turns);
 }
 
+bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::string &why)
+{
+    std::memset(&t, 0, sizeof(t));
+    const int n_fft = 1024, n_bins = 513;
+    if (cfg.n_fft != n_fft) { why = "n_fft must be 1024 for this kernel"; return false; }
+    if (cfg.frame_length < 2 || cfg.frame_length > n_fft) { why = "frame_length must be in [2, n_fft]"; return false; }
+    if (cfg.n_mels < 1 || cfg.n_mels > kGenMelsPerLane * kLanes) { why = "n_mels must be in [1, 128]"; return false; }
+    if (cfg.n_mfcc < 1 || cfg.n_mfcc > 16) { why = "n_mfcc must be in [1, 16] for n_fft = 1024"; return false; }
+    t.n_mels = cfg.n_mels;
+    t.n_mfcc = cfg.n_mfcc;
+    std::vector<float> win = make_window(cfg.window, cfg.frame_length);
+    win.resize(n_fft, 0.0f);
+    for (int l = 0; l < kLanes; ++l)
+        for (int a = 0; a < 8; ++a) {
+            const int n = l + 64 * a;
+            t.win[2 * a][l] = 0.5f * win[2 * n];
+            t.win[2 * a + 1][l] = 0.5f * win[2 * n + 1];
+        }
+    for (int i = 0; i < 512; ++i) unit((double)i / 512.0, t.w512[0][i], t.w512[1][i]);
+    for (int k = 0; k < 256; ++k) unit((double)k / 1024.0, t.w1024[0][k], t.w1024[1][k]);
+
+    // sparse mel: chunks of <= 12 bins dealt to (slot, lane); no bank placement here (general path)
+    const std::vector<float> fb = make_mel_filterbank(cfg.sample_rate, n_fft, cfg.n_mels, cfg.fmin, cfg.fmax, cfg.mel_norm);
+    for (int i = 0; i < kGenMelsPerLane; ++i)
+        for (int g = 0; g < kGenGather; ++g)
+            for (int l = 0; l < kLanes; ++l) t.mel_src[i][g][l] = kGenZeroSlot;
+    int next = 0;
+    for (int m = 0; m < cfg.n_mels; ++m) {
+        const float *row = &fb[(size_t)m * n_bins];
+        int first = -1, last = -1;
+        for (int k = 0; k < n_bins; ++k)
+            if (row[k] != 0.0f) { if (first < 0) first = k; last = k; }
+        if (first < 0) continue;
+        const int run = last - first + 1, pieces = (run + kMelChunk - 1) / kMelChunk;
+        if (pieces > kGenGather) { why = "a mel filter spans more than 72 bins"; return false; }
+        int k = first;
+        for (int g = 0; g < pieces; ++g) {
+            const int len = run / pieces + (g < run % pieces ? 1 : 0);
+            if (next >= kGenChunks * kLanes) { why = "mel filterbank needs more than 256 chunks of 12 bins"; return false; }
+            const int slot = next / kLanes, lane = next % kLanes;
+            const int k0 = std::min(k, n_bins - kMelChunk);
+            t.mel_k0[slot][lane] = k0;
+            for (int i = 0; i < kMelChunk; ++i) {
+                const int kk = k0 + i;
+                t.mel_w[slot][i][lane] = (kk >= k && kk < k + len) ? row[kk] : 0.0f;
+            }
+            t.mel_src[m / kLanes][g][m % kLanes] = next;     // partial index = slot * 64 + lane
+            ++next;
+            k += len;
+        }
+    }
+    t.n_chunk_slots = std::max(1, (next + kLanes - 1) / kLanes);
+    const std::vector<float> dct = make_dct_ortho(cfg.n_mfcc, cfg.n_mels);
+    for (int c = 0; c < cfg.n_mfcc; ++c)
+        for (int q = 0; q < 4; ++q)
+            for (int i = 0; i < kGenDctLen; ++i) {
+                const int m = q * kGenDctLen + i;
+                t.dct_w[i][4 * c + q] = m < cfg.n_mels ? dct[(size_t)c * cfg.n_mels + m] : 0.0f;
+            }
+    return true;
+}
+
 void build_row_tables_512(const dsp_mfcc_config &cfg, RowTables512 &t)
 {
     std::memset(&t, 0, sizeof(t));

@@ -74,6 +74,25 @@ struct RowTables512 {
 };
 void build_row_tables_512(const dsp_mfcc_config &cfg, RowTables512 &t);
 
+// ---- tables of the general 1024-point kernel (mfcc1024_kernel.hip) ------------------
+constexpr int kGenChunks = 4;      // mel chunks (12 bins) per lane  -> up to 256 chunks
+constexpr int kGenGather = 6;      // partial sums per filter (filters up to 72 bins wide)
+constexpr int kGenMelsPerLane = 2; // filters per lane -> n_mels <= 128
+constexpr int kGenDctLen = 32;     // log-mel values per DCT lane (split 4)
+struct GenTables1024 {
+    float win[16][kLanes];                 // x0.5 window for samples 2(l+64a), 2(l+64a)+1
+    float w512[2][512];                    // W512^i (cos, sin): stage twiddles
+    float w1024[2][256];                   // W1024^k (cos, sin), k < 256: untangling
+    int32_t mel_k0[kGenChunks][kLanes];    // chunk c of lane l reads P[k0 .. k0+12)
+    float mel_w[kGenChunks][kMelChunk][kLanes];
+    int32_t mel_src[kGenMelsPerLane][kGenGather][kLanes];   // filter m = lane + 64 i sums these partial slots
+    float dct_w[kGenDctLen][kLanes];       // lane 4c+q: row c, mels [32q, 32q+32)
+    int32_t n_chunk_slots;                 // chunk slots per lane in use (1..4)
+    int32_t n_mels, n_mfcc;
+};
+constexpr int kGenZeroSlot = kGenChunks * kLanes;   // partial slot that always reads 0
+bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::string &why);
+
 // Fills `t`; returns false (with a message) when the configuration does not
 // fit this kernel's layout.
 bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::string &why);

@@ -65,7 +65,7 @@ enum { DSP_PREFILTER_NONE = 0, DSP_PREFILTER_BUTTER_1000_3000 = 1, DSP_PREFILTER
  * turned into a POD; dsp_mfcc_default_config() fills in the reference values. */
 typedef struct dsp_mfcc_config {
     int sample_rate;  /* 16000 */
-    int n_fft;        /* 512   (supported: 512) */
+    int n_fft;        /* 512   (supported: 512, and 1024 through the general kernel) */
     int frame_length; /* 400   (<= n_fft) */
     int hop_length;   /* 160 */
     int n_mels;       /* 40 */

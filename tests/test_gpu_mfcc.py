@@ -239,3 +239,41 @@ def test_row_per_frame_kernel_matches_wave_kernel(dsp, torch_cuda, golden):
         assert np.abs(ya - yb).max() <= 2e-4
         ref = O.mfcc_frames(fr, O.default_cfg(frame_length=512, hop_length=512), threads=4)
         assert frame_linf_close(yb, ref, RTOL, ATOL_DB)[0]
+
+
+def test_config3_1024_point_128_mel_with_prefilter(dsp, torch_cuda):
+    """BASELINE config 3 at oracle-friendly size: per-frame float64 Butterworth (3000-7500 Hz literals)
+    from zero state -> Hann(1024) -> 1024-pt FFT -> 128 HTK mel -> per-frame dB -> 13 coeffs."""
+    from oracle import oracle as O
+    torch = torch_cuda
+    over = dict(n_fft=1024, frame_length=1024, hop_length=1024, n_mels=128)
+    for pre in (0, 2, 1):
+        cfg = dsp.default_config(prefilter=pre, **over)
+        ocfg = O.default_cfg(prefilter=pre, **over)
+        plan = dsp.MfccPlan(cfg)
+        for n in (1, 5, 64, 333):
+            fr = S.uniform_pm1(1024 * n, 700 + n).reshape(n, 1024)
+            if n >= 5:
+                fr[1] = 0.0
+                fr[3] = S.chirp(1024, 3500.0, 7000.0)
+            out = plan.frames(torch.from_numpy(fr).cuda()).cpu().numpy()
+            ref = O.mfcc_frames(fr, ocfg, threads=4)
+            ok, worst = frame_linf_close(out, ref, RTOL, ATOL_DB)
+            assert ok, (pre, n, worst)
+            if n >= 5:
+                assert not out[1].any()                       # silent frame stays exactly zero through the filter
+
+
+def test_1024_point_clip_framing_and_other_shapes(dsp, torch_cuda):
+    from oracle import oracle as O
+    torch = torch_cuda
+    for over in (dict(n_fft=1024, frame_length=800, hop_length=320, n_mels=40),
+                 dict(n_fft=1024, frame_length=1024, hop_length=512, n_mels=64, n_mfcc=16)):
+        cfg, ocfg = dsp.default_config(**over), O.default_cfg(**over)
+        x = np.stack([S.uniform_pm1(16000, 80), S.chirp(16000, 200.0, 7000.0)])
+        out = dsp.MfccPlan(cfg).clips(torch.from_numpy(x).cuda(), 500).cpu().numpy()
+        for i in range(2):
+            ref = O.compute_mfcc(x[i], 500, ocfg)
+            assert out[i].shape == ref.shape
+            ok, worst = frame_linf_close(out[i], ref, RTOL, ATOL_DB)
+            assert ok, (over, i, worst)

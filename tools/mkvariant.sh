@@ -6,5 +6,5 @@ NAME=$1; shift
 mkdir -p "$ROOT/variants"
 cd "$ROOT/dsp_amd/csrc"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -Wno-unused-value \
-    -Rpass-analysis=kernel-resource-usage "$@" -o "$ROOT/variants/$NAME.so" capi.cpp tables.cpp mfcc_kernels.hip mfcc_row_kernel.hip classify_kernels.hip svm_kernels.hip 2>&1 \
+    -Rpass-analysis=kernel-resource-usage "$@" -o "$ROOT/variants/$NAME.so" capi.cpp tables.cpp mfcc_kernels.hip mfcc_row_kernel.hip mfcc1024_kernel.hip classify_kernels.hip svm_kernels.hip 2>&1 \
     | grep -E "error|VGPRs:|Occupancy \[|ScratchSize" | head -3
