@@ -104,7 +104,17 @@ def cpu_baseline(sample_frames: int, seconds_budget: float = 25.0):
 def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
     """Secondary measurements (not the headline metric): same timing protocol, its own JSON line."""
     gen = torch.Generator(device=dev).manual_seed(2000 + rank)
-    if args.workload == "clips":
+    if args.workload == "config3":
+        n = args.clips or 1_000_000
+        frames = torch.rand((n, 1024), device=dev, generator=gen) * 2 - 1
+        plan = dsp_amd.MfccPlan(dsp_amd.default_config(n_fft=1024, frame_length=1024, hop_length=1024, n_mels=128, prefilter=2), local)
+        out = torch.empty((n, 13), device=dev)
+        step = lambda: plan.frames(frames, out)               # noqa: E731
+        units, unit, bytes_per = n, "frames/s", 4096 + 52      # SURVEY 8(d): 4 148 B per frame
+        what = (f"BASELINE configs[2] at {n} frames: float64 Butterworth 3000-7500 Hz per 1024-sample frame from zero state "
+                "-> Hann(1024) -> 1024-pt FFT -> 128 HTK mel -> dB -> 13 coeffs (two passes: IIR kernel, then the general 1024 kernel)")
+        kernel = "iir_kernel<double,float> + mfcc1024_kernel"
+    elif args.workload == "clips":
         n = args.clips or 12_500
         clips = torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1
         plan = dsp_amd.MfccPlan(dsp_amd.default_config(), local)
@@ -157,7 +167,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="all-gather the per-rank features every step (RCCL)")
-    ap.add_argument("--workload", choices=["frames", "clips", "classify"], default="frames",
+    ap.add_argument("--workload", choices=["frames", "clips", "classify", "config3"], default="frames",
                     help="frames = BASELINE configs[1] (the headline metric, default); clips = configs[3] per-GPU share "
                          "(12 500 x 1 s clips, reference framing 400/160); classify = the donut classifier on 1 s clips")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step for --workload clips / classify")

@@ -23,8 +23,9 @@ namespace dsp {
 // a9: direct form II, one lane per clip, time tiles transposed through LDS so HBM sees
 // coalesced 128-byte rows although each lane walks its own clip.
 // ---------------------------------------------------------------------------------
-constexpr int IIR_TS = 32;       // samples per tile
-constexpr int IIR_LD = IIR_TS + 1;   // +1 word: lane l reads column i of row l -> banks (33 l + i) % 32 distinct
+constexpr int IIR_TS = 16;       // samples per tile: small tiles keep LDS per block low -> more resident waves to
+                                 // hide the serial recurrence's latency (measured 3x over 32-sample tiles at fp64)
+constexpr int IIR_LD = IIR_TS + 1;   // +1 word: lane l reads column i of row l -> banks (17 l + i) % 32 distinct
 
 template <typename T>
 struct IirState { T d[8]; };
@@ -60,9 +61,30 @@ __global__ __launch_bounds__(64) void iir_kernel(const TIO *__restrict__ x, long
     IirState<T> s1, s2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1.d[j] = T(0); s2.d[j] = T(0); }
+    // 16-byte vector path needs every row start and every tile start 16-byte aligned
+    const bool vec_ok = (stride * sizeof(TIO)) % 16 == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0 &&
+                        (reinterpret_cast<uintptr_t>(y1) % 16) == 0 && (!TWO || (reinterpret_cast<uintptr_t>(y2) % 16) == 0);
     for (int t0 = 0; t0 < n; t0 += IIR_TS) {
         const int cols = n - t0 < IIR_TS ? n - t0 : IIR_TS;
-        // coalesced load: 64 rows x IIR_TS columns, lane -> (row = e / TS, col = e % TS)
+        // tile load: 64 rows x IIR_TS columns.  Fast path: 16-byte vectors (4 lanes cover one
+        // 64-byte row segment); otherwise element-wise, lane -> (row = e / TS, col = e % TS)
+        const bool vec = vec_ok && cols == IIR_TS;
+        if (vec) {
+            constexpr int PER = 16 / sizeof(TIO), CH = IIR_TS / PER;      // elements per vector, vectors per row
+            for (int e = lane; e < 64 * CH; e += 64) {
+                const int r = e / CH, c = (e % CH) * PER;
+                TIO tmp[PER];
+                if (r < rows) {
+                    const float4 q = *reinterpret_cast<const float4 *>(x + (clip0 + r) * stride + t0 + c);
+                    __builtin_memcpy(tmp, &q, 16);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) tmp[i] = TIO(0);
+                }
+#pragma unroll
+                for (int i = 0; i < PER; ++i) tin[r * IIR_LD + c + i] = tmp[i];
+            }
+        } else
         for (int e = lane; e < 64 * IIR_TS; e += 64) {
             const int r = e / IIR_TS, cidx = e % IIR_TS;
             TIO v = TIO(0);
@@ -78,6 +100,26 @@ __global__ __launch_bounds__(64) void iir_kernel(const TIO *__restrict__ x, long
             }
         }
         __syncthreads();
+        if (vec) {
+            constexpr int PER = 16 / sizeof(TIO), CH = IIR_TS / PER;
+            for (int e = lane; e < 64 * CH; e += 64) {
+                const int r = e / CH, c = (e % CH) * PER;
+                if (r < rows) {
+                    TIO tmp[PER];
+                    float4 q;
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) tmp[i] = tout1[r * IIR_LD + c + i];
+                    __builtin_memcpy(&q, tmp, 16);
+                    *reinterpret_cast<float4 *>(y1 + (clip0 + r) * stride + t0 + c) = q;
+                    if (TWO) {
+#pragma unroll
+                        for (int i = 0; i < PER; ++i) tmp[i] = tout2[r * IIR_LD + c + i];
+                        __builtin_memcpy(&q, tmp, 16);
+                        *reinterpret_cast<float4 *>(y2 + (clip0 + r) * stride + t0 + c) = q;
+                    }
+                }
+            }
+        } else
         for (int e = lane; e < 64 * IIR_TS; e += 64) {
             const int r = e / IIR_TS, cidx = e % IIR_TS;
             if (r < rows && cidx < cols) {
