@@ -44,8 +44,10 @@ bool valid_cfg(const dsp_mfcc_config &c, std::string &why)
     if (c.hop_length & 1) { why = "hop_length must be even (8-byte aligned frame loads)"; return false; }
     if (!(c.fmax > c.fmin) || c.fmin < 0) { why = "need 0 <= fmin < fmax"; return false; }
     if (!(c.amin > 0)) { why = "amin must be positive"; return false; }
-    if (c.log_mode != DSP_LOG_PER_FRAME_MAX) { why = "only DSP_LOG_PER_FRAME_MAX is implemented"; return false; }
+    if (c.log_mode != DSP_LOG_PER_FRAME_MAX && c.log_mode != DSP_LOG_GLOBAL_REF1) { why = "unknown log_mode"; return false; }
+    if (c.log_mode == DSP_LOG_GLOBAL_REF1 && c.n_fft != 512) { why = "DSP_LOG_GLOBAL_REF1 is implemented for n_fft = 512"; return false; }
     if (c.frame_length > c.n_fft) { why = "frame_length must not exceed n_fft"; return false; }
+    if (c.win_length < 0 || c.win_length > c.frame_length) { why = "win_length must be in [0, frame_length]"; return false; }
     if (c.prefilter != DSP_PREFILTER_NONE && c.prefilter != DSP_PREFILTER_BUTTER_1000_3000 &&
         c.prefilter != DSP_PREFILTER_BUTTER_3000_7500) { why = "unknown prefilter"; return false; }
     if (c.n_fft != 512 && c.n_fft != 1024) { why = "n_fft must be 512 or 1024"; return false; }
@@ -68,6 +70,8 @@ struct dsp_mfcc_plan {
     int resident_blocks_gen = 3;
     float *d_filtered = nullptr;                  // per-frame prefilter output (sub-batch)
     size_t filtered_cap = 0;
+    float *d_frame_max = nullptr, *d_clip_floor = nullptr;   // DSP_LOG_GLOBAL_REF1 two-pass workspace
+    size_t frame_max_cap = 0, clip_floor_cap = 0;
     int kernel = DSP_KERNEL_WAVE;
     int resident_blocks_row = 3;
     // staging for the host-pointer entry points
@@ -101,6 +105,7 @@ void dsp_mfcc_default_config(dsp_mfcc_config *c)
     c->mel_norm = DSP_MELNORM_NONE;
     c->log_mode = DSP_LOG_PER_FRAME_MAX;
     c->prefilter = DSP_PREFILTER_NONE;
+    c->win_length = 0;
     c->fmin = 0.0f;
     c->fmax = 8000.0f;
     c->amin = 1e-10f;
@@ -119,7 +124,7 @@ int dsp_mfcc_tables(const dsp_mfcc_config *cfg, float *window, float *mel, float
 {
     if (!cfg) return fail(DSP_EINVAL, "cfg is NULL");
     if (window) {
-        auto w = dsp::make_window(cfg->window, cfg->frame_length);
+        auto w = dsp::make_frame_window(*cfg);
         std::memcpy(window, w.data(), w.size() * sizeof(float));
     }
     if (mel) {
@@ -224,6 +229,8 @@ void dsp_mfcc_plan_destroy(dsp_mfcc_plan *p)
     if (p->d_row_tables) hipFree(p->d_row_tables);
     if (p->d_gen_tables) hipFree(p->d_gen_tables);
     if (p->d_filtered) hipFree(p->d_filtered);
+    if (p->d_frame_max) hipFree(p->d_frame_max);
+    if (p->d_clip_floor) hipFree(p->d_clip_floor);
     if (p->d_in) hipFree(p->d_in);
     if (p->d_out) hipFree(p->d_out);
     delete p;
@@ -251,6 +258,15 @@ int dsp_mfcc_plan_set_launch(dsp_mfcc_plan *p, int blocks_per_cu, int frames_per
     return DSP_OK;
 }
 
+static int reserve(float **buf, size_t *cap, size_t need)
+{
+    if (*cap >= need) return DSP_OK;
+    if (*buf) { hipFree(*buf); *buf = nullptr; *cap = 0; }
+    DSP_HIP(hipMalloc(buf, need));
+    *cap = need;
+    return DSP_OK;
+}
+
 static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames, int frames_per_clip,
                long clip_stride, void *stream)
 {
@@ -275,6 +291,9 @@ static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames,
     a.n_mfcc = p->cfg.n_mfcc;
     a.amin = p->cfg.amin;
     a.top_db = p->cfg.top_db;
+    a.log_mode = p->cfg.log_mode;
+    a.frame_max = nullptr;
+    a.clip_floor = nullptr;
     // persistent-style grid: exactly the 4-wave blocks the chip holds at once (one
     // extra block per CU would run as a second, mostly idle round: measured +14 %),
     // never more blocks than there are chunks of work
@@ -283,6 +302,25 @@ static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames,
     long blocks = (long)p->n_cu * per_cu;
     const long chunks = (n_frames + a.chunk - 1) / a.chunk;
     blocks = std::max(1L, std::min(blocks, (chunks + 3) / 4));
+    if (a.log_mode == DSP_LOG_GLOBAL_REF1 && frames_per_clip > 0) {
+        // clip-global top_db: pass 1 writes each frame's maximum, a tiny kernel turns them into one
+        // floor per clip, pass 2 is the normal kernel clipping at that floor
+        const long n_clips = n_frames / frames_per_clip;
+        int rc;
+        if ((rc = reserve(&p->d_frame_max, &p->frame_max_cap, (size_t)n_frames * sizeof(float))) < 0) return rc;
+        if ((rc = reserve(&p->d_clip_floor, &p->clip_floor_cap, (size_t)n_clips * sizeof(float))) < 0) return rc;
+        a.frame_max = p->d_frame_max;
+        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+        DSP_HIP(dsp::launch_clip_floor(p->d_frame_max, n_clips, frames_per_clip, a.top_db, p->d_clip_floor, (hipStream_t)stream));
+        a.frame_max = nullptr;
+        a.clip_floor = p->d_clip_floor;
+        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+        return DSP_OK;
+    }
+    if (a.log_mode == DSP_LOG_GLOBAL_REF1) {      // independent frames: one pass, wave-per-frame kernel only
+        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+        return DSP_OK;
+    }
     if (gen)
         DSP_HIP(dsp::launch_mfcc1024(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream));
     else if (row)
@@ -290,15 +328,6 @@ static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames,
                                         (hipStream_t)stream));
     else
         DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
-    return DSP_OK;
-}
-
-static int reserve(float **buf, size_t *cap, size_t need)
-{
-    if (*cap >= need) return DSP_OK;
-    if (*buf) { hipFree(*buf); *buf = nullptr; *cap = 0; }
-    DSP_HIP(hipMalloc(buf, need));
-    *cap = need;
     return DSP_OK;
 }
 

@@ -184,6 +184,8 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
 
     auto step = [&](c32 (&nxt)[NF][4]) -> bool {
         const long f = cur.f;
+        const long clip_f = cur.clip;       // clip of frame f (clip mode)
+        const int t_f = cur.t;
         c32 s[NF][4];
 #pragma unroll
         for (int u = 0; u < NF; ++u)
@@ -333,6 +335,30 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
         // cancellation between two ~-100 dB terms, and exactly invariant to a
         // power-of-two gain on the input.  (e, amin, ref are non-negative: their max
         // is an unsigned-integer max of the bit patterns, no NaN canonicalisation.)
+        if (args.log_mode != 0) {
+            // librosa power_to_db(ref = 1.0, top_db over the clip), keyword_classifier.py:42-55
+            bool pass1 = args.frame_max != nullptr;
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                const float k10 = 3.01029995663981195f;
+                const float top = __uint_as_float(max(__float_as_uint(wave_max_nonneg(e[u])), amin_u));
+                const float top_db_val = k10 * __builtin_amdgcn_logf(top);      // frame maximum in dB
+                if (pass1) {
+                    if (lane == 0 && (u == 0 || f + u < n_frames)) args.frame_max[f + u] = top_db_val;
+                    continue;
+                }
+                long clip_of = clip_f;
+                if (u > 0 && args.frames_per_clip > 0) {
+                    int tu = t_f + u;
+                    while (tu >= args.frames_per_clip) { tu -= args.frames_per_clip; ++clip_of; }
+                }
+                const float floor_db = args.clip_floor ? args.clip_floor[clip_of] : top_db_val + neg_top_db;
+                const float ec = __uint_as_float(max(__float_as_uint(e[u]), amin_u));
+                const float db = fmaxf(k10 * __builtin_amdgcn_logf(ec), floor_db);
+                if (lane < n_mels) lmel[u][lmel_wr] = db;
+            }
+            if (pass1) { wave_lds_sync(); return more; }
+        } else {
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
             const float ref = __uint_as_float(max(__float_as_uint(wave_max_nonneg(e[u])), amin_u));
@@ -341,6 +367,7 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
             float db = k10 * __builtin_amdgcn_logf(ec * __builtin_amdgcn_rcpf(ref));
             db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f); // clamp to [-top_db, 0]: the frame max is exactly 0
             if (lane < n_mels) lmel[u][lmel_wr] = db;
+        }
         }
         wave_lds_sync();
 
@@ -399,6 +426,25 @@ hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, i
     DSP_LAUNCH(2, 20, 6)
 #undef DSP_LAUNCH
     return hipErrorInvalidConfiguration;
+}
+
+__global__ void clip_floor_kernel(const float *__restrict__ frame_max, long n_clips, int fpc, float top_db,
+                                  float *__restrict__ clip_floor)
+{
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clips) return;
+    float m = -INFINITY;
+    for (int t = 0; t < fpc; ++t) m = fmaxf(m, frame_max[c * fpc + t]);
+    clip_floor[c] = m - top_db;
+}
+
+hipError_t launch_clip_floor(const float *frame_max, long n_clips, int frames_per_clip, float top_db, float *clip_floor,
+                             hipStream_t stream)
+{
+    if (n_clips <= 0) return hipSuccess;
+    hipLaunchKernelGGL(clip_floor_kernel, dim3((unsigned)((n_clips + 255) / 256)), dim3(256), 0, stream, frame_max, n_clips,
+                       frames_per_clip, top_db, clip_floor);
+    return hipGetLastError();
 }
 
 int mfcc512_lds_bytes_per_block() { return 4 * DSP_NF * LDS_WAVE_BYTES; }

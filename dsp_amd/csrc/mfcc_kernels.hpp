@@ -19,7 +19,18 @@ struct Mfcc512Args {
     int chunk;                     // consecutive frames one wave takes at a time
     int n_mels, n_mfcc;
     float amin, top_db;
+    // log_mode 1 (librosa power_to_db, ref = 1, top_db over the whole clip):
+    //   frame_max != nullptr : pass 1, only write 10 log10(max mel energy) per frame, no MFCC
+    //   clip_floor != nullptr: pass 2, clip log-mel at clip_floor[clip]
+    //   both nullptr         : every frame is its own clip (independent frames), one pass
+    int log_mode;
+    float *frame_max;
+    const float *clip_floor;
 };
+
+// clip_floor[c] = max_t frame_max[c][t] - top_db
+hipError_t launch_clip_floor(const float *frame_max, long n_clips, int frames_per_clip, float top_db, float *clip_floor,
+                             hipStream_t stream);
 
 hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks,
                           hipStream_t stream);

@@ -24,6 +24,18 @@ std::vector<float> make_window(int kind, int n)
     return w;
 }
 
+// The per-frame window: `frame_length` taps; a shorter `win_length` window sits centred with
+// zeros either side (librosa.util.pad_center, 2fa/audio/word/python/keyword_classifier.py:42-55).
+std::vector<float> make_frame_window(const dsp_mfcc_config &cfg)
+{
+    if (cfg.win_length <= 0 || cfg.win_length >= cfg.frame_length) return make_window(cfg.window, cfg.frame_length);
+    std::vector<float> w(cfg.frame_length, 0.0f);
+    const std::vector<float> core = make_window(cfg.window, cfg.win_length);
+    const int lpad = (cfg.frame_length - cfg.win_length) / 2;
+    for (int i = 0; i < cfg.win_length; ++i) w[lpad + i] = core[i];
+    return w;
+}
+
 // librosa.filters.mel(htk=True, norm=None|'slaney') (export_mfcc_params.py:49-57).
 std::vector<float> make_mel_filterbank(int sample_rate, int n_fft, int n_mels, float fmin,
                                        float fmax, int mel_norm)
@@ -86,7 +98,7 @@ bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::st
     if (cfg.n_mfcc < 1 || cfg.n_mfcc > 16) { why = "n_mfcc must be in [1, 16] for n_fft = 1024"; return false; }
     t.n_mels = cfg.n_mels;
     t.n_mfcc = cfg.n_mfcc;
-    std::vector<float> win = make_window(cfg.window, cfg.frame_length);
+    std::vector<float> win = make_frame_window(cfg);
     win.resize(n_fft, 0.0f);
     for (int l = 0; l < kLanes; ++l)
         for (int a = 0; a < 8; ++a) {
@@ -141,7 +153,7 @@ bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::st
 void build_row_tables_512(const dsp_mfcc_config &cfg, RowTables512 &t)
 {
     std::memset(&t, 0, sizeof(t));
-    std::vector<float> win = make_window(cfg.window, cfg.frame_length);
+    std::vector<float> win = make_frame_window(cfg);
     win.resize(512, 0.0f);
     for (int l = 0; l < kLanes; ++l) {
         const int j = l & 15;
@@ -169,7 +181,7 @@ bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::st
     // window, pre-scaled by 1/2: the packed real FFT untangling X[k] =
     // ((Z[k]+Z*[N/2-k]) - i W^k (Z[k]-Z*[N/2-k]))/2 then needs no scaling
     // (multiplying by 0.5 is exact in binary floating point).
-    std::vector<float> win = make_window(cfg.window, cfg.frame_length);
+    std::vector<float> win = make_frame_window(cfg);
     win.resize(n_fft, 0.0f);
     for (int l = 0; l < kLanes; ++l)
         for (int a = 0; a < 4; ++a) {

@@ -26,6 +26,7 @@ namespace dsp {
 
 // ---- plain tables (reference layouts) --------------------------------------
 std::vector<float> make_window(int kind, int n);                                  // export_mfcc_params.py:46
+std::vector<float> make_frame_window(const dsp_mfcc_config &cfg);                 // frame_length taps; win_length centred (librosa pad_center)
 std::vector<float> make_mel_filterbank(int sample_rate, int n_fft, int n_mels,    // :49-57, [n_mels][n_fft/2+1]
                                        float fmin, float fmax, int mel_norm);
 std::vector<float> make_dct_ortho(int n_mfcc, int n_mels);                        // :27-41, [n_mfcc][n_mels]

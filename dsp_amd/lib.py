@@ -19,7 +19,7 @@ class MfccConfig(C.Structure):
         ("sample_rate", C.c_int), ("n_fft", C.c_int), ("frame_length", C.c_int),
         ("hop_length", C.c_int), ("n_mels", C.c_int), ("n_mfcc", C.c_int),
         ("window", C.c_int), ("mel_norm", C.c_int), ("log_mode", C.c_int),
-        ("prefilter", C.c_int),
+        ("prefilter", C.c_int), ("win_length", C.c_int),
         ("fmin", C.c_float), ("fmax", C.c_float), ("amin", C.c_float), ("top_db", C.c_float),
     ]
 

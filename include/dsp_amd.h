@@ -74,6 +74,7 @@ typedef struct dsp_mfcc_config {
     int mel_norm;     /* DSP_MELNORM_* (reference: none, export_mfcc_params.py:56) */
     int log_mode;     /* DSP_LOG_*     (reference: per-frame max, mfcc.c:169-206) */
     int prefilter;    /* DSP_PREFILTER_* fp64 Butterworth per frame from zero state */
+    int win_length;   /* 0 = frame_length; else window taps centred in the frame (librosa win_length < n_fft) */
     float fmin, fmax; /* 0, 8000 */
     float amin;       /* 1e-10 */
     float top_db;     /* 80 */

@@ -35,6 +35,7 @@ void orc_mfcc_default_cfg(orc_mfcc_cfg *c)
     c->log_mode = ORC_LOG_PER_FRAME_MAX;  /* mfcc.c:169-206 */
     c->fft_mode = ORC_FFT_REFERENCE_ORDER;
     c->prefilter = ORC_PREFILTER_NONE;
+    c->win_length = 0;
     c->fmin = 0.0f;
     c->fmax = 8000.0f;
     c->amin = 1e-10f;                     /* mfcc.c:172 */
@@ -317,7 +318,14 @@ static void plan_init(mfcc_plan *p, const orc_mfcc_cfg *cfg)
     p->window = (float *)malloc(sizeof(float) * (size_t)cfg->frame_length);
     p->mel = (float *)malloc(sizeof(float) * (size_t)cfg->n_mels * (size_t)p->n_bins);
     p->dct = (float *)malloc(sizeof(float) * (size_t)cfg->n_mfcc * (size_t)cfg->n_mels);
-    orc_window(cfg->window, cfg->frame_length, p->window);
+    if (cfg->win_length > 0 && cfg->win_length < cfg->frame_length) {
+        /* librosa.util.pad_center(get_window(win_length), size=n_fft): zeros either side */
+        const int lpad = (cfg->frame_length - cfg->win_length) / 2;
+        memset(p->window, 0, sizeof(float) * (size_t)cfg->frame_length);
+        orc_window(cfg->window, cfg->win_length, p->window + lpad);
+    } else {
+        orc_window(cfg->window, cfg->frame_length, p->window);
+    }
     orc_mel_filterbank(cfg->sample_rate, cfg->n_fft, cfg->n_mels, cfg->fmin,
                        cfg->fmax, cfg->mel_norm, p->mel);
     orc_dct_ortho(cfg->n_mfcc, cfg->n_mels, p->dct);

@@ -59,6 +59,9 @@ typedef struct orc_mfcc_cfg {
     int fft_mode;      /* ORC_FFT_*      */
     int prefilter;     /* ORC_PREFILTER_* : fp64 IIR applied per frame from zero
                           state before the window (BASELINE config 3)          */
+    int win_length;    /* 0 = frame_length; else the window has win_length taps
+                          centred in the frame (librosa win_length < n_fft,
+                          2fa/audio/word/python/keyword_classifier.py:42-55)    */
     float fmin, fmax;  /* 0, sample_rate/2 */
     float amin;        /* 1e-10 (mfcc.c:172) */
     float top_db;      /* 80    (mfcc.c:173) */

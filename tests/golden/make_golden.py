@@ -18,6 +18,7 @@ Fixtures written (all float32 unless noted):
   classifier_ref.npz  butter filter / spectrogram / midpoints / classify goldens
                       (sync/lib/classifier.cpp)
   pcm_kat.npz         donut-classifier/data/*.wav.txt PCM16->float dump excerpt
+  librosa_mfcc_kat.npz  TEST_MFCC of 2fa/audio/word/c/test_mfcc.h (librosa-mode MFCC of stop_121417.wav)
 """
 from __future__ import annotations
 
@@ -143,6 +144,17 @@ def main():
         print(f"classify {name:16s} T={T} midpoints={nm} label={label}")
     cout["freqs"] = fr; cout["times_16000"] = tm
     np.savez_compressed(os.path.join(HERE, "classifier_ref.npz"), **cout)
+
+    # ---- the reference's only in-repo MFCC golden: TEST_MFCC (2fa/audio/word/c/test_mfcc.h:8) -------
+    # librosa-mode features of data/testing/stop_121417.wav, coefficient-major [13][1000], zero padded
+    # (exporter: 2fa/audio/word/python/export_test_mfcc.py:21-39).  Numbers only, parsed from the header.
+    import re
+    txt = open(os.path.join(ref, "2fa/audio/word/c/test_mfcc.h")).read()
+    body = txt[txt.index("TEST_MFCC[13000]"):]
+    vals = np.array([float(v) for v in re.findall(r"[-+]?\d\.\d+e[-+]\d+", body)], np.float32)
+    assert vals.size == 13000
+    np.savez_compressed(os.path.join(HERE, "librosa_mfcc_kat.npz"), test_mfcc=vals.reshape(13, 1000), pcm=stop[:, 0].copy())
+    print("TEST_MFCC golden:", vals.reshape(13, 1000)[:, :3])
 
     # ---- PCM16 -> float dump (donut-classifier/classifier.c:64-81) -------------
     txt = os.path.join(ref, "donut-classifier/data/birdQ_stereo_16k.wav.txt")
