@@ -267,14 +267,18 @@ static int reserve(float **buf, size_t *cap, size_t need)
     return DSP_OK;
 }
 
-static int run(dsp_mfcc_plan *p, const float *d_in, float *d_out, long n_frames, int frames_per_clip,
-               long clip_stride, void *stream)
+static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, int frames_per_clip,
+               long clip_stride, void *stream, int in_kind = 0)
 {
     if (n_frames == 0) return DSP_OK;
-    if ((reinterpret_cast<uintptr_t>(d_in) & 7) || (clip_stride & 1))
-        return fail(DSP_EINVAL, "input must be 8-byte aligned with an even clip stride");
+    const bool single_clip = frames_per_clip > 0 && n_frames == frames_per_clip;   // stride unused
+    if ((reinterpret_cast<uintptr_t>(d_in) & (in_kind == 1 ? 3 : 7)) || (!single_clip && (clip_stride & 1)))
+        return fail(DSP_EINVAL, "input must be 8-byte aligned (4 for mono int16) with an even clip stride");
+    if (in_kind != 0 && (p->cfg.n_fft != 512 || p->kernel != DSP_KERNEL_WAVE || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX))
+        return fail(DSP_EINVAL, "PCM16 ingestion runs on the 512-point wave-per-frame kernel, per-frame log mode");
     dsp::Mfcc512Args a;
     a.in = d_in;
+    a.in_kind = in_kind;
     a.out = d_out;
     a.tables = p->d_tables;
     a.n_frames = n_frames;
@@ -367,6 +371,22 @@ int dsp_mfcc_clips_device(dsp_mfcc_plan *p, const float *d_signal, long n_clips,
     const int rc = run(p, d_signal, d_out, n_clips * (long)t, t, clip_stride, stream);
     return rc < 0 ? rc : t;
 }
+
+int dsp_mfcc_clips_pcm16_device(dsp_mfcc_plan *p, const int16_t *d_pcm, long n_clips, int samples_per_clip,
+                                long clip_stride, int channels, int stereo_mode, float *d_out, int max_frames, void *stream)
+{
+    if (!p || n_clips < 0 || (channels != 1 && channels != 2)) return fail(DSP_EINVAL, "bad argument");
+    if (channels == 2 && stereo_mode != DSP_STEREO_CHANNEL0 && stereo_mode != DSP_STEREO_AVERAGE) return fail(DSP_EINVAL, "bad stereo_mode");
+    if (p->cfg.prefilter != DSP_PREFILTER_NONE) return fail(DSP_EINVAL, "the per-frame prefilter applies to independent float frames only");
+    const int t = dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
+    if (t == 0 || n_clips == 0) return 0;
+    if (!d_pcm || !d_out) return fail(DSP_EINVAL, "NULL buffer");
+    if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
+    const int kind = channels == 1 ? 1 : (stereo_mode == DSP_STEREO_CHANNEL0 ? 2 : 3);
+    const int rc = run(p, d_pcm, d_out, n_clips * (long)t, t, clip_stride, stream, kind);
+    return rc < 0 ? rc : t;
+}
+
 
 int dsp_mfcc_frames_host(dsp_mfcc_plan *p, const float *frames, long n_frames, float *out)
 {

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void mfcc1024_kernel(const Mfcc512Args args, c
     const int frame_len = args.frame_len;
 
     auto frame_src = [&](const FrameCursor &c) -> const float * {
-        if (args.frames_per_clip <= 0) return args.in + c.f * (long)frame_len;
-        return args.in + c.clip * args.clip_stride + (long)c.t * args.hop;
+        if (args.frames_per_clip <= 0) return static_cast<const float *>(args.in) + c.f * (long)frame_len;
+        return static_cast<const float *>(args.in) + c.clip * args.clip_stride + (long)c.t * args.hop;
     };
     auto load_frame8 = [&](const float *src, c32 (&z)[8]) {
 #pragma unroll

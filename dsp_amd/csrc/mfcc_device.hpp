@@ -12,6 +12,7 @@ namespace {
 
 struct c32 { float x, y; };
 typedef float f2v __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ c32 cadd(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ c32 csub(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }

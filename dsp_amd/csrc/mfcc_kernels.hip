@@ -46,20 +46,52 @@ namespace dsp {
 
 namespace {
 
-template <bool FULL>
-__device__ __forceinline__ void load_frame(const float *__restrict__ src, int lane, int frame_len, c32 (&z)[4])
+// IN: element type of the input in HBM (SURVEY.md 8f-1, PCM16 ingestion on device):
+//   0 float32 PCM in [-1,1]
+//   1 int16 mono                     x = s / 32768                (main_test.c:198-203)
+//   2 int16 stereo, channel 0        x = L / 32768                (classifier.c:292-297)
+//   3 int16 stereo, channel average  x = 0.5 (L/32768 + R/32768)  (main_test.c:205-217)
+// The power-of-two scale is folded into the window (exact), so a lane only converts int -> float.
+// `off` is the frame's first sample (per channel).
+template <bool FULL, int IN>
+__device__ __forceinline__ void load_frame(const void *__restrict__ base, long off, int lane, int frame_len, c32 (&z)[4])
 {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int i = 2 * (lane + 64 * a);
-        if (FULL || i + 1 < frame_len) {
-            // streamed once: nontemporal keeps the frames from displacing anything in L2
-            const f2v v = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));
-            z[a] = {v.x, v.y};
-        } else if (i < frame_len) {
-            z[a] = {src[i], 0.0f};
+        const bool both = FULL || i + 1 < frame_len, one = i < frame_len;
+        if (IN == 0) {
+            const float *src = static_cast<const float *>(base) + off;
+            if (both) {
+                // streamed once: nontemporal keeps the frames from displacing anything in L2
+                const f2v v = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));
+                z[a] = {v.x, v.y};
+            } else if (one) {
+                z[a] = {src[i], 0.0f};
+            } else {
+                z[a] = {0.0f, 0.0f};
+            }
+        } else if (IN == 1) {
+            const short *src = static_cast<const short *>(base) + off;
+            if (both) {
+                const int v = __builtin_nontemporal_load(reinterpret_cast<const int *>(src + i));     // samples i, i+1
+                z[a] = {(float)(short)(v & 0xFFFF), (float)(v >> 16)};
+            } else if (one) {
+                z[a] = {(float)src[i], 0.0f};
+            } else {
+                z[a] = {0.0f, 0.0f};
+            }
         } else {
-            z[a] = {0.0f, 0.0f};
+            const short *src = static_cast<const short *>(base) + 2 * off;                            // interleaved L R
+            int l0 = 0, r0 = 0, l1 = 0, r1 = 0;
+            if (both) {
+                const i2v v = __builtin_nontemporal_load(reinterpret_cast<const i2v *>(src + 2 * i));  // L0 R0 | L1 R1
+                l0 = (short)(v.x & 0xFFFF); r0 = v.x >> 16; l1 = (short)(v.y & 0xFFFF); r1 = v.y >> 16;
+            } else if (one) {
+                const int v = *reinterpret_cast<const int *>(src + 2 * i);
+                l0 = (short)(v & 0xFFFF); r0 = v >> 16;
+            }
+            z[a] = IN == 2 ? c32{(float)l0, (float)l1} : c32{(float)(l0 + r0), (float)(l1 + r1)};
         }
     }
 }
@@ -74,7 +106,7 @@ __device__ __forceinline__ void load_frame(const float *__restrict__ src, int la
 // faster than NF = 1 (the kernel is issue-bound, not latency-bound) and the two
 // unrolled copies may contract FMAs differently, so NF = 1 is the default: every
 // frame runs the same instructions and results do not depend on a frame's position.
-template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL, int NF>
+template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL, int NF, int IN = 0>
 __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args args)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -95,8 +127,9 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
 
     // ---- per-lane constants (one coalesced dword per field) -----------------
     float win[8];
+    constexpr float in_scale = IN == 0 ? 1.0f : (IN == 3 ? 1.0f / 65536.0f : 1.0f / 32768.0f);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) win[i] = T->win[i][lane];
+    for (int i = 0; i < 8; ++i) win[i] = T->win[i][lane] * in_scale;
     c32 tw1[3], tw2[3], tw3[3], twp[2];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -159,17 +192,17 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
     const long n_frames = args.n_frames;
 
     // source of frame c.f + u (u < NF)
-    auto frame_src_of = [&](const FrameCursor &c, int u) -> const float * {
-        if (args.frames_per_clip <= 0) return args.in + (c.f + u) * (long)frame_len;
+    auto frame_src_of = [&](const FrameCursor &c, int u) -> long {
+        if (args.frames_per_clip <= 0) return (c.f + u) * (long)frame_len;
         long clip = c.clip;
         int t = c.t + u;
         while (t >= c.fpc) { t -= c.fpc; ++clip; }
-        return args.in + clip * args.clip_stride + (long)t * args.hop;
+        return clip * args.clip_stride + (long)t * args.hop;
     };
     auto load_item = [&](const FrameCursor &c, c32 (&z)[NF][4]) {
 #pragma unroll
         for (int u = 0; u < NF; ++u) {
-            if (u == 0 || c.f + u < n_frames) load_frame<FULL>(frame_src_of(c, u), lane, frame_len, z[u]);
+            if (u == 0 || c.f + u < n_frames) load_frame<FULL, IN>(args.in, frame_src_of(c, u), lane, frame_len, z[u]);
         }
     };
 
@@ -412,6 +445,21 @@ hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, i
 {
     const bool full = args.frame_len == 512;
     const size_t lds = (size_t)4 * DSP_NF * LDS_WAVE_BYTES;
+    if (args.in_kind != 0) {
+        // PCM16 ingestion is instantiated for the reference's DCT / mel shape (13 x 40)
+        if (!(dct_split == 4 && dct_len == 10 && gather == 3)) return hipErrorInvalidConfiguration;
+#define DSP_LAUNCH_IN(K)                                                                                             \
+        if (args.in_kind == K) {                                                                                     \
+            if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<4, 10, 3, true, DSP_NF, K>), dim3(blocks), dim3(256), lds, stream, args);   \
+            else hipLaunchKernelGGL((mfcc512_wave_kernel<4, 10, 3, false, DSP_NF, K>), dim3(blocks), dim3(256), lds, stream, args);  \
+            return hipGetLastError();                                                                                \
+        }
+        DSP_LAUNCH_IN(1)
+        DSP_LAUNCH_IN(2)
+        DSP_LAUNCH_IN(3)
+#undef DSP_LAUNCH_IN
+        return hipErrorInvalidConfiguration;
+    }
 #define DSP_LAUNCH(S, L, G)                                                                                          \
     if (dct_split == S && dct_len == L && gather == G) {                                                             \
         if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true, DSP_NF>), dim3(blocks), dim3(256), lds, stream, args);   \

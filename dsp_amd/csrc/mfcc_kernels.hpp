@@ -8,7 +8,8 @@
 namespace dsp {
 
 struct Mfcc512Args {
-    const float *in;               // HBM: frames or clips
+    const void *in;                // HBM: frames or clips; float32, or int16 PCM (in_kind)
+    int in_kind;                   // 0 float32 | 1 int16 mono | 2 int16 stereo ch 0 | 3 int16 stereo average
     float *out;                    // HBM: [n_frames][n_mfcc]
     const LaneTables512 *tables;   // HBM: per-lane constants
     long n_frames;                 // total frames over all clips

@@ -172,11 +172,11 @@ __global__ __launch_bounds__(256) void mfcc512_row_kernel(const Mfcc512Args args
 
     // this lane's frame is cur.f + g
     auto row_src = [&](const FrameCursor &c) -> const float * {
-        if (args.frames_per_clip <= 0) return args.in + (c.f + g) * (long)frame_len;
+        if (args.frames_per_clip <= 0) return static_cast<const float *>(args.in) + (c.f + g) * (long)frame_len;
         long clip = c.clip;
         int t = c.t + g;
         while (t >= c.fpc) { t -= c.fpc; ++clip; }
-        return args.in + clip * args.clip_stride + (long)t * args.hop;
+        return static_cast<const float *>(args.in) + clip * args.clip_stride + (long)t * args.hop;
     };
     c32 v[16];
     auto load_item = [&](const FrameCursor &c) {

@@ -57,7 +57,7 @@ SYMBOLS = [
     "dsp_mfcc_stats_device", "dsp_svm_create", "dsp_svm_destroy", "dsp_svm_predict_device",
     "dsp_mfcc_default_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
     "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",
-    "dsp_mfcc_clips_host", "dsp_mfcc_plan_set_launch", "dsp_mfcc_plan_set_kernel", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables",
+    "dsp_mfcc_clips_host", "dsp_mfcc_clips_pcm16_device", "dsp_mfcc_plan_set_launch", "dsp_mfcc_plan_set_kernel", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables",
     "dsp_last_error", "dsp_device_count", "dsp_version",
 ]
 
@@ -99,6 +99,7 @@ def load() -> C.CDLL:
     L.dsp_mfcc_frames_for.argtypes = [cfgp, ip, ip]; L.dsp_mfcc_frames_for.restype = ip
     L.dsp_mfcc_frames_device.argtypes = [vp, vp, C.c_long, vp, vp]; L.dsp_mfcc_frames_device.restype = ip
     L.dsp_mfcc_clips_device.argtypes = [vp, vp, C.c_long, ip, C.c_long, vp, ip, vp]; L.dsp_mfcc_clips_device.restype = ip
+    L.dsp_mfcc_clips_pcm16_device.argtypes = [vp, vp, C.c_long, ip, C.c_long, ip, ip, vp, ip, vp]; L.dsp_mfcc_clips_pcm16_device.restype = ip
     L.dsp_mfcc_frames_host.argtypes = [vp, vp, C.c_long, vp]; L.dsp_mfcc_frames_host.restype = ip
     L.dsp_mfcc_clips_host.argtypes = [vp, vp, C.c_long, ip, C.c_long, vp, ip]; L.dsp_mfcc_clips_host.restype = ip
     L.dsp_mfcc_plan_set_launch.argtypes = [vp, ip, ip]; L.dsp_mfcc_plan_set_launch.restype = ip

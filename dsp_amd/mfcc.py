@@ -118,6 +118,23 @@ class MfccPlan:
         _lib.check(self._L.dsp_mfcc_frames_device(self._h, frames.data_ptr(), n, out.data_ptr(), self._stream()), "dsp_mfcc_frames_device")
         return out
 
+    def clips_pcm16(self, pcm, max_frames: int, stereo_mode: int = 0, out=None):
+        """pcm: cuda int16 [n_clips][samples] (mono) or [n_clips][samples][2] (interleaved stereo;
+        stereo_mode 0 = channel 0, 1 = channel average) -> cuda float32 [n_clips][T][n_mfcc]."""
+        import torch
+        if not (pcm.is_cuda and pcm.dtype == torch.int16 and pcm.is_contiguous() and pcm.dim() in (2, 3)):
+            raise ValueError("pcm must be a contiguous int16 CUDA tensor [n_clips][samples] or [n_clips][samples][2]")
+        channels = 1 if pcm.dim() == 2 else int(pcm.shape[2])
+        n, s = int(pcm.shape[0]), int(pcm.shape[1])
+        t = frames_for(self.cfg, s, max_frames)
+        if out is None:
+            out = torch.empty((n, t, self.cfg.n_mfcc), dtype=torch.float32, device=pcm.device)
+        if n and t:
+            got = _lib.check(self._L.dsp_mfcc_clips_pcm16_device(self._h, pcm.data_ptr(), n, s, s, channels, int(stereo_mode),
+                                                                  out.data_ptr(), int(max_frames), self._stream()), "dsp_mfcc_clips_pcm16_device")
+            assert got == t
+        return out
+
     def clips(self, clips, max_frames: int, out=None):
         """clips: cuda float32 [n_clips][samples] -> cuda float32 [n_clips][T][n_mfcc]."""
         import torch

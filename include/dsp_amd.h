@@ -110,6 +110,16 @@ int dsp_mfcc_clips_device(dsp_mfcc_plan *plan, const float *d_signal, long n_cli
                           int samples_per_clip, long clip_stride, float *d_out,
                           int max_frames, void *stream);
 
+/* PCM16 ingestion on the device: the same framing on interleaved int16 PCM,
+ * converted in the load exactly like the reference's WAV readers: mono s/32768
+ * (2fa/audio/word/c/main_test.c:198-203); stereo channel 0 (donut-classifier/classifier.c:292-297)
+ * or the channel average 0.5(L/32768 + R/32768) (main_test.c:205-217).  samples_per_clip and
+ * clip_stride count samples PER CHANNEL.  Halves (mono) the HBM bytes of the float path.   */
+enum { DSP_STEREO_CHANNEL0 = 0, DSP_STEREO_AVERAGE = 1 };
+int dsp_mfcc_clips_pcm16_device(dsp_mfcc_plan *plan, const int16_t *d_pcm, long n_clips, int samples_per_clip,
+                                long clip_stride, int channels, int stereo_mode, float *d_out, int max_frames,
+                                void *stream);
+
 /* --- host-pointer conveniences: copy in, run, copy out, synchronise. -------- */
 int dsp_mfcc_frames_host(dsp_mfcc_plan *plan, const float *frames, long n_frames, float *out);
 int dsp_mfcc_clips_host(dsp_mfcc_plan *plan, const float *signal, long n_clips,

@@ -70,7 +70,7 @@ def test_bad_configs_are_rejected_before_touching_a_device():
     L = dsp_amd.load()
     h = C.c_void_p()
     for over, msg in ((dict(n_fft=256), "n_fft"), (dict(n_fft=1024, n_mels=200), "n_mels"), (dict(frame_length=401), "even"), (dict(hop_length=0), "hop"),
-                      (dict(n_mels=100), "n_mels"), (dict(log_mode=dl.LOG_GLOBAL_REF1), "LOG")):
+                      (dict(n_mels=100), "n_mels"), (dict(log_mode=7), "log_mode"), (dict(win_length=999), "win_length")):
         cfg = dsp_amd.default_config(**over)
         assert L.dsp_mfcc_plan_create(C.byref(cfg), 0, C.byref(h)) == -1
         assert msg.lower() in dl.last_error().lower()

@@ -277,3 +277,34 @@ def test_1024_point_clip_framing_and_other_shapes(dsp, torch_cuda):
             assert out[i].shape == ref.shape
             ok, worst = frame_linf_close(out[i], ref, RTOL, ATOL_DB)
             assert ok, (over, i, worst)
+
+
+def test_pcm16_ingestion_matches_float_path(dsp, torch_cuda, golden):
+    """int16 PCM converted in the kernel's load == the reference's WAV-reader conversions
+    followed by compute_mfcc (goldens birdq_ch0 / birdq_avg / stop_121417 come from exactly that)."""
+    torch = torch_cuda
+    g = golden("mfcc_ref.npz")
+    plan = dsp.MfccPlan()
+    bird = torch.from_numpy(g["birdq_pcm"].copy()).cuda()                  # [24029][2] int16, interleaved
+    stop = torch.from_numpy(g["stop_pcm"].copy()).cuda()
+    # stereo: channel 0 (donut-classifier/classifier.c:292-297) and average (main_test.c:205-217)
+    for mode, key in ((0, "birdq_ch0"), (1, "birdq_avg")):
+        out = plan.clips_pcm16(bird[None].contiguous(), 500, stereo_mode=mode).cpu().numpy()[0]
+        ok, worst = frame_linf_close(out, g["mfcc__" + key], RTOL, ATOL_DB)
+        assert out.shape == (148, 13) and ok, (key, worst)
+        # bit-identical to the float path fed with the reference's conversion
+        x = _cases(g)[key]
+        assert np.array_equal(out, plan.clips(torch.from_numpy(x[None]).cuda(), 500).cpu().numpy()[0])
+    out = plan.clips_pcm16(stop[None].contiguous(), 500).cpu().numpy()[0]   # mono
+    assert frame_linf_close(out, g["mfcc__stop_121417"], RTOL, ATOL_DB)[0]
+    assert np.array_equal(out, plan.clips(torch.from_numpy(_cases(g)["stop_121417"][None]).cuda(), 500).cpu().numpy()[0])
+    # batches, extreme samples, short clips
+    pcm = torch.randint(-32768, 32768, (33, 3000), dtype=torch.int16, device="cuda")
+    pcm[0, :8] = torch.tensor([-32768, 32767, 0, -1, 1, -32768, 32767, 0], dtype=torch.int16)
+    a = plan.clips_pcm16(pcm, 500)
+    b = plan.clips((pcm.float() / 32768.0).contiguous(), 500)
+    assert torch.equal(a, b)
+    st = torch.randint(-32768, 32768, (5, 3000, 2), dtype=torch.int16, device="cuda")
+    avg = 0.5 * (st[..., 0].float() / 32768.0 + st[..., 1].float() / 32768.0)
+    assert torch.equal(plan.clips_pcm16(st, 500, stereo_mode=1), plan.clips(avg.contiguous(), 500))
+    assert plan.clips_pcm16(pcm[:, :398].contiguous(), 500).shape[1] == 0
