@@ -104,7 +104,16 @@ def cpu_baseline(sample_frames: int, seconds_budget: float = 25.0):
 def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
     """Secondary measurements (not the headline metric): same timing protocol, its own JSON line."""
     gen = torch.Generator(device=dev).manual_seed(2000 + rank)
-    if args.workload == "config3":
+    if args.workload == "pcm16":
+        n = args.clips or 1_000_000
+        pcm = torch.randint(-32768, 32768, (n, FRAME), dtype=torch.int16, device=dev, generator=gen)
+        plan = dsp_amd.MfccPlan(dsp_amd.default_config(frame_length=FRAME, hop_length=FRAME), local)
+        out = torch.empty((n, 1, 13), device=dev)
+        step = lambda: plan.clips_pcm16(pcm, 1, out=out)       # noqa: E731
+        units, unit, bytes_per = n, "frames/s", FRAME * 2 + 52
+        what = f"{n} x 512-sample int16 mono frames (PCM16 ingestion in the kernel's load, SURVEY 8f-1), otherwise configs[1]"
+        kernel = "mfcc512_wave_kernel<IN=1>"
+    elif args.workload == "config3":
         n = args.clips or 1_000_000
         frames = torch.rand((n, 1024), device=dev, generator=gen) * 2 - 1
         plan = dsp_amd.MfccPlan(dsp_amd.default_config(n_fft=1024, frame_length=1024, hop_length=1024, n_mels=128, prefilter=2), local)
@@ -167,7 +176,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="all-gather the per-rank features every step (RCCL)")
-    ap.add_argument("--workload", choices=["frames", "clips", "classify", "config3"], default="frames",
+    ap.add_argument("--workload", choices=["frames", "clips", "classify", "config3", "pcm16"], default="frames",
                     help="frames = BASELINE configs[1] (the headline metric, default); clips = configs[3] per-GPU share "
                          "(12 500 x 1 s clips, reference framing 400/160); classify = the donut classifier on 1 s clips")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step for --workload clips / classify")
