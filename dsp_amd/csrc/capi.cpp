@@ -60,7 +60,8 @@ struct dsp_mfcc_plan {
     dsp_mfcc_config cfg;
     int device = 0;
     int n_cu = 0;
-    int resident_blocks = 4; // 256-thread blocks one CU holds (occupancy query)
+    int resident_blocks = 4; // 256-thread blocks one CU holds (occupancy query), tile epilogue kernel
+    int resident_blocks_frame = 4;   // same, per-frame epilogue kernel
     int blocks_per_cu = 0;   // 0 = default (= resident_blocks)
     int chunk = 0;           // 0 = default
     dsp::LaneTables512 host;
@@ -209,14 +210,21 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
     }
     p->n_cu = prop.multiProcessorCount;
     if (cfg->n_fft == 512) {
-        p->resident_blocks = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
-                                                        cfg->frame_length == 512);
+        p->resident_blocks_frame = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
+                                                              cfg->frame_length == 512, false);
+        p->resident_blocks = dsp::mfcc512_has_tile()
+                                 ? dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
+                                                              cfg->frame_length == 512, true)
+                                 : p->resident_blocks_frame;
         p->resident_blocks_row = dsp::mfcc512_row_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
                                                                 cfg->frame_length == 512);
     } else {
         p->resident_blocks_gen = dsp::mfcc1024_blocks_per_cu(cfg->frame_length == 1024);
     }
-    if (const char *k = std::getenv("DSP_AMD_KERNEL")) p->kernel = std::atoi(k) == 1 ? DSP_KERNEL_ROW : DSP_KERNEL_WAVE;
+    if (const char *k = std::getenv("DSP_AMD_KERNEL")) {
+        const int id = std::atoi(k);
+        p->kernel = id == 1 ? DSP_KERNEL_ROW : (id == 2 ? DSP_KERNEL_WAVE_FRAME : DSP_KERNEL_WAVE);
+    }
     *out = p;
     return DSP_OK;
 }
@@ -245,7 +253,7 @@ int dsp_mfcc_plan_config(const dsp_mfcc_plan *p, dsp_mfcc_config *cfg)
 
 int dsp_mfcc_plan_set_kernel(dsp_mfcc_plan *p, int kernel)
 {
-    if (!p || (kernel != DSP_KERNEL_WAVE && kernel != DSP_KERNEL_ROW)) return fail(DSP_EINVAL, "bad kernel id");
+    if (!p || (kernel != DSP_KERNEL_WAVE && kernel != DSP_KERNEL_ROW && kernel != DSP_KERNEL_WAVE_FRAME)) return fail(DSP_EINVAL, "bad kernel id");
     p->kernel = kernel;
     return DSP_OK;
 }
@@ -274,7 +282,7 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     const bool single_clip = frames_per_clip > 0 && n_frames == frames_per_clip;   // stride unused
     if ((reinterpret_cast<uintptr_t>(d_in) & (in_kind == 1 ? 3 : 7)) || (!single_clip && (clip_stride & 1)))
         return fail(DSP_EINVAL, "input must be 8-byte aligned (4 for mono int16) with an even clip stride");
-    if (in_kind != 0 && (p->cfg.n_fft != 512 || p->kernel != DSP_KERNEL_WAVE || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX))
+    if (in_kind != 0 && (p->cfg.n_fft != 512 || p->kernel != DSP_KERNEL_WAVE || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX || !dsp::mfcc512_has_tile()))
         return fail(DSP_EINVAL, "PCM16 ingestion runs on the 512-point wave-per-frame kernel, per-frame log mode");
     dsp::Mfcc512Args a;
     a.in = d_in;
@@ -288,9 +296,11 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     a.frame_len = p->cfg.frame_length;
     const bool gen = p->cfg.n_fft == 1024;
     const bool row = !gen && p->kernel == DSP_KERNEL_ROW;
-    const int nf = gen ? 1 : (row ? 4 : dsp::mfcc512_frames_per_item());
+    // 16-frame tile epilogue: per-frame log mode on the wave-per-frame kernel
+    const bool tile = !gen && p->kernel == DSP_KERNEL_WAVE && p->cfg.log_mode == DSP_LOG_PER_FRAME_MAX && dsp::mfcc512_has_tile();
+    const int nf = gen ? 1 : (row ? 4 : (tile ? 8 : dsp::mfcc512_frames_per_item()));
     a.chunk = p->chunk > 0 ? p->chunk : 8;
-    a.chunk = ((a.chunk + nf - 1) / nf) * nf;   // whole items per chunk
+    a.chunk = ((a.chunk + nf - 1) / nf) * nf;   // whole items (tile: half-tiles of 8 frames) per chunk
     a.n_mels = p->cfg.n_mels;
     a.n_mfcc = p->cfg.n_mfcc;
     a.amin = p->cfg.amin;
@@ -302,7 +312,8 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     // extra block per CU would run as a second, mostly idle round: measured +14 %),
     // never more blocks than there are chunks of work
     const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu
-                       : (gen ? p->resident_blocks_gen : (row ? p->resident_blocks_row : p->resident_blocks));
+                       : (gen ? p->resident_blocks_gen
+                              : (row ? p->resident_blocks_row : (tile ? p->resident_blocks : p->resident_blocks_frame)));
     long blocks = (long)p->n_cu * per_cu;
     const long chunks = (n_frames + a.chunk - 1) / a.chunk;
     blocks = std::max(1L, std::min(blocks, (chunks + 3) / 4));
@@ -314,15 +325,15 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
         if ((rc = reserve(&p->d_frame_max, &p->frame_max_cap, (size_t)n_frames * sizeof(float))) < 0) return rc;
         if ((rc = reserve(&p->d_clip_floor, &p->clip_floor_cap, (size_t)n_clips * sizeof(float))) < 0) return rc;
         a.frame_max = p->d_frame_max;
-        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream, false));
         DSP_HIP(dsp::launch_clip_floor(p->d_frame_max, n_clips, frames_per_clip, a.top_db, p->d_clip_floor, (hipStream_t)stream));
         a.frame_max = nullptr;
         a.clip_floor = p->d_clip_floor;
-        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream, false));
         return DSP_OK;
     }
     if (a.log_mode == DSP_LOG_GLOBAL_REF1) {      // independent frames: one pass, wave-per-frame kernel only
-        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream, false));
         return DSP_OK;
     }
     if (gen)
@@ -331,7 +342,7 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
         DSP_HIP(dsp::launch_mfcc512_row(a, p->d_row_tables, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks,
                                         (hipStream_t)stream));
     else
-        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+        DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream, tile));
     return DSP_OK;
 }
 

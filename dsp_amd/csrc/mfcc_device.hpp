@@ -13,6 +13,7 @@ namespace {
 struct c32 { float x, y; };
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef int i2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ c32 cadd(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ c32 csub(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
@@ -127,6 +128,7 @@ constexpr int LDS_XCHG = 0;                 // 256 x float2 exchange tile, later
 constexpr int LDS_PART = 2048 + 64;         // 65 partial sums (+ zero slot)
 constexpr int LDS_LOGMEL = LDS_PART + 320;  // up to 80 log-mel values
 constexpr int LDS_WAVE_BYTES = LDS_LOGMEL + 320;
+constexpr int LDS_TILE_BYTES = 64 * 16 * 4;   // mel energies of 16 frames, E[mel][frame ^ (mel>>2)]
 static_assert(LDS_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
 // wave-uniform cursor over the frames this wave owns: chunks of `chunk`
 // consecutive frames dealt round-robin to the waves of the grid, so one wave's

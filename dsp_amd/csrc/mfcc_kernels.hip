@@ -106,13 +106,28 @@ __device__ __forceinline__ void load_frame(const void *__restrict__ base, long o
 // faster than NF = 1 (the kernel is issue-bound, not latency-bound) and the two
 // unrolled copies may contract FMAs differently, so NF = 1 is the default: every
 // frame runs the same instructions and results do not depend on a frame's position.
-template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL, int NF, int IN = 0>
-__global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args args)
+//
+// TILE = 1 (default for the per-frame log mode): the log and the DCT leave the per-frame
+// path.  A frame ends with ONE ds_write of its mel energies into a 16-frame LDS tile
+// E[mel][frame]; every 16 frames the wave reads the tile back transposed (lane = (mel%4,
+// frame)), takes the per-frame maximum and the logs there (10 v_log per 16 frames instead
+// of 16) and runs the DCT as v_mfma_f32_16x16x4_f32: D[coef][frame] += A[coef][mel] B[mel][frame]
+// with the log-mels as B straight from registers.  The MFMA pipe is otherwise idle; this is
+// not a reshaping of the chain into a GEMM but the one dense 13x40 product it already contains.
+// Saves ~45 of ~225 VALU issue slots and 10 LDS dwords per frame.
+template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL, int NF, int IN = 0, int TILE = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mfcc512_wave_kernel(const Mfcc512Args args)
 {
+    static_assert(!TILE || NF == 1, "the tile epilogue carries one frame at a time");
+    constexpr int KS = DCT_SPLIT == 2 ? DCT_LEN / 2 : DCT_LEN;    // MFMA k-steps (4 mel filters each)
+    constexpr int CT = DCT_SPLIT == 2 ? 2 : 1;                    // 16-coefficient output tiles
+    constexpr int WAVE_BYTES = NF * LDS_WAVE_BYTES + (TILE ? LDS_TILE_BYTES : 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char *wl = smem + wib * (NF * LDS_WAVE_BYTES);
+    char *wl = smem + wib * WAVE_BYTES;
+    float *etile = reinterpret_cast<float *>(wl + NF * LDS_WAVE_BYTES);
+    (void)etile;
     float2 *xchg[NF];
     float *pbuf[NF], *part[NF], *lmel[NF];
 #pragma unroll
@@ -147,8 +162,19 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
 #pragma unroll
     for (int g = 0; g < GATHER; ++g) gat[g] = T->mel_src[g][lane];
     float dctw[(DCT_LEN + 3) & ~3];
+    // the MFMA A operand stays in registers for the reference's shape (10 VGPRs); larger shapes
+    // re-read it (L1/L2-resident, once per 16 frames) to stay within 128 VGPRs = 4 waves/SIMD
+    constexpr bool A_IN_REGS = CT * KS <= 10;
+    float dcta[CT][KS];
+    if (TILE && A_IN_REGS) {
 #pragma unroll
-    for (int i = 0; i < DCT_LEN; ++i) dctw[i] = T->dct_w[i][lane];
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) dcta[ct][s] = T->dct_a[ct][s][lane];
+    } else if (!TILE) {
+#pragma unroll
+        for (int i = 0; i < DCT_LEN; ++i) dctw[i] = T->dct_w[i][lane];
+    }
     const int n_mels = args.n_mels, n_mfcc = args.n_mfcc;
     // log-mel parts are stored 16-byte aligned (stride DCT_STRIDE floats) so each DCT lane
     // fetches its DCT_LEN values with ds_read_b128 (+ one b64)
@@ -214,6 +240,59 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
     for (int d = 0; d < DSP_PREFETCH; ++d) {
         if (pre.valid()) { load_item(pre, ring[d]); pre.next(NF); }
     }
+
+    // ---- 16-frame tile epilogue (TILE): log + DCT for the frames in slots [0, count) ----
+    int slot = 0;               // frames in the tile
+    long fb0 = 0, fb1 = 0;      // first frame of slots 0..7 / 8..15 (each half is 8 consecutive frames)
+    auto flush = [&](int count) {
+        wave_lds_sync();
+        const int n = lane & 15, q = lane >> 4;
+        float ev[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) ev[s] = etile[64 * s + 16 * q + (n ^ s)];     // mel 4s+q of frame n
+        unsigned mx = amin_u;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) mx = max(mx, __float_as_uint(ev[s]));
+        {   // max over the four 16-lane rows (same frame, other mel residues)
+            auto r = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
+            mx = max(r[0], r[1]);
+            r = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
+            mx = max(r[0], r[1]);
+        }
+        const float rinv = __builtin_amdgcn_rcpf(__uint_as_float(mx));
+        const float k10 = 3.01029995663981195f;            // 10 * log10(2)
+        f4v acc[CT][2];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct][0] = acc[ct][1] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+        float aop[CT][KS];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) aop[ct][s] = A_IN_REGS ? dcta[ct][s] : T->dct_a[ct][s][lane];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float ec = __uint_as_float(max(__float_as_uint(ev[s]), amin_u));
+            float db = k10 * __builtin_amdgcn_logf(ec * rinv);
+            db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f);
+            if (4 * s + q >= n_mels) db = 0.0f;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                acc[ct][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[ct][s], db, acc[ct][s & 1], 0, 0, 0);
+        }
+        const long fl = (n < 8 ? fb0 : fb1 - 8) + n;
+        const bool ok = n < count && fl < n_frames;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const f4v d = acc[ct][0] + acc[ct][1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 16 * ct + 4 * q + j;
+                if (ok && c < n_mfcc) args.out[fl * n_mfcc + c] = d[j];
+            }
+        }
+        wave_lds_sync();
+    };
+    (void)flush;
 
     auto step = [&](c32 (&nxt)[NF][4]) -> bool {
         const long f = cur.f;
@@ -368,6 +447,12 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
         // cancellation between two ~-100 dB terms, and exactly invariant to a
         // power-of-two gain on the input.  (e, amin, ref are non-negative: their max
         // is an unsigned-integer max of the bit patterns, no NaN canonicalisation.)
+        if (TILE) {
+            if ((slot & 7) == 0) { if (slot == 0) fb0 = f; else fb1 = f; }
+            etile[16 * lane + (slot ^ (lane >> 2))] = e[0];
+            if (++slot == 16 || !more) { flush(slot); slot = 0; }
+            return more;
+        }
         if (args.log_mode != 0) {
             // librosa power_to_db(ref = 1.0, top_db over the clip), keyword_classifier.py:42-55
             bool pass1 = args.frame_max != nullptr;
@@ -440,38 +525,44 @@ __global__ __launch_bounds__(256) void mfcc512_wave_kernel(const Mfcc512Args arg
 
 // -----------------------------------------------------------------------------
 
+// Instantiations: (DCT_SPLIT, DCT_LEN, GATHER) x FULL x TILE for float input; PCM16 input for the
+// reference's shape (13 x 40) only.
+#define DSP_FOR_SHAPES(X) X(4, 10, 3) X(4, 10, 6) X(4, 16, 3) X(4, 16, 6) X(2, 20, 3) X(2, 20, 6)
+
+static size_t lds_bytes(bool tile) { return (size_t)4 * (DSP_NF * LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0)); }
+
+template <int S, int L, int G, int IN, int TILE>
+static hipError_t launch_one(const Mfcc512Args &args, bool full, int blocks, hipStream_t stream)
+{
+    const size_t lds = lds_bytes(TILE);
+    if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true, DSP_NF, IN, TILE>), dim3(blocks), dim3(256), lds, stream, args);
+    else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false, DSP_NF, IN, TILE>), dim3(blocks), dim3(256), lds, stream, args);
+    return hipGetLastError();
+}
+
 hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks,
-                          hipStream_t stream)
+                          hipStream_t stream, bool tile)
 {
     const bool full = args.frame_len == 512;
-    const size_t lds = (size_t)4 * DSP_NF * LDS_WAVE_BYTES;
+    if (tile && (DSP_NF != 1 || args.log_mode != 0 || args.chunk % 8 != 0)) return hipErrorInvalidConfiguration;
     if (args.in_kind != 0) {
-        // PCM16 ingestion is instantiated for the reference's DCT / mel shape (13 x 40)
-        if (!(dct_split == 4 && dct_len == 10 && gather == 3)) return hipErrorInvalidConfiguration;
-#define DSP_LAUNCH_IN(K)                                                                                             \
-        if (args.in_kind == K) {                                                                                     \
-            if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<4, 10, 3, true, DSP_NF, K>), dim3(blocks), dim3(256), lds, stream, args);   \
-            else hipLaunchKernelGGL((mfcc512_wave_kernel<4, 10, 3, false, DSP_NF, K>), dim3(blocks), dim3(256), lds, stream, args);  \
-            return hipGetLastError();                                                                                \
-        }
-        DSP_LAUNCH_IN(1)
-        DSP_LAUNCH_IN(2)
-        DSP_LAUNCH_IN(3)
-#undef DSP_LAUNCH_IN
+        if (!(dct_split == 4 && dct_len == 10 && gather == 3) || !tile) return hipErrorInvalidConfiguration;
+#if DSP_NF == 1
+        if (args.in_kind == 1) return launch_one<4, 10, 3, 1, 1>(args, full, blocks, stream);
+        if (args.in_kind == 2) return launch_one<4, 10, 3, 2, 1>(args, full, blocks, stream);
+        if (args.in_kind == 3) return launch_one<4, 10, 3, 3, 1>(args, full, blocks, stream);
+#endif
         return hipErrorInvalidConfiguration;
     }
-#define DSP_LAUNCH(S, L, G)                                                                                          \
-    if (dct_split == S && dct_len == L && gather == G) {                                                             \
-        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true, DSP_NF>), dim3(blocks), dim3(256), lds, stream, args);   \
-        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false, DSP_NF>), dim3(blocks), dim3(256), lds, stream, args);  \
-        return hipGetLastError();                                                                                    \
-    }
-    DSP_LAUNCH(4, 10, 3)
-    DSP_LAUNCH(4, 10, 6)
-    DSP_LAUNCH(4, 16, 3)
-    DSP_LAUNCH(4, 16, 6)
-    DSP_LAUNCH(2, 20, 3)
-    DSP_LAUNCH(2, 20, 6)
+#if DSP_NF == 1
+#define DSP_LAUNCH(S, L, G)                                                                  \
+    if (dct_split == S && dct_len == L && gather == G)                                       \
+        return tile ? launch_one<S, L, G, 0, 1>(args, full, blocks, stream) : launch_one<S, L, G, 0, 0>(args, full, blocks, stream);
+#else
+#define DSP_LAUNCH(S, L, G)                                                                  \
+    if (dct_split == S && dct_len == L && gather == G) return launch_one<S, L, G, 0, 0>(args, full, blocks, stream);
+#endif
+    DSP_FOR_SHAPES(DSP_LAUNCH)
 #undef DSP_LAUNCH
     return hipErrorInvalidConfiguration;
 }
@@ -495,26 +586,31 @@ hipError_t launch_clip_floor(const float *frame_max, long n_clips, int frames_pe
     return hipGetLastError();
 }
 
-int mfcc512_lds_bytes_per_block() { return 4 * DSP_NF * LDS_WAVE_BYTES; }
+int mfcc512_lds_bytes_per_block(bool tile) { return (int)lds_bytes(tile); }
 int mfcc512_frames_per_item() { return DSP_NF; }
+bool mfcc512_has_tile() { return DSP_NF == 1; }
 
-// resident 256-thread blocks per CU for the instantiation a plan will launch
-int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full)
+template <int S, int L, int G, int TILE>
+static int occupancy_one(bool full)
 {
     int n = 0;
-    const size_t lds = (size_t)4 * DSP_NF * LDS_WAVE_BYTES;
-#define DSP_OCC(S, L, G)                                                                                   \
-    if (dct_split == S && dct_len == L && gather == G) {                                                   \
-        hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, true, DSP_NF>, 256, lds)   \
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, false, DSP_NF>, 256, lds); \
-        return e == hipSuccess && n > 0 ? n : 4;                                                           \
-    }
-    DSP_OCC(4, 10, 3)
-    DSP_OCC(4, 10, 6)
-    DSP_OCC(4, 16, 3)
-    DSP_OCC(4, 16, 6)
-    DSP_OCC(2, 20, 3)
-    DSP_OCC(2, 20, 6)
+    const size_t lds = lds_bytes(TILE);
+    hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, true, DSP_NF, 0, TILE>, 256, lds)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, false, DSP_NF, 0, TILE>, 256, lds);
+    return e == hipSuccess && n > 0 ? n : 4;
+}
+
+// resident 256-thread blocks per CU for the instantiation a plan will launch
+int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full, bool tile)
+{
+#if DSP_NF == 1
+#define DSP_OCC(S, L, G) \
+    if (dct_split == S && dct_len == L && gather == G) return tile ? occupancy_one<S, L, G, 1>(full) : occupancy_one<S, L, G, 0>(full);
+#else
+#define DSP_OCC(S, L, G) \
+    if (dct_split == S && dct_len == L && gather == G) return occupancy_one<S, L, G, 0>(full);
+#endif
+    DSP_FOR_SHAPES(DSP_OCC)
 #undef DSP_OCC
     return 4;
 }

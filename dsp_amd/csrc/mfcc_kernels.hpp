@@ -33,15 +33,17 @@ struct Mfcc512Args {
 hipError_t launch_clip_floor(const float *frame_max, long n_clips, int frames_per_clip, float top_db, float *clip_floor,
                              hipStream_t stream);
 
+// tile: 16-frame log + MFMA-DCT epilogue (per-frame log mode, chunk % 8 == 0); false: per-frame epilogue
 hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks,
-                          hipStream_t stream);
+                          hipStream_t stream, bool tile);
 hipError_t launch_mfcc512_row(const Mfcc512Args &args, const RowTables512 *row_tables, int dct_split, int dct_len,
                               int gather, int blocks, hipStream_t stream);
 int mfcc512_row_blocks_per_cu(int dct_split, int dct_len, int gather, bool full);
 hipError_t launch_mfcc1024(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream);
 int mfcc1024_blocks_per_cu(bool full);
-int mfcc512_lds_bytes_per_block();
+int mfcc512_lds_bytes_per_block(bool tile);
 int mfcc512_frames_per_item();   // frames a wave processes together; chunk must be a multiple
-int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full);
+bool mfcc512_has_tile();         // false in the DSP_NF > 1 experiment builds
+int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full, bool tile);
 
 }  // namespace dsp

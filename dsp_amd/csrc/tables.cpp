@@ -319,6 +319,12 @@ bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::st
                 t.dct_w[i][lane] = m < cfg.n_mels ? dct[(size_t)c * cfg.n_mels + m] : 0.0f;
             }
         }
+    for (int ct = 0; ct < 2; ++ct)
+        for (int s = 0; s < kDctSteps; ++s)
+            for (int l = 0; l < kLanes; ++l) {
+                const int c = 16 * ct + l % 16, m = 4 * s + l / 16;
+                t.dct_a[ct][s][l] = (c < cfg.n_mfcc && m < cfg.n_mels) ? dct[(size_t)c * cfg.n_mels + m] : 0.0f;
+            }
     return true;
 }
 

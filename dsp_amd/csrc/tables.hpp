@@ -38,6 +38,7 @@ constexpr int kLanes = 64;
 constexpr int kMelChunk = 12;   // bins per lane in the sparse mel product
 constexpr int kMelGather = 6;   // max chunks per filter (kernels are instantiated for 3 and 6)
 constexpr int kDctMaxLen = 20;  // log-mel values per lane in the DCT (n_mels / split, padded even)
+constexpr int kDctSteps = 16;  // MFMA k-steps of 4 mel filters (n_mels <= 64)
 constexpr int kZeroSlot = 64;   // LDS partial slot that always reads 0
 
 struct LaneTables512 {
@@ -63,6 +64,9 @@ struct LaneTables512 {
     int32_t dct_split;         // 4 (n_mfcc <= 16) or 2 (n_mfcc <= 32)
     int32_t dct_len;           // floats per part (even, <= kDctMaxLen)
     int32_t n_mels, n_mfcc;
+    // DCT as the A operand of v_mfma_f32_16x16x4_f32 (16-frame tile epilogue): lane (c = l%16, q = l/16),
+    // k-step s holds D[16 ct + c][4 s + q] (0 outside n_mfcc x n_mels)
+    float dct_a[2][kDctSteps][kLanes];
 };
 
 // ---- per-lane layout of the FFT front end of the row-per-frame kernel -------------

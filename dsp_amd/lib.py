@@ -35,6 +35,7 @@ class LaneTables512(C.Structure):
         ("mel_gather", C.c_int32), ("mel_conflict_free", C.c_int32),
         ("dct_w", (C.c_float * 64) * 20), ("dct_split", C.c_int32), ("dct_len", C.c_int32),
         ("n_mels", C.c_int32), ("n_mfcc", C.c_int32),
+        ("dct_a", ((C.c_float * 64) * 16) * 2),
     ]
 
 
