@@ -212,10 +212,8 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
     if (cfg->n_fft == 512) {
         p->resident_blocks_frame = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
                                                               cfg->frame_length == 512, false);
-        p->resident_blocks = dsp::mfcc512_has_tile()
-                                 ? dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
-                                                              cfg->frame_length == 512, true)
-                                 : p->resident_blocks_frame;
+        p->resident_blocks = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
+                                                        cfg->frame_length == 512, true);
         p->resident_blocks_row = dsp::mfcc512_row_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
                                                                 cfg->frame_length == 512);
     } else {
@@ -282,7 +280,7 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     const bool single_clip = frames_per_clip > 0 && n_frames == frames_per_clip;   // stride unused
     if ((reinterpret_cast<uintptr_t>(d_in) & (in_kind == 1 ? 3 : 7)) || (!single_clip && (clip_stride & 1)))
         return fail(DSP_EINVAL, "input must be 8-byte aligned (4 for mono int16) with an even clip stride");
-    if (in_kind != 0 && (p->cfg.n_fft != 512 || p->kernel != DSP_KERNEL_WAVE || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX || !dsp::mfcc512_has_tile()))
+    if (in_kind != 0 && (p->cfg.n_fft != 512 || p->kernel != DSP_KERNEL_WAVE || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX))
         return fail(DSP_EINVAL, "PCM16 ingestion runs on the 512-point wave-per-frame kernel, per-frame log mode");
     dsp::Mfcc512Args a;
     a.in = d_in;
@@ -297,8 +295,8 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     const bool gen = p->cfg.n_fft == 1024;
     const bool row = !gen && p->kernel == DSP_KERNEL_ROW;
     // 16-frame tile epilogue: per-frame log mode on the wave-per-frame kernel
-    const bool tile = !gen && p->kernel == DSP_KERNEL_WAVE && p->cfg.log_mode == DSP_LOG_PER_FRAME_MAX && dsp::mfcc512_has_tile();
-    const int nf = gen ? 1 : (row ? 4 : (tile ? 8 : dsp::mfcc512_frames_per_item()));
+    const bool tile = !gen && p->kernel == DSP_KERNEL_WAVE && p->cfg.log_mode == DSP_LOG_PER_FRAME_MAX;
+    const int nf = gen ? 1 : (row ? 4 : (tile ? 8 : 1));
     a.chunk = p->chunk > 0 ? p->chunk : 8;
     a.chunk = ((a.chunk + nf - 1) / nf) * nf;   // whole items (tile: half-tiles of 8 frames) per chunk
     a.n_mels = p->cfg.n_mels;

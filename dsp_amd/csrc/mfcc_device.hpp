@@ -172,6 +172,71 @@ struct FrameCursor {
     }
 };
 
+// Cursor of the wave-per-frame kernel: same walk as FrameCursor (chunks of `chunk` consecutive
+// frames dealt round-robin to the waves), one frame per step, and it carries the sample offset of
+// the frame incrementally, so a step is a handful of scalar adds and selects: no multiply, no
+// loop, no branch.  CLIPS: frames overlap inside clips (offset = clip * clip_stride + t * hop);
+// otherwise frames lie back to back (offset = f * frame_len).
+template <bool CLIPS>
+struct WaveCursor {
+    long f, off;                 // frame index (valid while f < n) and its first sample
+    long clip;                   // CLIPS: clip of frame f
+    long n;
+    long chunk_f, chunk_off;     // first frame of the current chunk; CLIPS: chunk_off = offset of its clip
+    long chunk_clip;
+    long stride_f, stride_off;   // chunk-to-chunk jump of this wave; CLIPS: stride_off = jump_clips * clip_stride
+    long clip_off, clip_stride;  // CLIPS: offset of the current clip
+    int left, chunk;             // frames of the chunk still to come after f
+    int t, t0, fpc, jump_t, hop; // CLIPS: frame in clip, of f / of the chunk start; hop = samples between frames
+    long jump_clips;
+    __device__ __forceinline__ void init(long wave, long n_waves, int chunk_, long n_, int fpc_, int hop_, long clip_stride_)
+    {
+        chunk = chunk_; n = n_; fpc = fpc_; hop = hop_; clip_stride = clip_stride_;
+        stride_f = n_waves * chunk;
+        chunk_f = wave * chunk;
+        f = chunk_f;
+        left = chunk - 1;
+        clip = chunk_clip = 0; t = t0 = 0; jump_t = 0; jump_clips = 0; clip_off = 0;
+        if (CLIPS) {            // the only divisions and wide multiplies: once per wave
+            chunk_clip = f / fpc; t0 = (int)(f - chunk_clip * fpc);
+            jump_clips = stride_f / fpc; jump_t = (int)(stride_f - jump_clips * fpc);
+            stride_off = jump_clips * clip_stride;
+            chunk_off = chunk_clip * clip_stride;
+            clip = chunk_clip; t = t0; clip_off = chunk_off;
+            off = clip_off + (long)t * hop;
+        } else {
+            stride_off = stride_f * hop;
+            chunk_off = chunk_f * hop;
+            off = chunk_off;
+        }
+    }
+    __device__ __forceinline__ bool valid() const { return f < n; }
+    __device__ __forceinline__ void next()
+    {
+        if (left > 0) {
+            --left; ++f;
+            if (CLIPS) {
+                ++t; off += hop;
+                if (t == fpc) { t = 0; ++clip; clip_off += clip_stride; off = clip_off; }
+            } else {
+                off += hop;
+            }
+        } else {
+            left = chunk - 1;
+            chunk_f += stride_f; f = chunk_f;
+            chunk_off += stride_off;
+            if (CLIPS) {
+                chunk_clip += jump_clips; t0 += jump_t;
+                if (t0 >= fpc) { t0 -= fpc; ++chunk_clip; chunk_off += clip_stride; }
+                clip = chunk_clip; t = t0; clip_off = chunk_off;
+                off = clip_off + t * hop;      // t * hop < samples per clip < 2^31
+            } else {
+                off = chunk_off;
+            }
+        }
+    }
+};
+
 }  // namespace
 
 }  // namespace dsp

@@ -33,13 +33,17 @@
 #ifndef DSP_DIAG_MODE
 #define DSP_DIAG_MODE 0
 #endif
-// items (NF frames each) in flight per wave; each costs 8*NF VGPRs
+// exchange 1 (slot <-> lane bits 5:4): 1 = through the LDS tile, 0 = v_permlane32/16_swap
+#ifndef DSP_X1_LDS
+#define DSP_X1_LDS 0
+#endif
+// conjugate partner of the untangling step: 1 = one b128 LDS round trip, 0 = 4 ds_bpermute_b32
+#ifndef DSP_UNT_LDS
+#define DSP_UNT_LDS 0
+#endif
+// frames in flight per wave (software prefetch ring); each costs 8 VGPRs
 #ifndef DSP_PREFETCH
 #define DSP_PREFETCH 2
-#endif
-// frames one wave carries through the pipeline together
-#ifndef DSP_NF
-#define DSP_NF 1
 #endif
 
 namespace dsp {
@@ -100,12 +104,10 @@ __device__ __forceinline__ void load_frame(const void *__restrict__ base, long o
 
 // DCT_SPLIT lanes per coefficient, DCT_LEN log-mel values per lane.  GATHER: partial
 // sums per mel filter.  FULL: frame_length == 512 (no tail predicate on the loads).
-// NF: frames one wave carries through the pipeline together.  NF = 2 pays every LDS
-// round trip once per PAIR of frames and lets two independent dependency chains fill
-// each other's latency while the 52 per-lane constants are held once; measured no
-// faster than NF = 1 (the kernel is issue-bound, not latency-bound) and the two
-// unrolled copies may contract FMAs differently, so NF = 1 is the default: every
-// frame runs the same instructions and results do not depend on a frame's position.
+// IN: input element type (see load_frame).  CLIPS: frames overlap inside clips (hop < frame).
+// Every frame runs the same instructions whatever its position (results do not depend on
+// where a frame sits in the batch).  (Carrying two frames per wave through the pipeline
+// together was built and measured no faster: the kernel is issue-bound, not latency-bound.)
 //
 // TILE = 1 (default for the per-frame log mode): the log and the DCT leave the per-frame
 // path.  A frame ends with ONE ds_write of its mel energies into a 16-frame LDS tile
@@ -115,28 +117,22 @@ __device__ __forceinline__ void load_frame(const void *__restrict__ base, long o
 // with the log-mels as B straight from registers.  The MFMA pipe is otherwise idle; this is
 // not a reshaping of the chain into a GEMM but the one dense 13x40 product it already contains.
 // Saves ~45 of ~225 VALU issue slots and 10 LDS dwords per frame.
-template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL, int NF, int IN = 0, int TILE = 0>
+template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL, int IN, int TILE, bool CLIPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mfcc512_wave_kernel(const Mfcc512Args args)
 {
-    static_assert(!TILE || NF == 1, "the tile epilogue carries one frame at a time");
     constexpr int KS = DCT_SPLIT == 2 ? DCT_LEN / 2 : DCT_LEN;    // MFMA k-steps (4 mel filters each)
     constexpr int CT = DCT_SPLIT == 2 ? 2 : 1;                    // 16-coefficient output tiles
-    constexpr int WAVE_BYTES = NF * LDS_WAVE_BYTES + (TILE ? LDS_TILE_BYTES : 0);
+    constexpr int WAVE_BYTES = LDS_WAVE_BYTES + (TILE ? LDS_TILE_BYTES : 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char *wl = smem + wib * WAVE_BYTES;
-    float *etile = reinterpret_cast<float *>(wl + NF * LDS_WAVE_BYTES);
+    float *etile = reinterpret_cast<float *>(wl + LDS_WAVE_BYTES);
     (void)etile;
-    float2 *xchg[NF];
-    float *pbuf[NF], *part[NF], *lmel[NF];
-#pragma unroll
-    for (int u = 0; u < NF; ++u) {
-        xchg[u] = reinterpret_cast<float2 *>(wl + u * LDS_WAVE_BYTES + LDS_XCHG);
-        pbuf[u] = reinterpret_cast<float *>(wl + u * LDS_WAVE_BYTES + LDS_XCHG);
-        part[u] = reinterpret_cast<float *>(wl + u * LDS_WAVE_BYTES + LDS_PART);
-        lmel[u] = reinterpret_cast<float *>(wl + u * LDS_WAVE_BYTES + LDS_LOGMEL);
-    }
+    float2 *xchg = reinterpret_cast<float2 *>(wl + LDS_XCHG);
+    float *pbuf = reinterpret_cast<float *>(wl + LDS_XCHG);
+    float *part = reinterpret_cast<float *>(wl + LDS_PART);
+    float *lmel = reinterpret_cast<float *>(wl + LDS_LOGMEL);
 
     const LaneTables512 *__restrict__ T = args.tables;
 
@@ -198,48 +194,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     const bool self_paired = kap == 0;              // bins 0/256, 64/192 and 128 pair inside lane 0
 
     // zero the slots that are only ever read
-#pragma unroll
-    for (int u = 0; u < NF; ++u) {
-        if (lane == 0) part[u][kZeroSlot] = 0.0f;
-        if (lane < 16) lmel[u][64 + lane] = 0.0f;
-        lmel[u][lane] = 0.0f;
-    }
+    if (lane == 0) part[kZeroSlot] = 0.0f;
+    if (lane < 16) lmel[64 + lane] = 0.0f;
+    lmel[lane] = 0.0f;
     wave_lds_sync();
 
     const long wave = (long)blockIdx.x * 4 + wib;
     const long n_waves = (long)gridDim.x * 4;
-    FrameCursor cur;
-    cur.init(wave, n_waves, args.chunk, args.n_frames, args.frames_per_clip);
-    if (!cur.valid()) return;
-
     const unsigned amin_u = __float_as_uint(args.amin);
     const float neg_top_db = -args.top_db;
     const int frame_len = args.frame_len;
     const long n_frames = args.n_frames;
 
-    // source of frame c.f + u (u < NF)
-    auto frame_src_of = [&](const FrameCursor &c, int u) -> long {
-        if (args.frames_per_clip <= 0) return (c.f + u) * (long)frame_len;
-        long clip = c.clip;
-        int t = c.t + u;
-        while (t >= c.fpc) { t -= c.fpc; ++clip; }
-        return clip * args.clip_stride + (long)t * args.hop;
-    };
-    auto load_item = [&](const FrameCursor &c, c32 (&z)[NF][4]) {
-#pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            if (u == 0 || c.f + u < n_frames) load_frame<FULL, IN>(args.in, frame_src_of(c, u), lane, frame_len, z[u]);
+    // Software prefetch, DSP_PREFETCH frames deep.  ONE cursor (`pre`) walks this wave's frames
+    // and issues their loads; the frame index (and clip) of each ring buffer waits in `fq`
+    // until the frame is consumed, so the consumer side needs no cursor of its own.
+    WaveCursor<CLIPS> pre;
+    pre.init(wave, n_waves, args.chunk, n_frames, args.frames_per_clip, CLIPS ? args.hop : frame_len, args.clip_stride);
+    c32 ring[DSP_PREFETCH][4] = {};
+    long fq[DSP_PREFETCH], cq[DSP_PREFETCH];
+    auto refill = [&](int d) {
+        if (pre.valid()) {
+            load_frame<FULL, IN>(args.in, pre.off, lane, frame_len, ring[d]);
+            fq[d] = pre.f; cq[d] = pre.clip;
+            pre.next();
+        } else {
+            fq[d] = -1; cq[d] = 0;
         }
     };
-
-    // Software prefetch, DSP_PREFETCH items deep: `pre` runs ahead of `cur` and each
-    // buffer is refilled right after its frames have been consumed.
-    FrameCursor pre = cur;
-    c32 ring[DSP_PREFETCH][NF][4] = {};
 #pragma unroll
-    for (int d = 0; d < DSP_PREFETCH; ++d) {
-        if (pre.valid()) { load_item(pre, ring[d]); pre.next(NF); }
-    }
+    for (int d = 0; d < DSP_PREFETCH; ++d) refill(d);
+    if (fq[0] < 0) return;
 
     // ---- 16-frame tile epilogue (TILE): log + DCT for the frames in slots [0, count) ----
     int slot = 0;               // frames in the tile
@@ -294,152 +279,159 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     };
     (void)flush;
 
-    auto step = [&](c32 (&nxt)[NF][4]) -> bool {
-        const long f = cur.f;
-        const long clip_f = cur.clip;       // clip of frame f (clip mode)
-        const int t_f = cur.t;
-        c32 s[NF][4];
+    // one frame: ring[d] -> coefficients (or a tile slot); refills ring[d]; false when this was the wave's last frame
+    auto step = [&](int rd) -> bool {
+        c32 (&nxt)[4] = ring[rd];
+        const long f = fq[rd];
+        const long clip_f = cq[rd];          // clip of frame f (clip mode)
+        (void)clip_f;
+        c32 s[4];
 #pragma unroll
-        for (int u = 0; u < NF; ++u)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) s[u][a] = {nxt[u][a].x * win[2 * a], nxt[u][a].y * win[2 * a + 1]};
-        cur.next(NF);
-        const bool more = cur.valid();
+        for (int a = 0; a < 4; ++a) s[a] = {nxt[a].x * win[2 * a], nxt[a].y * win[2 * a + 1]};
 #if !(DSP_DIAG_MODE & 2)
-        if (pre.valid()) { load_item(pre, nxt); pre.next(NF); }   // hidden by the work below
+        refill(rd);                         // hidden by the work below
+#else
+        fq[rd] = pre.valid() ? pre.f : -1; if (pre.valid()) pre.next();
 #endif
+        const bool more = fq[(rd + 1) % DSP_PREFETCH] >= 0;
 #if DSP_DIAG_MODE == 1
-#pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            float c = ((s[u][0].x + s[u][0].y) + (s[u][1].x + s[u][1].y)) + ((s[u][2].x + s[u][2].y) + (s[u][3].x + s[u][3].y));
+        {
+            float c = ((s[0].x + s[0].y) + (s[1].x + s[1].y)) + ((s[2].x + s[2].y) + (s[3].x + s[3].y));
             c += dpp<DPP_QUAD_1032>(c);
-            if (dct_store && f + u < n_frames) args.out[(f + u) * n_mfcc + dct_c] = c;
+            if (dct_store) args.out[f * n_mfcc + dct_c] = c;
         }
         return more;
 #endif
 
         // ---- 256-point complex FFT, radix-4 DIF --------------------------------
+        radix4(s);                                             // digit a (bits 7:6)
 #pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            radix4(s[u]);                                          // digit a (bits 7:6)
+        for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw1[q - 1]);
+#if DSP_X1_LDS
+        // exchange 1: slot a <-> lane bits 5:4 through LDS.  A1 = 64 a + ((16 h + r) ^ 16 (a & 1)):
+        // writer lane (h, r) slot a, reader lane (h, r) slot a' takes lane (a', r) slot h
 #pragma unroll
-            for (int q = 1; q < 4; ++q) s[u][q] = cmul(s[u][q], tw1[q - 1]);
-            // exchange 1: slot <-> lane bits 5:4, in registers
-            swap_hi32(s[u][0].x, s[u][2].x); swap_hi32(s[u][0].y, s[u][2].y);
-            swap_hi32(s[u][1].x, s[u][3].x); swap_hi32(s[u][1].y, s[u][3].y);
-            swap_odd16(s[u][0].x, s[u][1].x); swap_odd16(s[u][0].y, s[u][1].y);
-            swap_odd16(s[u][2].x, s[u][3].x); swap_odd16(s[u][2].y, s[u][3].y);
-            radix4(s[u]);                                          // digit b (bits 5:4)
+        for (int a = 0; a < 4; ++a) xchg[64 * a + (lane ^ (16 * (a & 1)))] = {s[a].x, s[a].y};
+        wave_lds_sync();
 #pragma unroll
-            for (int q = 1; q < 4; ++q) s[u][q] = cmul(s[u][q], tw2[q - 1]);
+        for (int a = 0; a < 4; ++a) {
+            const float2 v = xchg[64 * d2 + ((16 * a + (lane & 15)) ^ (16 * (d2 & 1)))];
+            s[a] = {v.x, v.y};
         }
+        wave_lds_sync();
+#else
+        // exchange 1: slot <-> lane bits 5:4, in registers
+        swap_hi32(s[0].x, s[2].x); swap_hi32(s[0].y, s[2].y);
+        swap_hi32(s[1].x, s[3].x); swap_hi32(s[1].y, s[3].y);
+        swap_odd16(s[0].x, s[1].x); swap_odd16(s[0].y, s[1].y);
+        swap_odd16(s[2].x, s[3].x); swap_odd16(s[2].y, s[3].y);
+#endif
+        radix4(s);                                             // digit b (bits 5:4)
+#pragma unroll
+        for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw2[q - 1]);
 #if DSP_X2_LDS
         // exchange 2: slot <-> lane bits 3:2, through LDS
 #pragma unroll
-        for (int u = 0; u < NF; ++u)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) xchg[u][(lane ^ (4 * p)) + 64 * p] = {s[u][p].x, s[u][p].y};
+        for (int p = 0; p < 4; ++p) xchg[(lane ^ (4 * p)) + 64 * p] = {s[p].x, s[p].y};
         wave_lds_sync();
 #pragma unroll
-        for (int u = 0; u < NF; ++u)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float2 v = xchg[u][64 * d1 + 16 * d2 + 4 * (c ^ d1) + d0];
-                s[u][c] = {v.x, v.y};
-            }
+        for (int c = 0; c < 4; ++c) {
+            const float2 v = xchg[64 * d1 + 16 * d2 + 4 * (c ^ d1) + d0];
+            s[c] = {v.x, v.y};
+        }
         wave_lds_sync();
 #else
         // exchange 2: slot <-> lane bits 3:2, DPP row moves
-#pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            swap_lane8(s[u][0].x, s[u][2].x); swap_lane8(s[u][0].y, s[u][2].y);
-            swap_lane8(s[u][1].x, s[u][3].x); swap_lane8(s[u][1].y, s[u][3].y);
-            swap_lane4(s[u][0].x, s[u][1].x); swap_lane4(s[u][0].y, s[u][1].y);
-            swap_lane4(s[u][2].x, s[u][3].x); swap_lane4(s[u][2].y, s[u][3].y);
-        }
+        swap_lane8(s[0].x, s[2].x); swap_lane8(s[0].y, s[2].y);
+        swap_lane8(s[1].x, s[3].x); swap_lane8(s[1].y, s[3].y);
+        swap_lane4(s[0].x, s[1].x); swap_lane4(s[0].y, s[1].y);
+        swap_lane4(s[2].x, s[3].x); swap_lane4(s[2].y, s[3].y);
 #endif
+        radix4(s);                                             // digit c (bits 3:2)
 #pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            radix4(s[u]);                                          // digit c (bits 3:2)
-#pragma unroll
-            for (int q = 1; q < 4; ++q) s[u][q] = cmul(s[u][q], tw3[q - 1]);
-        }
+        for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw3[q - 1]);
 #if DSP_X3_LDS
         // exchange 3: slot <-> lane bits 1:0, through LDS; reader lane = k mod 64
 #pragma unroll
-        for (int u = 0; u < NF; ++u)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) xchg[u][w3base + 16 * o] = {s[u][o].x, s[u][o].y};
+        for (int o = 0; o < 4; ++o) xchg[w3base + 16 * o] = {s[o].x, s[o].y};
         wave_lds_sync();
 #pragma unroll
-        for (int u = 0; u < NF; ++u)
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {
-                const float2 v = xchg[u][r3base + 4 * (dd ^ d0)];
-                s[u][dd] = {v.x, v.y};
-            }
+        for (int dd = 0; dd < 4; ++dd) {
+            const float2 v = xchg[r3base + 4 * (dd ^ d0)];
+            s[dd] = {v.x, v.y};
+        }
         wave_lds_sync();
 #else
         // exchange 3: slot <-> lane bits 1:0, DPP quad permutes
-#pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            swap_quad<DPP_QUAD_2301>(s[u][0].x, s[u][2].x, bit1); swap_quad<DPP_QUAD_2301>(s[u][0].y, s[u][2].y, bit1);
-            swap_quad<DPP_QUAD_2301>(s[u][1].x, s[u][3].x, bit1); swap_quad<DPP_QUAD_2301>(s[u][1].y, s[u][3].y, bit1);
-            swap_quad<DPP_QUAD_1032>(s[u][0].x, s[u][1].x, bit0); swap_quad<DPP_QUAD_1032>(s[u][0].y, s[u][1].y, bit0);
-            swap_quad<DPP_QUAD_1032>(s[u][2].x, s[u][3].x, bit0); swap_quad<DPP_QUAD_1032>(s[u][2].y, s[u][3].y, bit0);
-        }
+        swap_quad<DPP_QUAD_2301>(s[0].x, s[2].x, bit1); swap_quad<DPP_QUAD_2301>(s[0].y, s[2].y, bit1);
+        swap_quad<DPP_QUAD_2301>(s[1].x, s[3].x, bit1); swap_quad<DPP_QUAD_2301>(s[1].y, s[3].y, bit1);
+        swap_quad<DPP_QUAD_1032>(s[0].x, s[1].x, bit0); swap_quad<DPP_QUAD_1032>(s[0].y, s[1].y, bit0);
+        swap_quad<DPP_QUAD_1032>(s[2].x, s[3].x, bit0); swap_quad<DPP_QUAD_1032>(s[2].y, s[3].y, bit0);
 #endif
 
         // ---- last butterfly, packed-real untangling, power spectrum ----------------
         // the lane with bins kap, kap+64 pairs them with 256-kap and 192-kap; both live
         // in the partner lane (slots 3 and 2).  Lane 0 (kap = 0) pairs inside itself.
-#pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            radix4(s[u]);                                          // digit d: s[t] = Z[64 t + kap] / 2
-            c32 b, d;
-            b.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[u][3].x)));
-            b.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[u][3].y)));
-            d.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[u][2].x)));
-            d.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[u][2].y)));
-            if (self_paired) { b = s[u][0]; d = s[u][3]; }
-            float P[4];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const c32 x = s[u][h], v = h == 0 ? b : d;
-                const c32 E = {x.x + v.x, x.y - v.y};           // Z[k] + conj(Z[N-k])
-                const c32 O = {x.x - v.x, x.y + v.y};           // Z[k] - conj(Z[N-k])
-                const c32 Tw = cmul(O, twp[h]);                 // W512^k * O
-                const float xr = E.x + Tw.y, xi = E.y - Tw.x;   // X[k]
-                const float mr = E.x - Tw.y, mi = E.y + Tw.x;   // X[256-k] (conjugated)
-                P[2 * h] = xr * xr + xi * xi;
-                P[2 * h + 1] = mr * mr + mi * mi;
-            }
-            const float p128 = 4.0f * (s[u][2].x * s[u][2].x + s[u][2].y * s[u][2].y);   // lane 0: |Z[128]|^2 un-halved
-            pbuf[u][kap] = P[0];
-            pbuf[u][256 - kap] = P[1];
-            pbuf[u][64 + kap] = P[2];
-            pbuf[u][192 - kap] = P[3];
-            if (self_paired) pbuf[u][128] = p128;
+        radix4(s);                                             // digit d: s[t] = Z[64 t + kap] / 2
+        c32 b, d;
+#if DSP_UNT_LDS
+        {
+            float4 *pt = reinterpret_cast<float4 *>(xchg);
+            pt[lane] = make_float4(s[2].x, s[2].y, s[3].x, s[3].y);
+            wave_lds_sync();
+            const float4 v = pt[partner >> 2];
+            wave_lds_sync();
+            d = {v.x, v.y};
+            b = {v.z, v.w};
         }
+#else
+        b.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[3].x)));
+        b.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[3].y)));
+        d.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[2].x)));
+        d.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(s[2].y)));
+#endif
+        // selects, not a branch: lane 0 exists in every wave, so a branch is always taken
+        b.x = self_paired ? s[0].x : b.x; b.y = self_paired ? s[0].y : b.y;
+        d.x = self_paired ? s[3].x : d.x; d.y = self_paired ? s[3].y : d.y;
+        float P[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const c32 x = s[h], v = h == 0 ? b : d;
+            const c32 E = {x.x + v.x, x.y - v.y};           // Z[k] + conj(Z[N-k])
+            const c32 O = {x.x - v.x, x.y + v.y};           // Z[k] - conj(Z[N-k])
+            const c32 Tw = cmul(O, twp[h]);                 // W512^k * O
+            const float xr = E.x + Tw.y, xi = E.y - Tw.x;   // X[k]
+            const float mr = E.x - Tw.y, mi = E.y + Tw.x;   // X[256-k] (conjugated)
+            P[2 * h] = xr * xr + xi * xi;
+            P[2 * h + 1] = mr * mr + mi * mi;
+        }
+        const float p128 = 4.0f * (s[2].x * s[2].x + s[2].y * s[2].y);   // lane 0: |Z[128]|^2 un-halved
+        pbuf[kap] = P[0];
+        pbuf[64 + kap] = P[2];
+        pbuf[192 - kap] = P[3];
+        pbuf[256 - kap] = P[1];
+        if (self_paired) pbuf[128] = p128;
         wave_lds_sync();
 
         // ---- sparse mel filterbank -------------------------------------------
-#pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            const float *rd = pbuf[u] + mel_k0;
+        {
+            const float *rd = pbuf + mel_k0;
             float acc = 0.0f;
 #pragma unroll
             for (int i = 0; i < kMelChunk; ++i) acc = fmaf(melw[i], rd[i], acc);
-            part[u][lane] = acc;
+            part[lane] = acc;
         }
         wave_lds_sync();
-        float e[NF];
+        float e = part[gat[0]];
 #pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            e[u] = part[u][gat[0]];
-#pragma unroll
-            for (int g = 1; g < GATHER; ++g) e[u] += part[u][gat[g]];
-            if (lane >= n_mels) e[u] = 0.0f;
+        for (int g = 1; g < GATHER; ++g) e += part[gat[g]];
+        if (lane >= n_mels) e = 0.0f;
+
+        if (TILE) {
+            if ((slot & 7) == 0) { if (slot == 0) fb0 = f; else fb1 = f; }
+            etile[16 * lane + (slot ^ (lane >> 2))] = e;
+            if (++slot == 16 || !more) { flush(slot); slot = 0; }
+            return more;
         }
 
         // ---- 10 log10 with per-frame reference (mfcc.c:169-206) ---------------
@@ -447,52 +439,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
         // cancellation between two ~-100 dB terms, and exactly invariant to a
         // power-of-two gain on the input.  (e, amin, ref are non-negative: their max
         // is an unsigned-integer max of the bit patterns, no NaN canonicalisation.)
-        if (TILE) {
-            if ((slot & 7) == 0) { if (slot == 0) fb0 = f; else fb1 = f; }
-            etile[16 * lane + (slot ^ (lane >> 2))] = e[0];
-            if (++slot == 16 || !more) { flush(slot); slot = 0; }
-            return more;
-        }
+        const float k10 = 3.01029995663981195f;            // 10 * log10(2)
         if (args.log_mode != 0) {
             // librosa power_to_db(ref = 1.0, top_db over the clip), keyword_classifier.py:42-55
-            bool pass1 = args.frame_max != nullptr;
-#pragma unroll
-            for (int u = 0; u < NF; ++u) {
-                const float k10 = 3.01029995663981195f;
-                const float top = __uint_as_float(max(__float_as_uint(wave_max_nonneg(e[u])), amin_u));
-                const float top_db_val = k10 * __builtin_amdgcn_logf(top);      // frame maximum in dB
-                if (pass1) {
-                    if (lane == 0 && (u == 0 || f + u < n_frames)) args.frame_max[f + u] = top_db_val;
-                    continue;
-                }
-                long clip_of = clip_f;
-                if (u > 0 && args.frames_per_clip > 0) {
-                    int tu = t_f + u;
-                    while (tu >= args.frames_per_clip) { tu -= args.frames_per_clip; ++clip_of; }
-                }
-                const float floor_db = args.clip_floor ? args.clip_floor[clip_of] : top_db_val + neg_top_db;
-                const float ec = __uint_as_float(max(__float_as_uint(e[u]), amin_u));
-                const float db = fmaxf(k10 * __builtin_amdgcn_logf(ec), floor_db);
-                if (lane < n_mels) lmel[u][lmel_wr] = db;
+            const float top = __uint_as_float(max(__float_as_uint(wave_max_nonneg(e)), amin_u));
+            const float top_db_val = k10 * __builtin_amdgcn_logf(top);      // frame maximum in dB
+            if (args.frame_max != nullptr) {        // pass 1
+                if (lane == 0) args.frame_max[f] = top_db_val;
+                return more;
             }
-            if (pass1) { wave_lds_sync(); return more; }
+            const float floor_db = args.clip_floor ? args.clip_floor[clip_f] : top_db_val + neg_top_db;
+            const float ec = __uint_as_float(max(__float_as_uint(e), amin_u));
+            const float db = fmaxf(k10 * __builtin_amdgcn_logf(ec), floor_db);
+            if (lane < n_mels) lmel[lmel_wr] = db;
         } else {
-#pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            const float ref = __uint_as_float(max(__float_as_uint(wave_max_nonneg(e[u])), amin_u));
-            const float ec = __uint_as_float(max(__float_as_uint(e[u]), amin_u));
-            const float k10 = 3.01029995663981195f;            // 10 * log10(2)
+            const float ref = __uint_as_float(max(__float_as_uint(wave_max_nonneg(e)), amin_u));
+            const float ec = __uint_as_float(max(__float_as_uint(e), amin_u));
             float db = k10 * __builtin_amdgcn_logf(ec * __builtin_amdgcn_rcpf(ref));
             db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f); // clamp to [-top_db, 0]: the frame max is exactly 0
-            if (lane < n_mels) lmel[u][lmel_wr] = db;
-        }
+            if (lane < n_mels) lmel[lmel_wr] = db;
         }
         wave_lds_sync();
 
         // ---- DCT-II ------------------------------------------------------------
-#pragma unroll
-        for (int u = 0; u < NF; ++u) {
-            const float *rd = lmel[u] + dct_rd;
+        {
+            const float *rd = lmel + dct_rd;
             float c = 0.0f;
 #pragma unroll
             for (int i = 0; i + 4 <= DCT_LEN; i += 4) {
@@ -509,7 +480,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
             }
             c += dpp<DPP_QUAD_1032>(c);
             if (DCT_SPLIT == 4) c += dpp<DPP_QUAD_2301>(c);
-            if (dct_store && (u == 0 || f + u < n_frames)) args.out[(f + u) * n_mfcc + dct_c] = c;
+            if (dct_store) args.out[f * n_mfcc + dct_c] = c;
         }
         wave_lds_sync();
         return more;
@@ -517,26 +488,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
 
     static_assert(DSP_PREFETCH >= 1 && DSP_PREFETCH <= 3, "prefetch ring depth");
     while (true) {
-        if (!step(ring[0])) return;
-        if (DSP_PREFETCH > 1 && !step(ring[DSP_PREFETCH > 1 ? 1 : 0])) return;
-        if (DSP_PREFETCH > 2 && !step(ring[DSP_PREFETCH > 2 ? 2 : 0])) return;
+        if (!step(0)) return;
+        if (DSP_PREFETCH > 1 && !step(DSP_PREFETCH > 1 ? 1 : 0)) return;
+        if (DSP_PREFETCH > 2 && !step(DSP_PREFETCH > 2 ? 2 : 0)) return;
     }
 }
 
 // -----------------------------------------------------------------------------
 
-// Instantiations: (DCT_SPLIT, DCT_LEN, GATHER) x FULL x TILE for float input; PCM16 input for the
-// reference's shape (13 x 40) only.
+// Instantiations: (DCT_SPLIT, DCT_LEN, GATHER) x FULL x TILE x CLIPS for float input; PCM16 input
+// (always clips, tile epilogue) for the reference's shape (13 x 40) only.
 #define DSP_FOR_SHAPES(X) X(4, 10, 3) X(4, 10, 6) X(4, 16, 3) X(4, 16, 6) X(2, 20, 3) X(2, 20, 6)
 
-static size_t lds_bytes(bool tile) { return (size_t)4 * (DSP_NF * LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0)); }
+static size_t lds_bytes(bool tile) { return (size_t)4 * (LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0)); }
 
 template <int S, int L, int G, int IN, int TILE>
-static hipError_t launch_one(const Mfcc512Args &args, bool full, int blocks, hipStream_t stream)
+static hipError_t launch_one(const Mfcc512Args &args, bool full, bool clips, int blocks, hipStream_t stream)
 {
     const size_t lds = lds_bytes(TILE);
-    if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true, DSP_NF, IN, TILE>), dim3(blocks), dim3(256), lds, stream, args);
-    else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false, DSP_NF, IN, TILE>), dim3(blocks), dim3(256), lds, stream, args);
+    const dim3 g(blocks), b(256);
+    if (IN == 0 && !clips) {
+        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true, 0, TILE, false>), g, b, lds, stream, args);
+        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false, 0, TILE, false>), g, b, lds, stream, args);
+    } else {
+        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true, IN, TILE, true>), g, b, lds, stream, args);
+        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false, IN, TILE, true>), g, b, lds, stream, args);
+    }
     return hipGetLastError();
 }
 
@@ -544,24 +521,19 @@ hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, i
                           hipStream_t stream, bool tile)
 {
     const bool full = args.frame_len == 512;
-    if (tile && (DSP_NF != 1 || args.log_mode != 0 || args.chunk % 8 != 0)) return hipErrorInvalidConfiguration;
+    const bool clips = args.frames_per_clip > 0;
+    if (tile && (args.log_mode != 0 || args.chunk % 8 != 0)) return hipErrorInvalidConfiguration;
     if (args.in_kind != 0) {
-        if (!(dct_split == 4 && dct_len == 10 && gather == 3) || !tile) return hipErrorInvalidConfiguration;
-#if DSP_NF == 1
-        if (args.in_kind == 1) return launch_one<4, 10, 3, 1, 1>(args, full, blocks, stream);
-        if (args.in_kind == 2) return launch_one<4, 10, 3, 2, 1>(args, full, blocks, stream);
-        if (args.in_kind == 3) return launch_one<4, 10, 3, 3, 1>(args, full, blocks, stream);
-#endif
+        if (!(dct_split == 4 && dct_len == 10 && gather == 3) || !tile || !clips) return hipErrorInvalidConfiguration;
+        if (args.in_kind == 1) return launch_one<4, 10, 3, 1, 1>(args, full, true, blocks, stream);
+        if (args.in_kind == 2) return launch_one<4, 10, 3, 2, 1>(args, full, true, blocks, stream);
+        if (args.in_kind == 3) return launch_one<4, 10, 3, 3, 1>(args, full, true, blocks, stream);
         return hipErrorInvalidConfiguration;
     }
-#if DSP_NF == 1
 #define DSP_LAUNCH(S, L, G)                                                                  \
     if (dct_split == S && dct_len == L && gather == G)                                       \
-        return tile ? launch_one<S, L, G, 0, 1>(args, full, blocks, stream) : launch_one<S, L, G, 0, 0>(args, full, blocks, stream);
-#else
-#define DSP_LAUNCH(S, L, G)                                                                  \
-    if (dct_split == S && dct_len == L && gather == G) return launch_one<S, L, G, 0, 0>(args, full, blocks, stream);
-#endif
+        return tile ? launch_one<S, L, G, 0, 1>(args, full, clips, blocks, stream)           \
+                    : launch_one<S, L, G, 0, 0>(args, full, clips, blocks, stream);
     DSP_FOR_SHAPES(DSP_LAUNCH)
 #undef DSP_LAUNCH
     return hipErrorInvalidConfiguration;
@@ -587,29 +559,22 @@ hipError_t launch_clip_floor(const float *frame_max, long n_clips, int frames_pe
 }
 
 int mfcc512_lds_bytes_per_block(bool tile) { return (int)lds_bytes(tile); }
-int mfcc512_frames_per_item() { return DSP_NF; }
-bool mfcc512_has_tile() { return DSP_NF == 1; }
 
 template <int S, int L, int G, int TILE>
 static int occupancy_one(bool full)
 {
     int n = 0;
     const size_t lds = lds_bytes(TILE);
-    hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, true, DSP_NF, 0, TILE>, 256, lds)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, false, DSP_NF, 0, TILE>, 256, lds);
+    hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, true, 0, TILE, false>, 256, lds)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, false, 0, TILE, false>, 256, lds);
     return e == hipSuccess && n > 0 ? n : 4;
 }
 
 // resident 256-thread blocks per CU for the instantiation a plan will launch
 int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full, bool tile)
 {
-#if DSP_NF == 1
 #define DSP_OCC(S, L, G) \
     if (dct_split == S && dct_len == L && gather == G) return tile ? occupancy_one<S, L, G, 1>(full) : occupancy_one<S, L, G, 0>(full);
-#else
-#define DSP_OCC(S, L, G) \
-    if (dct_split == S && dct_len == L && gather == G) return occupancy_one<S, L, G, 0>(full);
-#endif
     DSP_FOR_SHAPES(DSP_OCC)
 #undef DSP_OCC
     return 4;

@@ -42,8 +42,6 @@ int mfcc512_row_blocks_per_cu(int dct_split, int dct_len, int gather, bool full)
 hipError_t launch_mfcc1024(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream);
 int mfcc1024_blocks_per_cu(bool full);
 int mfcc512_lds_bytes_per_block(bool tile);
-int mfcc512_frames_per_item();   // frames a wave processes together; chunk must be a multiple
-bool mfcc512_has_tile();         // false in the DSP_NF > 1 experiment builds
 int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full, bool tile);
 
 }  // namespace dsp
