@@ -179,23 +179,28 @@ struct FrameCursor {
 // otherwise frames lie back to back (offset = f * frame_len).
 template <bool CLIPS>
 struct WaveCursor {
-    long f, off;                 // frame index (valid while f < n) and its first sample
+    long f, off;                 // frame index and its first sample; meaningful while valid()
     long clip;                   // CLIPS: clip of frame f
-    long n;
     long chunk_f, chunk_off;     // first frame of the current chunk; CLIPS: chunk_off = offset of its clip
     long chunk_clip;
     long stride_f, stride_off;   // chunk-to-chunk jump of this wave; CLIPS: stride_off = jump_clips * clip_stride
     long clip_off, clip_stride;  // CLIPS: offset of the current clip
+    long jump_clips;
+    int remaining;               // frames this wave still has to visit, f included (32-bit: scalar compare)
     int left, chunk;             // frames of the chunk still to come after f
     int t, t0, fpc, jump_t, hop; // CLIPS: frame in clip, of f / of the chunk start; hop = samples between frames
-    long jump_clips;
-    __device__ __forceinline__ void init(long wave, long n_waves, int chunk_, long n_, int fpc_, int hop_, long clip_stride_)
+    __device__ __forceinline__ void init(long wave, long n_waves, int chunk_, long n, int fpc_, int hop_, long clip_stride_)
     {
-        chunk = chunk_; n = n_; fpc = fpc_; hop = hop_; clip_stride = clip_stride_;
+        chunk = chunk_; fpc = fpc_; hop = hop_; clip_stride = clip_stride_;
         stride_f = n_waves * chunk;
         chunk_f = wave * chunk;
         f = chunk_f;
         left = chunk - 1;
+        // frames of this wave: its chunks, minus what the batch's last (partial) chunk lacks
+        const long n_chunks = (n + chunk - 1) / chunk;
+        const long mine = wave < n_chunks ? (n_chunks - 1 - wave) / n_waves + 1 : 0;
+        const bool owns_last = mine > 0 && (n_chunks - 1 - wave) % n_waves == 0;
+        remaining = (int)(mine * chunk - (owns_last ? n_chunks * chunk - n : 0));
         clip = chunk_clip = 0; t = t0 = 0; jump_t = 0; jump_clips = 0; clip_off = 0;
         if (CLIPS) {            // the only divisions and wide multiplies: once per wave
             chunk_clip = f / fpc; t0 = (int)(f - chunk_clip * fpc);
@@ -210,29 +215,35 @@ struct WaveCursor {
             off = chunk_off;
         }
     }
-    __device__ __forceinline__ bool valid() const { return f < n; }
+    __device__ __forceinline__ bool valid() const { return remaining > 0; }
+    // all selects on wave-uniform values (s_cselect), no branch
     __device__ __forceinline__ void next()
     {
-        if (left > 0) {
-            --left; ++f;
-            if (CLIPS) {
-                ++t; off += hop;
-                if (t == fpc) { t = 0; ++clip; clip_off += clip_stride; off = clip_off; }
-            } else {
-                off += hop;
-            }
+        --remaining;
+        const bool in_chunk = left > 0;
+        left = in_chunk ? left - 1 : chunk - 1;
+        chunk_f += in_chunk ? 0 : stride_f;
+        f = in_chunk ? f + 1 : chunk_f;
+        if (CLIPS) {
+            // inside the chunk: next frame of the clip, or frame 0 of the next clip
+            const bool wrap = t + 1 == fpc;
+            const int t_in = wrap ? 0 : t + 1;
+            const long clip_in = clip + (wrap ? 1 : 0);
+            const long clip_off_in = clip_off + (wrap ? clip_stride : 0);
+            const long off_in = wrap ? clip_off_in : off + hop;
+            // chunk jump: advance the chunk start by (jump_clips, jump_t) with carry
+            const int t0_raw = t0 + (in_chunk ? 0 : jump_t);
+            const bool carry = t0_raw >= fpc;
+            t0 = carry ? t0_raw - fpc : t0_raw;
+            chunk_clip += in_chunk ? 0 : jump_clips + (carry ? 1 : 0);
+            chunk_off += in_chunk ? 0 : stride_off + (carry ? clip_stride : 0);
+            t = in_chunk ? t_in : t0;
+            clip = in_chunk ? clip_in : chunk_clip;
+            clip_off = in_chunk ? clip_off_in : chunk_off;
+            off = in_chunk ? off_in : chunk_off + t0 * hop;      // t0 * hop < samples per clip < 2^31
         } else {
-            left = chunk - 1;
-            chunk_f += stride_f; f = chunk_f;
-            chunk_off += stride_off;
-            if (CLIPS) {
-                chunk_clip += jump_clips; t0 += jump_t;
-                if (t0 >= fpc) { t0 -= fpc; ++chunk_clip; chunk_off += clip_stride; }
-                clip = chunk_clip; t = t0; clip_off = chunk_off;
-                off = clip_off + t * hop;      // t * hop < samples per clip < 2^31
-            } else {
-                off = chunk_off;
-            }
+            chunk_off += in_chunk ? 0 : stride_off;
+            off = in_chunk ? off + hop : chunk_off;
         }
     }
 };
