@@ -29,6 +29,13 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
+}  // namespace
+
+// error sink shared with the other translation units of the C ABI (capi_util.hpp)
+namespace dsp { int capi_fail(int code, const std::string &msg) { return fail(code, msg); } }
+
+namespace {
+
 #define DSP_HIP(call)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \

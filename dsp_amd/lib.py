@@ -39,6 +39,20 @@ class LaneTables512(C.Structure):
     ]
 
 
+class StopModelParams(C.Structure):
+    """dsp_stop_model_params (include/dsp_amd.h)."""
+
+    _fields_ = [("n_coef", C.c_int), ("max_frames", C.c_int), ("units", C.c_int * 4),
+                ("scaler_mean", C.c_void_p), ("scaler_scale", C.c_void_p),
+                ("kernel", C.c_void_p * 4), ("bias", C.c_void_p * 4)]
+
+
+class GmmParams(C.Structure):
+    """dsp_gmm_params (include/dsp_amd.h)."""
+
+    _fields_ = [("k", C.c_int), ("d", C.c_int), ("means", C.c_void_p), ("inv_covs", C.c_void_p), ("log_consts", C.c_void_p)]
+
+
 class ClassifyTrace(C.Structure):
     """dsp_classify_trace (include/dsp_amd.h)."""
 
@@ -59,6 +73,9 @@ SYMBOLS = [
     "dsp_mfcc_default_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
     "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",
     "dsp_mfcc_clips_host", "dsp_mfcc_clips_pcm16_device", "dsp_mfcc_plan_set_launch", "dsp_mfcc_plan_set_kernel", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables",
+    "dsp_stop_model_create", "dsp_stop_model_destroy", "dsp_stop_predict_device", "dsp_classify_signal_batch_device",
+    "dsp_classify_signal", "dsp_speaker_model_create", "dsp_speaker_model_destroy", "dsp_speaker_llr_device",
+    "dsp_upsample_linear_device", "dsp_upsample_linear_host",
     "dsp_last_error", "dsp_device_count", "dsp_version",
 ]
 
@@ -120,6 +137,16 @@ def load() -> C.CDLL:
     L.dsp_svm_create.restype = ip
     L.dsp_svm_destroy.argtypes = [vp]; L.dsp_svm_destroy.restype = None
     L.dsp_svm_predict_device.argtypes = [vp, vp, C.c_long, vp, vp, vp, vp]; L.dsp_svm_predict_device.restype = ip
+    L.dsp_stop_model_create.argtypes = [C.POINTER(StopModelParams), ip, C.POINTER(vp)]; L.dsp_stop_model_create.restype = ip
+    L.dsp_stop_model_destroy.argtypes = [vp]; L.dsp_stop_model_destroy.restype = None
+    L.dsp_stop_predict_device.argtypes = [vp, vp, C.c_long, ip, vp, vp]; L.dsp_stop_predict_device.restype = ip
+    L.dsp_classify_signal_batch_device.argtypes = [vp, vp, vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_signal_batch_device.restype = ip
+    L.dsp_classify_signal.argtypes = [vp, vp, ip]; L.dsp_classify_signal.restype = C.c_float
+    L.dsp_speaker_model_create.argtypes = [C.POINTER(GmmParams), C.POINTER(GmmParams), ip, C.POINTER(vp)]; L.dsp_speaker_model_create.restype = ip
+    L.dsp_speaker_model_destroy.argtypes = [vp]; L.dsp_speaker_model_destroy.restype = None
+    L.dsp_speaker_llr_device.argtypes = [vp, vp, C.c_long, ip, vp, vp, vp, vp, vp]; L.dsp_speaker_llr_device.restype = ip
+    L.dsp_upsample_linear_device.argtypes = [vp, C.c_long, ip, C.c_long, vp, ip, C.c_long, vp]; L.dsp_upsample_linear_device.restype = ip
+    L.dsp_upsample_linear_host.argtypes = [vp, ip, vp, ip]; L.dsp_upsample_linear_host.restype = ip
     L.dsp_last_error.argtypes = []; L.dsp_last_error.restype = C.c_char_p
     L.dsp_device_count.argtypes = []; L.dsp_device_count.restype = ip
     L.dsp_version.argtypes = []; L.dsp_version.restype = C.c_char_p

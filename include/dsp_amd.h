@@ -190,6 +190,62 @@ void dsp_svm_destroy(dsp_svm *svm);
 int dsp_svm_predict_device(dsp_svm *svm, const float *d_feat, long n_clips, int *d_labels, float *d_decision,
                            float *d_prob1, void *stream);
 
+/* --- consumers of the MFCC matrix and the resampler (8f-4) ------- */
+
+/* The stop-word net behind classify_signal (2fa/audio/word/c/stop_detector.h:10,
+ * stop_detector.c:12-55; audio_classifier_inference.c:38-90).  The trained parameters are the
+ * arrays of the reference's model_params.h, handed over by the caller (never compiled in here). */
+typedef struct dsp_stop_model dsp_stop_model;
+typedef struct dsp_stop_model_params {
+    int n_coef;                  /* 13   MFCC_N_MFCC                              */
+    int max_frames;              /* 500  MAX_FRAMES (stop_detector.c:9)           */
+    int units[4];                /* 4, 2, 2, 1  DENSE1..4_UNITS (model_params.h:7-10), each <= 16, last = 1 */
+    const float *scaler_mean;    /* SCALER_MEAN  [n_coef * max_frames], coefficient-major */
+    const float *scaler_scale;   /* SCALER_SCALE [n_coef * max_frames]            */
+    const float *kernel[4];      /* DENSEn_KERNEL, (in, out) row-major             */
+    const float *bias[4];        /* DENSEn_BIAS                                    */
+} dsp_stop_model_params;
+int dsp_stop_model_create(const dsp_stop_model_params *params, int device, dsp_stop_model **out);
+void dsp_stop_model_destroy(dsp_stop_model *model);
+/* audio_classifier_predict over a batch: d_mfcc[n_clips][frames_per_clip][n_coef] frame-major (what
+ * compute_mfcc writes), viewed coefficient-major and zero-padded / truncated at max_frames as
+ * stop_detector.c:36-50 does; d_prob[n_clips] = P("stop").  HBM pointers.                       */
+int dsp_stop_predict_device(dsp_stop_model *model, const float *d_mfcc, long n_clips, int frames_per_clip,
+                            float *d_prob, void *stream);
+/* classify_signal over a batch of equally long clips resident in HBM: plan (reference defaults,
+ * n_mfcc = n_coef) -> MFCC matrices in a workspace -> the net.                                  */
+int dsp_classify_signal_batch_device(dsp_mfcc_plan *plan, dsp_stop_model *model, const float *d_signal, long n_clips,
+                                     int samples_per_clip, long clip_stride, float *d_prob, void *stream);
+/* classify_signal's own contract (stop_detector.h:10) with host buffers: probability in [0, 1];
+ * a failure returns 0 with the reason in dsp_last_error().                                       */
+float dsp_classify_signal(dsp_stop_model *model, const float *signal, int num_samples);
+
+/* Speaker verification: max-component log-likelihood ratio of a target GMM against a UBM in the
+ * reference's fixed point (2fa/audio/pico-audio/src/speaker_gmm.h:11-38, speaker_gmm.c:29-141;
+ * parameters gmm_params.inc: means Q6 int8, inverse covariances Q11 int32, log constants Q8 int16). */
+typedef struct dsp_gmm_params {
+    int k, d;                    /* 32 mixtures, 13 dimensions (k <= 64, d <= 16) */
+    const int8_t *means;         /* [k][d] */
+    const int32_t *inv_covs;     /* [k][d] */
+    const int16_t *log_consts;   /* [k]    */
+} dsp_gmm_params;
+typedef struct dsp_speaker_model dsp_speaker_model;
+int dsp_speaker_model_create(const dsp_gmm_params *target, const dsp_gmm_params *ubm, int device, dsp_speaker_model **out);
+void dsp_speaker_model_destroy(dsp_speaker_model *model);
+/* mfcc_target_speaker_llr_mean (:127-136) and classify_speaker (:138-141) per clip of
+ * d_mfcc[n_clips][frames_per_clip][d]: d_llr_mean[n_clips] (Q8, integer mean over the frames),
+ * d_labels[n_clips] = llr_mean > (int64)(-0.7 * 256); optional per-frame log-likelihoods
+ * d_ll_target / d_ll_ubm [n_clips][frames_per_clip] (target_gmm_log_likelihood / ubm_..., :84-102).
+ * Bit-exact integer results.  HBM pointers; d_labels, d_ll_* may be NULL.                        */
+int dsp_speaker_llr_device(dsp_speaker_model *model, const float *d_mfcc, long n_clips, int frames_per_clip,
+                           int64_t *d_llr_mean, int *d_labels, int64_t *d_ll_target, int64_t *d_ll_ubm, void *stream);
+
+/* upsampleLinear (sync/particle/main.cpp:62-77) over a batch: d_out[c][i] for i < new_size from
+ * d_in[c][0..old_size), the reference's fp32 operation order (bit-identical).  new_size >= 2.     */
+int dsp_upsample_linear_device(const float *d_in, long n_clips, int old_size, long in_stride, float *d_out,
+                               int new_size, long out_stride, void *stream);
+int dsp_upsample_linear_host(const float *in, int old_size, float *out, int new_size);
+
 /* Reference-layout constant tables for a configuration (what mfcc_params.h holds
  * for the reference config): window[frame_length], mel[n_mels][n_fft/2+1],
  * dct[n_mfcc][n_mels].  Host-only, no GPU needed; any pointer may be NULL.      */

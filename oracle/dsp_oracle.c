@@ -877,3 +877,111 @@ int orc_svm_predict(const orc_svm_model *m, const float *x, float *decision,
     if (prob1) *prob1 = 1.0f - p0;
     return (1.0f - p0) > p0 ? 1 : 0;
 }
+
+/* ---- classify_signal tail (stop_detector.c, audio_classifier_inference.c) ---------- */
+
+void orc_stop_features(const orc_stop_model *m, const float *mfcc, int n_frames, float *feats)
+{
+    /* stop_detector.c:26-50: T clamped to max_frames; feats[c * max_T + t] */
+    int T = n_frames > m->max_frames ? m->max_frames : n_frames;
+    for (int c = 0; c < m->n_coef; ++c)
+        for (int t = 0; t < m->max_frames; ++t)
+            feats[(size_t)c * m->max_frames + t] = t < T ? mfcc[(size_t)t * m->n_coef + c] : 0.0f;
+}
+
+static void orc_dense(const float *x, const float *w, const float *b, int n_in, int n_out, float *y, int relu)
+{
+    /* audio_classifier_inference.c:18-35: y[j] = b[j] + sum_i w[i * n_out + j] * x[i], i ascending */
+    for (int j = 0; j < n_out; ++j) {
+        float sum = b[j];
+        for (int i = 0; i < n_in; ++i) sum += w[(size_t)i * n_out + j] * x[i];
+        y[j] = (relu && !(sum > 0.0f)) ? 0.0f : sum;
+    }
+}
+
+float orc_stop_predict(const orc_stop_model *m, const float *feats)
+{
+    const int n_in = m->n_coef * m->max_frames;
+    float *x = (float *)malloc((size_t)n_in * sizeof(float));
+    for (int i = 0; i < n_in; ++i) {            /* :41-47 */
+        float scale = m->scaler_scale[i];
+        if (scale == 0.0f) scale = 1.0f;
+        x[i] = (feats[i] - m->scaler_mean[i]) / scale;
+    }
+    float h[2][64];
+    orc_dense(x, m->kernel[0], m->bias[0], n_in, m->units[0], h[0], 1);
+    orc_dense(h[0], m->kernel[1], m->bias[1], m->units[0], m->units[1], h[1], 1);
+    orc_dense(h[1], m->kernel[2], m->bias[2], m->units[1], m->units[2], h[0], 1);
+    orc_dense(h[0], m->kernel[3], m->bias[3], m->units[2], m->units[3], h[1], 0);
+    free(x);
+    return 1.0f / (1.0f + expf(-h[1][0]));      /* :13-15 */
+}
+
+float orc_classify_signal(const orc_stop_model *m, const float *signal, int num_samples)
+{
+    orc_mfcc_cfg cfg;
+    orc_mfcc_default_cfg(&cfg);
+    cfg.n_mfcc = m->n_coef;
+    float *mf = (float *)calloc((size_t)m->max_frames * m->n_coef, sizeof(float));
+    float *feats = (float *)malloc((size_t)m->max_frames * m->n_coef * sizeof(float));
+    int T = orc_compute_mfcc(&cfg, signal, num_samples, mf, m->max_frames);
+    orc_stop_features(m, mf, T, feats);
+    float p = orc_stop_predict(m, feats);
+    free(mf);
+    free(feats);
+    return p;
+}
+
+/* ---- speaker GMM (pico-audio/src/speaker_gmm.c) -------------------------------------- */
+
+int64_t orc_gmm_log_likelihood(const orc_gmm *g, const int16_t *x)
+{
+    int64_t best = INT64_MIN;
+    for (int k = 0; k < g->k; ++k) {
+        int64_t sum_sq = 0;
+        for (int d = 0; d < g->d; ++d) {
+            int64_t diff = (int64_t)x[d] - (int64_t)g->means[k * g->d + d];
+            sum_sq += diff * diff * (int64_t)g->inv_covs[k * g->d + d];   /* Q6 * Q6 * Q11 = Q23 */
+        }
+        sum_sq >>= 15;      /* Q23 -> Q8 (arithmetic shift, as gcc does for int64_t) */
+        sum_sq /= 2;        /* toward zero */
+        int64_t term = (int64_t)g->log_consts[k] - sum_sq;
+        if (term > best) best = term;
+    }
+    return best;
+}
+
+void orc_float_to_q6(const float *in, int16_t *out, int n)
+{
+    for (int i = 0; i < n; ++i) out[i] = (int16_t)(int32_t)(in[i] * 64);
+}
+
+int64_t orc_speaker_llr_mean(const orc_gmm *target, const orc_gmm *ubm, const float *mfcc, int n_frames)
+{
+    int16_t x[64];
+    int64_t sum = 0;
+    for (int t = 0; t < n_frames; ++t) {
+        orc_float_to_q6(mfcc + (size_t)t * target->d, x, target->d);
+        sum += orc_gmm_log_likelihood(target, x) - orc_gmm_log_likelihood(ubm, x);
+    }
+    return sum / n_frames;
+}
+
+int orc_classify_speaker(const orc_gmm *target, const orc_gmm *ubm, const float *mfcc, int n_frames)
+{
+    const int64_t threshold = (int64_t)(-0.7 * (1 << 8));
+    return orc_speaker_llr_mean(target, ubm, mfcc, n_frames) > threshold ? 1 : 0;
+}
+
+/* ---- linear resampler (sync/particle/main.cpp:62-77) ------------------------------------ */
+
+void orc_upsample_linear(const float *in, int old_size, float *out, int new_size)
+{
+    for (int i = 0; i < new_size; ++i) {
+        float old_index = i * ((float)(old_size - 1) / (float)(new_size - 1));
+        int lo = (int)floor(old_index);
+        int hi = lo == old_size - 1 ? old_size - 1 : lo + 1;
+        float frac = old_index - lo;
+        out[i] = in[lo] + (in[hi] - in[lo]) * frac;
+    }
+}

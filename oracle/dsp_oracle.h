@@ -18,7 +18,10 @@
  * as fixtures).  Exception: the aubio front end of cepstrum/scrubjay_infer.c is
  * a third-party library absent from the reference tree and from this image
  * (aubio, unpinned, cepstrum/CMakeLists.txt:10) -> orc_mfcc_stats()/orc_svm_*()
- * are "parity unpinned" at the aubio boundary; see DESIGN.md.
+ * are "parity unpinned" at the aubio boundary; see DESIGN.md.  The consumers added for SURVEY 8f are
+ * pinned the same way (stop-word net, speaker GMM: goldens from the reference's own stop_detector.c /
+ * audio_classifier_inference.c / speaker_gmm.c in oracle/_ref); orc_upsample_linear() restates a firmware
+ * file that cannot be built here and has no fixture: "parity unpinned".
  */
 #ifndef DSP_ORACLE_H
 #define DSP_ORACLE_H
@@ -171,6 +174,48 @@ typedef struct orc_svm_model {
  * Returns the label (0/1); decision and P(label 1) are written if non-NULL.  */
 int orc_svm_predict(const orc_svm_model *m, const float *x, float *decision,
                     float *prob1);
+
+/* ---- consumers of the MFCC matrix and the resampler (8f-4) ---- */
+
+/* 2fa/audio/word/c/model_params.h:6-10 (sizes) + :12-4925 (trained parameters; passed in,
+ * never compiled in here).                                                          */
+typedef struct orc_stop_model {
+    int n_coef;        /* 13  MFCC_N_MFCC */
+    int max_frames;    /* 500 MAX_FRAMES (stop_detector.c:9) */
+    int units[4];      /* 4, 2, 2, 1 */
+    const float *scaler_mean, *scaler_scale; /* [n_coef * max_frames], coefficient-major */
+    const float *kernel[4];                  /* (in, out) row-major */
+    const float *bias[4];
+} orc_stop_model;
+
+/* stop_detector.c:36-50  frame-major [n_frames][n_coef] -> coefficient-major
+ * feats[n_coef][max_frames], zero-padded / truncated at max_frames.                 */
+void orc_stop_features(const orc_stop_model *m, const float *mfcc, int n_frames, float *feats);
+/* audio_classifier_inference.c:38-90  StandardScaler -> 3 x (dense + ReLU) -> dense ->
+ * sigmoid, sums in the reference's order (fp32, input index ascending).             */
+float orc_stop_predict(const orc_stop_model *m, const float *feats);
+/* stop_detector.c:12-55  compute_mfcc (reference defaults) -> features -> net.      */
+float orc_classify_signal(const orc_stop_model *m, const float *signal, int num_samples);
+
+/* 2fa/audio/pico-audio/src/speaker_gmm.c (parameters: gmm_params.inc:8-13 Q formats). */
+typedef struct orc_gmm {
+    int k, d;                 /* 32 mixtures, 13 dimensions */
+    const int8_t *means;      /* [k][d]  Q6  */
+    const int32_t *inv_covs;  /* [k][d]  Q11 */
+    const int16_t *log_consts;/* [k]     Q8  */
+} orc_gmm;
+/* speaker_gmm.c:29-50  max-component approximation of the log-likelihood, Q8.       */
+int64_t orc_gmm_log_likelihood(const orc_gmm *g, const int16_t *x);
+/* speaker_gmm.c:118-122  x * 64 truncated to int16 (out of range: low 16 bits of the
+ * int32 truncation, what gcc on x86-64 does for the reference).                      */
+void orc_float_to_q6(const float *in, int16_t *out, int n);
+/* speaker_gmm.c:104-108,127-136  sum over frames of (target - ubm), integer mean.   */
+int64_t orc_speaker_llr_mean(const orc_gmm *target, const orc_gmm *ubm, const float *mfcc, int n_frames);
+/* speaker_gmm.c:124-125,138-141  mean LLR > (int64)(-0.7 * 256).                     */
+int orc_classify_speaker(const orc_gmm *target, const orc_gmm *ubm, const float *mfcc, int n_frames);
+
+/* sync/particle/main.cpp:62-77  linear-interpolation resampler (fp32, no contraction). */
+void orc_upsample_linear(const float *in, int old_size, float *out, int new_size);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,17 @@ class SvmModel(C.Structure):
                 ("sv", C.POINTER(C.c_float)), ("coef", C.POINTER(C.c_float))]
 
 
+class StopModel(C.Structure):
+    _fields_ = [("n_coef", C.c_int), ("max_frames", C.c_int), ("units", C.c_int * 4),
+                ("scaler_mean", C.POINTER(C.c_float)), ("scaler_scale", C.POINTER(C.c_float)),
+                ("kernel", C.POINTER(C.c_float) * 4), ("bias", C.POINTER(C.c_float) * 4)]
+
+
+class Gmm(C.Structure):
+    _fields_ = [("k", C.c_int), ("d", C.c_int), ("means", C.POINTER(C.c_int8)),
+                ("inv_covs", C.POINTER(C.c_int32)), ("log_consts", C.POINTER(C.c_int16))]
+
+
 WINDOW_HANN, WINDOW_HAMMING, WINDOW_RECT = 0, 1, 2
 MELNORM_NONE, MELNORM_SLANEY = 0, 1
 LOG_PER_FRAME_MAX, LOG_GLOBAL_REF1 = 0, 1
@@ -96,6 +107,20 @@ def lib() -> C.CDLL:
         L.orc_mfcc_stats.argtypes = [_F, C.c_int, C.c_int, _F]
         L.orc_svm_predict.argtypes = [C.POINTER(SvmModel), _F, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_svm_predict.restype = C.c_int
+        L.orc_stop_features.argtypes = [C.POINTER(StopModel), _F, C.c_int, _F]
+        L.orc_stop_predict.argtypes = [C.POINTER(StopModel), _F]
+        L.orc_stop_predict.restype = C.c_float
+        L.orc_classify_signal.argtypes = [C.POINTER(StopModel), _F, C.c_int]
+        L.orc_classify_signal.restype = C.c_float
+        _I16 = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
+        L.orc_gmm_log_likelihood.argtypes = [C.POINTER(Gmm), _I16]
+        L.orc_gmm_log_likelihood.restype = C.c_int64
+        L.orc_float_to_q6.argtypes = [_F, _I16, C.c_int]
+        L.orc_speaker_llr_mean.argtypes = [C.POINTER(Gmm), C.POINTER(Gmm), _F, C.c_int]
+        L.orc_speaker_llr_mean.restype = C.c_int64
+        L.orc_classify_speaker.argtypes = [C.POINTER(Gmm), C.POINTER(Gmm), _F, C.c_int]
+        L.orc_classify_speaker.restype = C.c_int
+        L.orc_upsample_linear.argtypes = [_F, C.c_int, _F, C.c_int]
         _lib = L
     return _lib
 
@@ -251,6 +276,86 @@ def svm_predict(model: dict, x: np.ndarray):
     return int(label), float(dec.value), float(p1.value)
 
 
+# ---- consumers of the MFCC matrix ------------------------------------------------
+
+def _stop_model(model: dict):
+    """model: dict with scaler_mean, scaler_scale [n_coef*max_frames], kernel0..3, bias0..3."""
+    keep = {k: np.ascontiguousarray(model[k], np.float32) for k in
+            ["scaler_mean", "scaler_scale"] + [f"kernel{i}" for i in range(4)] + [f"bias{i}" for i in range(4)]}
+    m = StopModel()
+    m.n_coef, m.max_frames = int(model.get("n_coef", 13)), int(model.get("max_frames", 500))
+    for i in range(4):
+        m.units[i] = keep[f"bias{i}"].size
+        m.kernel[i] = keep[f"kernel{i}"].ctypes.data_as(C.POINTER(C.c_float))
+        m.bias[i] = keep[f"bias{i}"].ctypes.data_as(C.POINTER(C.c_float))
+    m.scaler_mean = keep["scaler_mean"].ctypes.data_as(C.POINTER(C.c_float))
+    m.scaler_scale = keep["scaler_scale"].ctypes.data_as(C.POINTER(C.c_float))
+    return m, keep
+
+
+def stop_features(model: dict, mfcc: np.ndarray) -> np.ndarray:
+    m, _keep = _stop_model(model)
+    mfcc = np.ascontiguousarray(mfcc, np.float32)
+    out = np.empty(m.n_coef * m.max_frames, np.float32)
+    lib().orc_stop_features(C.byref(m), mfcc.reshape(-1), mfcc.shape[0], out)
+    return out
+
+
+def stop_predict(model: dict, feats: np.ndarray) -> float:
+    m, _keep = _stop_model(model)
+    return float(lib().orc_stop_predict(C.byref(m), np.ascontiguousarray(feats, np.float32).reshape(-1)))
+
+
+def classify_signal(model: dict, signal: np.ndarray) -> float:
+    m, _keep = _stop_model(model)
+    signal = np.ascontiguousarray(signal, np.float32)
+    return float(lib().orc_classify_signal(C.byref(m), signal, signal.size))
+
+
+def _gmm(g: dict):
+    keep = (np.ascontiguousarray(g["means"], np.int8), np.ascontiguousarray(g["inv_covs"], np.int32),
+            np.ascontiguousarray(g["log_consts"], np.int16))
+    s = Gmm()
+    s.k, s.d = keep[0].shape
+    s.means = keep[0].ctypes.data_as(C.POINTER(C.c_int8))
+    s.inv_covs = keep[1].ctypes.data_as(C.POINTER(C.c_int32))
+    s.log_consts = keep[2].ctypes.data_as(C.POINTER(C.c_int16))
+    return s, keep
+
+
+def float_to_q6(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(x.size, np.int16)
+    lib().orc_float_to_q6(x.reshape(-1), out, x.size)
+    return out.reshape(x.shape)
+
+
+def gmm_log_likelihood(g: dict, x_q6: np.ndarray) -> int:
+    s, _keep = _gmm(g)
+    return int(lib().orc_gmm_log_likelihood(C.byref(s), np.ascontiguousarray(x_q6, np.int16)))
+
+
+def speaker_llr_mean(target: dict, ubm: dict, mfcc: np.ndarray) -> int:
+    t, _k1 = _gmm(target)
+    u, _k2 = _gmm(ubm)
+    mfcc = np.ascontiguousarray(mfcc, np.float32)
+    return int(lib().orc_speaker_llr_mean(C.byref(t), C.byref(u), mfcc.reshape(-1), mfcc.shape[0]))
+
+
+def classify_speaker(target: dict, ubm: dict, mfcc: np.ndarray) -> int:
+    t, _k1 = _gmm(target)
+    u, _k2 = _gmm(ubm)
+    mfcc = np.ascontiguousarray(mfcc, np.float32)
+    return int(lib().orc_classify_speaker(C.byref(t), C.byref(u), mfcc.reshape(-1), mfcc.shape[0]))
+
+
+def upsample_linear(x: np.ndarray, new_size: int) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(new_size, np.float32)
+    lib().orc_upsample_linear(x, x.size, out, new_size)
+    return out
+
+
 # ---- the reference itself (only where oracle/_ref was built) -------------------
 
 def have_ref() -> bool:
@@ -314,3 +419,75 @@ def ref_classifier_lib() -> C.CDLL:
         L.ref_sum_intense.restype = C.c_float
         _ref_cls = L
     return _ref_cls
+
+
+_ref_stop = None
+_ref_gmm = None
+
+
+def ref_stop_lib() -> C.CDLL:
+    """The reference's stop detector (2fa/audio/word/c: mfcc.c + stop_detector.c + audio_classifier_inference.c)."""
+    global _ref_stop
+    if _ref_stop is None:
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_stop.so"))
+        L.classify_signal.argtypes = [_F, C.c_int]
+        L.classify_signal.restype = C.c_float
+        L.audio_classifier_predict.argtypes = [_F]
+        L.audio_classifier_predict.restype = C.c_float
+        for name in ("ref_stop_scaler_mean", "ref_stop_scaler_scale"):
+            getattr(L, name).restype = C.POINTER(C.c_float)
+        for name in ("ref_stop_kernel", "ref_stop_bias"):
+            getattr(L, name).argtypes = [C.c_int]
+            getattr(L, name).restype = C.POINTER(C.c_float)
+        L.ref_stop_units.argtypes = [C.POINTER(C.c_int)]
+        _ref_stop = L
+    return _ref_stop
+
+
+def ref_stop_model() -> dict:
+    """The trained parameters compiled into the reference (model_params.h), as arrays."""
+    L = ref_stop_lib()
+    n_in = L.ref_stop_input_size()
+    units = (C.c_int * 4)()
+    L.ref_stop_units(units)
+    m = {"n_coef": 13, "max_frames": n_in // 13,
+         "scaler_mean": np.ctypeslib.as_array(L.ref_stop_scaler_mean(), (n_in,)).copy(),
+         "scaler_scale": np.ctypeslib.as_array(L.ref_stop_scaler_scale(), (n_in,)).copy()}
+    fan_in = n_in
+    for i in range(4):
+        m[f"kernel{i}"] = np.ctypeslib.as_array(L.ref_stop_kernel(i), (fan_in * units[i],)).copy()
+        m[f"bias{i}"] = np.ctypeslib.as_array(L.ref_stop_bias(i), (units[i],)).copy()
+        fan_in = units[i]
+    return m
+
+
+def ref_gmm_lib() -> C.CDLL:
+    """The reference's speaker GMM (2fa/audio/pico-audio/src/speaker_gmm.c + gmm_params.inc)."""
+    global _ref_gmm
+    if _ref_gmm is None:
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_gmm.so"))
+        _I16 = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
+        L.target_gmm_log_likelihood.argtypes = [_I16]
+        L.target_gmm_log_likelihood.restype = C.c_int64
+        L.ubm_gmm_log_likelihood.argtypes = [_I16]
+        L.ubm_gmm_log_likelihood.restype = C.c_int64
+        L.float_to_g6int16_arr.argtypes = [_F, _I16, C.c_int]
+        L.mfcc_target_speaker_llr_mean.argtypes = [_F, C.c_int]
+        L.mfcc_target_speaker_llr_mean.restype = C.c_int64
+        L.classify_speaker.argtypes = [_F, C.c_int]
+        L.classify_speaker.restype = C.c_int
+        _ref_gmm = L
+    return _ref_gmm
+
+
+def ref_gmm_params() -> tuple[dict, dict]:
+    """(target, ubm) parameter tables of the reference's gmm_params.inc (K = 32, D = 13)."""
+    L = ref_gmm_lib()
+    out = []
+    for who in ("target", "ubm"):
+        out.append({
+            "means": np.ctypeslib.as_array((C.c_int8 * (32 * 13)).in_dll(L, f"{who}_means")).reshape(32, 13).copy(),
+            "inv_covs": np.ctypeslib.as_array((C.c_int32 * (32 * 13)).in_dll(L, f"{who}_inv_covs")).reshape(32, 13).copy(),
+            "log_consts": np.ctypeslib.as_array((C.c_int16 * 32).in_dll(L, f"{who}_log_consts")).copy(),
+        })
+    return out[0], out[1]

@@ -49,13 +49,83 @@ def read_wav_i16(path):
     return d.reshape(-1, w.getnchannels()), w.getframerate()
 
 
+STOP_CLIPS = [  # 2fa/audio/data/testing: clips on which the reference's net is not in its all-ReLUs-dead plateau
+    "stop_121417.wav", "four__common_voice_en_20726027.wav", "four__common_voice_en_22102474.wav",
+    "off__common_voice_en_20947144.wav", "house__common_voice_en_21901759.wav", "down__common_voice_en_20545290.wav",
+    "bed__common_voice_en_504965.wav",
+]
+
+
+def consumers(ref):
+    """Goldens for the consumers of the MFCC matrix: the reference's stop detector
+    (2fa/audio/word/c/stop_detector.c + audio_classifier_inference.c, parameters model_params.h) and speaker GMM
+    (2fa/audio/pico-audio/src/speaker_gmm.c, parameters gmm_params.inc), both compiled from the reference's
+    own sources into oracle/_ref.  The trained parameters are stored as arrays (data, read out of the compiled
+    reference), the reference's outputs as the expected values."""
+    L = O.ref_stop_lib()
+    model = O.ref_stop_model()
+    out = {k: v for k, v in model.items() if isinstance(v, np.ndarray)}
+    out["n_coef"], out["max_frames"] = np.int32(model["n_coef"]), np.int32(model["max_frames"])
+    np.savez_compressed(os.path.join(HERE, "stop_model.npz"), **out)
+    g = {}
+    rng = np.random.default_rng(11)
+    for i, name in enumerate(STOP_CLIPS):
+        pcm, sr = read_wav_i16(os.path.join(ref, "2fa/audio/data/testing", name))
+        assert sr == 16000 and pcm.shape[1] == 1
+        x = (pcm[:, 0] / np.float32(32768.0)).astype(np.float32)
+        g[f"clip{i}__pcm"] = pcm[:, 0].copy()
+        g[f"clip{i}__prob"] = np.float32(L.classify_signal(x, x.size))
+        print(f"classify_signal {name:45s} -> {g[f'clip{i}__prob']:.6f}")
+    # feature-level cases (audio_classifier_predict): perturbations around the scaler mean keep the net off its plateaus
+    feats = np.stack([model["scaler_mean"] + rng.standard_normal(6500).astype(np.float32) * model["scaler_scale"] * np.float32(s)
+                      for s in (0.0, 0.5, 1.0, 2.0, 4.0, 1.0, 1.0, 3.0)]).astype(np.float32)
+    g["feats"] = feats
+    g["feats_prob"] = np.array([L.audio_classifier_predict(f) for f in feats], np.float32)
+    print("audio_classifier_predict on synthetic features:", g["feats_prob"])
+    np.savez_compressed(os.path.join(HERE, "stop_ref.npz"), **g)
+
+    G = O.ref_gmm_lib()
+    target, ubm = O.ref_gmm_params()
+    s = {"target_means": target["means"], "target_inv_covs": target["inv_covs"], "target_log_consts": target["log_consts"],
+         "ubm_means": ubm["means"], "ubm_inv_covs": ubm["inv_covs"], "ubm_log_consts": ubm["log_consts"]}
+    # Q6 conversion, including values beyond int16 after the x64 (speaker_gmm.c:118-122)
+    xs = np.array([0.0, 0.49, -0.49, 1.0 / 64, -1.0 / 64, 3.999, -3.999, 511.99, -512.0, 600.0, -700.25, 1e4, -1e4], np.float32)
+    q = np.empty(xs.size, np.int16)
+    G.float_to_g6int16_arr(xs.copy(), q, xs.size)
+    s["q6_in"], s["q6_out"] = xs, q
+    # per-frame log-likelihoods and per-clip LLR means on the reference's own MFCC of the stop clips
+    for i, name in enumerate(STOP_CLIPS[:4]):
+        pcm, _ = read_wav_i16(os.path.join(ref, "2fa/audio/data/testing", name))
+        x = (pcm[:, 0] / np.float32(32768.0)).astype(np.float32)
+        mf = O.ref_compute_mfcc(x, 500)
+        xq = np.empty(mf.shape, np.int16)
+        G.float_to_g6int16_arr(mf.reshape(-1).copy(), xq.reshape(-1), mf.size)
+        s[f"clip{i}__mfcc"] = mf
+        s[f"clip{i}__ll_target"] = np.array([G.target_gmm_log_likelihood(r.copy()) for r in xq], np.int64)
+        s[f"clip{i}__ll_ubm"] = np.array([G.ubm_gmm_log_likelihood(r.copy()) for r in xq], np.int64)
+        s[f"clip{i}__llr_mean"] = np.int64(G.mfcc_target_speaker_llr_mean(mf.reshape(-1).copy(), mf.shape[0]))
+        s[f"clip{i}__label"] = np.int32(G.classify_speaker(mf.reshape(-1).copy(), mf.shape[0]))
+        print(f"speaker gmm {name:45s} llr_mean={s[f'clip{i}__llr_mean']} label={s[f'clip{i}__label']}")
+    # synthetic frames near the mixture means (so that different mixtures win)
+    synth = (target["means"][rng.integers(0, 32, 200)] / np.float32(64.0) + rng.standard_normal((200, 13)).astype(np.float32) * np.float32(0.3)).astype(np.float32)
+    s["synth__mfcc"] = synth
+    s["synth__llr_mean"] = np.int64(G.mfcc_target_speaker_llr_mean(synth.reshape(-1).copy(), 200))
+    s["synth__label"] = np.int32(G.classify_speaker(synth.reshape(-1).copy(), 200))
+    print("speaker gmm synthetic:", s["synth__llr_mean"], s["synth__label"])
+    np.savez_compressed(os.path.join(HERE, "speaker_gmm_ref.npz"), **s)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="", help="'consumers': regenerate only stop_model / stop_ref / speaker_gmm_ref")
     args = ap.parse_args()
     ref = args.ref
     O.build(force=True)
     assert O.have_ref(), "oracle/_ref not built (reference checkout missing?)"
+    if args.only == "consumers":
+        consumers(ref)
+        return
 
     # ---- compute_mfcc goldens ------------------------------------------------
     cases = {}
@@ -162,6 +232,8 @@ def main():
         vals = np.array(open(txt).read().split(",")[:4096], dtype=np.float64)  # one comma-separated row, "%f"
         np.savez_compressed(os.path.join(HERE, "pcm_kat.npz"), pcm=bird[: vals.shape[0]].copy(), dump=vals)
         print("pcm dump rows:", vals.shape)
+
+    consumers(ref)
 
 
 if __name__ == "__main__":
