@@ -457,6 +457,7 @@ struct ClassifyCtx {
     dsp::SpecTables *d_tab = nullptr;
     // workspace for one sub-batch
     float *d_x = nullptr, *d_bp = nullptr, *d_mp = nullptr, *d_sbp = nullptr, *d_smp = nullptr;
+    float *d_mean_bp = nullptr, *d_mean_mp = nullptr;      // spectrogram segment means, written by the IIR kernel
     int *d_labels = nullptr;
     dsp::ClassifyTrace *d_trace = nullptr;
     long cap_clips = 0;
@@ -479,6 +480,8 @@ int cls_init()
     dsp::build_spec_tables(16000, t);
     DSP_HIP(hipMalloc(&g_cls.d_tab, sizeof(t)));
     DSP_HIP(hipMemcpy(g_cls.d_tab, &t, sizeof(t), hipMemcpyHostToDevice));
+    DSP_HIP(dsp::launch_spec_threshold(g_cls.d_tab, nullptr));
+    DSP_HIP(hipStreamSynchronize(nullptr));
     return DSP_OK;
 }
 
@@ -488,9 +491,9 @@ int cls_reserve(long clips, int n)
 {
     if (clips <= g_cls.cap_clips && n <= g_cls.cap_n) return DSP_OK;
     for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_bp, (void *)g_cls.d_mp, (void *)g_cls.d_sbp, (void *)g_cls.d_smp,
-                    (void *)g_cls.d_labels, (void *)g_cls.d_trace})
+                    (void *)g_cls.d_mean_bp, (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_trace})
         if (p) hipFree(p);
-    g_cls.d_x = g_cls.d_bp = g_cls.d_mp = g_cls.d_sbp = g_cls.d_smp = nullptr;
+    g_cls.d_x = g_cls.d_bp = g_cls.d_mp = g_cls.d_sbp = g_cls.d_smp = g_cls.d_mean_bp = g_cls.d_mean_mp = nullptr;
     g_cls.d_labels = nullptr; g_cls.d_trace = nullptr;
     g_cls.cap_clips = 0; g_cls.cap_n = 0;
     const size_t sig = (size_t)clips * n * sizeof(float);
@@ -500,6 +503,8 @@ int cls_reserve(long clips, int n)
     DSP_HIP(hipMalloc(&g_cls.d_mp, sig));
     DSP_HIP(hipMalloc(&g_cls.d_sbp, spec));
     DSP_HIP(hipMalloc(&g_cls.d_smp, spec));
+    DSP_HIP(hipMalloc(&g_cls.d_mean_bp, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(float)));
+    DSP_HIP(hipMalloc(&g_cls.d_mean_mp, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_labels, (size_t)clips * sizeof(int)));
     DSP_HIP(hipMalloc(&g_cls.d_trace, (size_t)clips * sizeof(dsp::ClassifyTrace)));
     g_cls.cap_clips = clips; g_cls.cap_n = n;
@@ -519,15 +524,16 @@ dsp::IirCoef coef_f32(double lo, double hi)
 int cls_run(const float *d_x, long clips, int n, long stride, hipStream_t st)
 {
     const dsp::IirCoef bp = coef_f32(3000, 7500), mp = coef_f32(1000, 3000);   // classifier.cpp:14-19, 438-442
-    DSP_HIP(dsp::launch_iir_f32(d_x, clips, n, stride, bp, g_cls.d_bp, mp, g_cls.d_mp, st));
+    DSP_HIP(dsp::launch_iir_f32(d_x, clips, n, stride, bp, g_cls.d_bp, mp, g_cls.d_mp, st, g_cls.d_mean_bp, g_cls.d_mean_mp));
     // the IIR kernel writes with the input's row stride; the workspace rows are n long
-    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_bp, clips, n, stride, g_cls.d_tab, g_cls.d_sbp, st));
-    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_mp, clips, n, stride, g_cls.d_tab, g_cls.d_smp, st));
-    DSP_HIP(dsp::launch_classify_tail(g_cls.d_sbp, g_cls.d_smp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, st));
+    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_bp, clips, n, stride, g_cls.d_tab, g_cls.d_sbp, st, g_cls.d_mean_bp));
+    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_mp, clips, n, stride, g_cls.d_tab, g_cls.d_smp, st, g_cls.d_mean_mp));
+    DSP_HIP(dsp::launch_classify_tail(g_cls.d_sbp, g_cls.d_smp, clips, n, 16000, g_cls.d_tab, g_cls.d_labels, g_cls.d_trace, st));
     return DSP_OK;
 }
 
-constexpr long kClsSubBatch = 2048;
+// clips per pass through the workspace (270 KB per 1 s clip): large enough that lane-per-clip IIR waves fill the chip
+constexpr long kClsSubBatch = 32768;
 
 }  // namespace
 
@@ -649,8 +655,8 @@ int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long s
         if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), (int)std::max<long>(n, stride))) < 0) return rc;
         if ((rc = cls_run(d_signal + c0 * stride, cnt, n, stride, st)) < 0) return rc;
         DSP_HIP(hipMemcpyAsync(d_labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, st));
-        DSP_HIP(hipStreamSynchronize(st));
     }
+    DSP_HIP(hipStreamSynchronize(st));      // the workspace is shared: it must be idle before the lock is released
     return DSP_OK;
 }
 

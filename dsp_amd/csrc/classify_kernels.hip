@@ -48,96 +48,135 @@ __device__ __forceinline__ T iir_step(IirState<T> &s, const C &c, T x)
 
 // T: arithmetic type of the recurrence; TIO: element type in HBM (float rows filtered in double
 // are converted on load and rounded once on store: BASELINE config 3's per-frame prefilter).
-template <typename T, typename C, bool TWO, typename TIO = T>
-__global__ __launch_bounds__(64) void iir_kernel(const TIO *__restrict__ x, long n_clips, int n, long stride,
-                                                 const C c1, TIO *__restrict__ y1, const C c2, TIO *__restrict__ y2)
+// TWO: two filters over the same input, one wavefront each (128-thread block, shared input tile): the serial
+// recurrences of the two filters run side by side instead of back to back in one lane.
+// MEANS (float): also emit the spectrogram's segment means of the outputs (see classify_kernels.hpp).
+template <typename T, typename C, bool TWO, typename TIO = T, bool MEANS = false>
+__global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restrict__ x, long n_clips, int n, long stride,
+                                                             const C c1, TIO *__restrict__ y1, const C c2, TIO *__restrict__ y2,
+                                                             float *__restrict__ means1 = nullptr, float *__restrict__ means2 = nullptr)
 {
+    constexpr int NTHR = TWO ? 128 : 64;
     __shared__ TIO tin[64 * IIR_LD];
-    __shared__ TIO tout1[64 * IIR_LD];
-    __shared__ TIO tout2[TWO ? 64 * IIR_LD : 1];
-    const int lane = threadIdx.x;
+    __shared__ TIO tout[TWO ? 2 : 1][64 * IIR_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = TWO ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;       // which filter this wavefront runs
+    const C c = wv ? c2 : c1;
+    TIO *__restrict__ y = wv ? y2 : y1;
+    float *__restrict__ means = wv ? means2 : means1;
+    TIO *to = tout[wv];
     const long clip0 = (long)blockIdx.x * 64;
     const int rows = (int)((n_clips - clip0) < 64 ? (n_clips - clip0) : 64);
-    IirState<T> s1, s2;
+    IirState<T> st;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1.d[j] = T(0); s2.d[j] = T(0); }
+    for (int j = 0; j < 8; ++j) st.d[j] = T(0);
     // 16-byte vector path needs every row start and every tile start 16-byte aligned
     const bool vec_ok = (stride * sizeof(TIO)) % 16 == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0 &&
                         (reinterpret_cast<uintptr_t>(y1) % 16) == 0 && (!TWO || (reinterpret_cast<uintptr_t>(y2) % 16) == 0);
+    float cur = 0.0f, prev = 0.0f;                    // MEANS: running sums of the current and the previous segment
+    const int n_seg = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
+    (void)cur; (void)prev; (void)n_seg; (void)means;
+    // Full tiles travel as 16-byte vectors (4 lanes cover one 64-byte row segment) and are software-pipelined:
+    // the next tile's global loads are issued before this tile's recurrence runs, so the serial arithmetic
+    // hides the HBM latency even with one wave per SIMD.
+    constexpr int PER = 16 / sizeof(TIO), CH = IIR_TS / PER;      // elements per vector, vectors per row
+    constexpr int NV = 64 * CH / NTHR;                            // vectors per thread in the tile load
+    float4 pre[NV];
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e = tid + NTHR * k, r = e / CH, cc = (e % CH) * PER;
+            pre[k] = r < rows ? *reinterpret_cast<const float4 *>(x + (clip0 + r) * stride + t0 + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (vec_ok && n >= IIR_TS) issue(0);
     for (int t0 = 0; t0 < n; t0 += IIR_TS) {
         const int cols = n - t0 < IIR_TS ? n - t0 : IIR_TS;
-        // tile load: 64 rows x IIR_TS columns.  Fast path: 16-byte vectors (4 lanes cover one
-        // 64-byte row segment); otherwise element-wise, lane -> (row = e / TS, col = e % TS)
         const bool vec = vec_ok && cols == IIR_TS;
         if (vec) {
-            constexpr int PER = 16 / sizeof(TIO), CH = IIR_TS / PER;      // elements per vector, vectors per row
-            for (int e = lane; e < 64 * CH; e += 64) {
-                const int r = e / CH, c = (e % CH) * PER;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int e = tid + NTHR * k, r = e / CH, cc = (e % CH) * PER;
                 TIO tmp[PER];
-                if (r < rows) {
-                    const float4 q = *reinterpret_cast<const float4 *>(x + (clip0 + r) * stride + t0 + c);
-                    __builtin_memcpy(tmp, &q, 16);
-                } else {
+                __builtin_memcpy(tmp, &pre[k], 16);
 #pragma unroll
-                    for (int i = 0; i < PER; ++i) tmp[i] = TIO(0);
-                }
-#pragma unroll
-                for (int i = 0; i < PER; ++i) tin[r * IIR_LD + c + i] = tmp[i];
+                for (int i = 0; i < PER; ++i) tin[r * IIR_LD + cc + i] = tmp[i];
             }
         } else
-        for (int e = lane; e < 64 * IIR_TS; e += 64) {
+        for (int e = tid; e < 64 * IIR_TS; e += NTHR) {
             const int r = e / IIR_TS, cidx = e % IIR_TS;
             TIO v = TIO(0);
             if (r < rows && cidx < cols) v = x[(clip0 + r) * stride + t0 + cidx];
             tin[r * IIR_LD + cidx] = v;
         }
         __syncthreads();
-        if (lane < rows) {
+        if (vec_ok && t0 + 2 * IIR_TS <= n) issue(t0 + IIR_TS);
+        // one sample of this lane's recurrence (+ the segment sums when MEANS)
+        // (the segment bookkeeping is derived from the wave-uniform sample index s, so it stays in scalar registers)
+        auto sample = [&](T xv, int s) -> TIO {
+            const TIO o = (TIO)iir_step<T, C>(st, c, xv);
+            if (MEANS) {
+                // sample s = 224 k + pos belongs to segment k and, for pos < 32, still to segment k - 1
+                const int k = s / kSpecHop, pos = s - k * kSpecHop;
+                if (pos == 0) { prev = cur; cur = 0.0f; }
+                cur = cur + (float)o;
+                if (pos < kSpecSeg - kSpecHop && k >= 1) {
+                    prev = prev + (float)o;
+                    if (pos == kSpecSeg - kSpecHop - 1 && k - 1 < n_seg) means[(clip0 + lane) * n_seg + k - 1] = prev / (float)kSpecSeg;
+                }
+            }
+            return o;
+        };
+        if (lane < rows && cols == IIR_TS) {
+            // full tile: the row goes LDS -> registers -> LDS in three bursts, so the LDS latency is paid once
+            // per 16 samples and not once per sample on top of the recurrence's own dependency chain
+            T xr[IIR_TS];
+            TIO orr[IIR_TS];
+#pragma unroll
+            for (int i = 0; i < IIR_TS; ++i) xr[i] = (T)tin[lane * IIR_LD + i];
+#pragma unroll
+            for (int i = 0; i < IIR_TS; ++i) orr[i] = sample(xr[i], t0 + i);
+#pragma unroll
+            for (int i = 0; i < IIR_TS; ++i) to[lane * IIR_LD + i] = orr[i];
+        } else if (lane < rows) {
             for (int i = 0; i < cols; ++i) {
-                const T xv = (T)tin[lane * IIR_LD + i];
-                tout1[lane * IIR_LD + i] = (TIO)iir_step<T, C>(s1, c1, xv);
-                if (TWO) tout2[lane * IIR_LD + i] = (TIO)iir_step<T, C>(s2, c2, xv);
+                to[lane * IIR_LD + i] = sample((T)tin[lane * IIR_LD + i], t0 + i);
             }
         }
         __syncthreads();
+        // each wavefront stores its own filter's tile
         if (vec) {
-            constexpr int PER = 16 / sizeof(TIO), CH = IIR_TS / PER;
             for (int e = lane; e < 64 * CH; e += 64) {
-                const int r = e / CH, c = (e % CH) * PER;
+                const int r = e / CH, cc = (e % CH) * PER;
                 if (r < rows) {
                     TIO tmp[PER];
                     float4 q;
 #pragma unroll
-                    for (int i = 0; i < PER; ++i) tmp[i] = tout1[r * IIR_LD + c + i];
+                    for (int i = 0; i < PER; ++i) tmp[i] = to[r * IIR_LD + cc + i];
                     __builtin_memcpy(&q, tmp, 16);
-                    *reinterpret_cast<float4 *>(y1 + (clip0 + r) * stride + t0 + c) = q;
-                    if (TWO) {
-#pragma unroll
-                        for (int i = 0; i < PER; ++i) tmp[i] = tout2[r * IIR_LD + c + i];
-                        __builtin_memcpy(&q, tmp, 16);
-                        *reinterpret_cast<float4 *>(y2 + (clip0 + r) * stride + t0 + c) = q;
-                    }
+                    *reinterpret_cast<float4 *>(y + (clip0 + r) * stride + t0 + cc) = q;
                 }
             }
         } else
         for (int e = lane; e < 64 * IIR_TS; e += 64) {
             const int r = e / IIR_TS, cidx = e % IIR_TS;
-            if (r < rows && cidx < cols) {
-                y1[(clip0 + r) * stride + t0 + cidx] = tout1[r * IIR_LD + cidx];
-                if (TWO) y2[(clip0 + r) * stride + t0 + cidx] = tout2[r * IIR_LD + cidx];
-            }
+            if (r < rows && cidx < cols) y[(clip0 + r) * stride + t0 + cidx] = to[r * IIR_LD + cidx];
         }
-        __syncthreads();
+        // no barrier here: the next iteration refills tin (read before the barrier above) and the barrier
+        // after that refill orders this tile's reads of tout before the next tile's writes
     }
 }
 
 hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, const IirCoef &c1, float *y1,
-                          const IirCoef &c2, float *y2, hipStream_t stream)
+                          const IirCoef &c2, float *y2, hipStream_t stream, float *means1, float *means2)
 {
     if (n_clips <= 0 || n <= 0) return hipSuccess;
     const int blocks = (int)((n_clips + 63) / 64);
-    if (y2) hipLaunchKernelGGL((iir_kernel<float, IirCoef, true>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2);
-    else hipLaunchKernelGGL((iir_kernel<float, IirCoef, false>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c1, y1, c1, y1);
+    if (y2 && means1 && means2)
+        hipLaunchKernelGGL((iir_kernel<float, IirCoef, true, float, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2,
+                           means1, means2);
+    else if (y2) hipLaunchKernelGGL((iir_kernel<float, IirCoef, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2, nullptr, nullptr);
+    else hipLaunchKernelGGL((iir_kernel<float, IirCoef, false>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c1, y1, c1, y1, nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -146,7 +185,7 @@ hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long strid
 {
     if (n_clips <= 0 || n <= 0) return hipSuccess;
     const int blocks = (int)((n_clips + 63) / 64);
-    hipLaunchKernelGGL((iir_kernel<double, IirCoefD, false, float>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c, y, c, y);
+    hipLaunchKernelGGL((iir_kernel<double, IirCoefD, false, float>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c, y, c, y, nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -155,72 +194,170 @@ hipError_t launch_iir_f64(const double *x, long n_clips, int n, long stride, con
 {
     if (n_clips <= 0 || n <= 0) return hipSuccess;
     const int blocks = (int)((n_clips + 63) / 64);
-    hipLaunchKernelGGL((iir_kernel<double, IirCoefD, false>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c, y, c, y);
+    hipLaunchKernelGGL((iir_kernel<double, IirCoefD, false>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c, y, c, y, nullptr, nullptr);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------
-// a10: spectrogram.  One lane per (clip, time bin): the lane runs the reference's per-frame
-// algorithm serially (sequential mean, window, in-place radix-2 FFT, PSD) on a private
-// 256-point work array.
+// a10: spectrogram.  A wavefront takes 64 consecutive (clip, time bin) frames.
+//   phase 1  lane f runs the reference's SEQUENTIAL fp32 sum of frame f (classifier.cpp:329-333):
+//            the order of the 256 additions is part of the result, so it stays serial per frame
+//            and the parallelism is across the 64 frames;
+//   phase 2  frame by frame the whole wave runs the 256-point FFT: lane g owns 4 points and does
+//            two radix-2 levels of PlainFFT.cpp:50-84 per LDS round trip (4 round trips).  Every
+//            butterfly is the reference's expression with the reference's twiddle value, and the
+//            butterflies of one level are independent, so the results are bit-identical to the
+//            serial loop whatever the lane split.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned bitrev8(unsigned v) { return __brev(v) >> 24; }
+__device__ __forceinline__ unsigned bitrev6(unsigned v) { return __brev(v) >> 26; }
 
-__global__ __launch_bounds__(64) void spectrogram_kernel(const float *__restrict__ y, long n_clips, int n, long stride,
-                                                         const SpecTables *__restrict__ tab, float *__restrict__ sxx, int T)
+struct cpx { float x, y; };
+
+// LDS position of FFT point i (float2 units).  The four level pairs touch i = base + j 4^p with the
+// lane number spread over the other base-4 digits; XOR-ing 5 d2 and 16 d3 (d2, d3 = base-4 digits 2 and 3
+// of i) into the low five bits makes every ds_write_b64 (16-lane groups) and ds_read_b64 (32-lane
+// groups) of all four patterns bank-conflict free (exhaustive search, tools/emulate_wave_fft.py style).
+__device__ __forceinline__ int spec_swz(int i)
 {
-    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
-    if (gid >= n_clips * T) return;
-    const long clip = gid / T;
-    const int t = (int)(gid - clip * T);
-    const float *seg = y + clip * stride + (long)t * kSpecHop;
-    float re[kSpecSeg], im[kSpecSeg];
-    // classifier.cpp:329-346: sequential sum, mean, detrend, window
-    float sum = 0.0f;
-    for (int i = 0; i < kSpecSeg; ++i) sum = sum + seg[i];
-    const float mean = sum / (float)kSpecSeg;
-    // bit-reversal permutation (PlainFFT.cpp:33-47) applied while loading
-    for (int i = 0; i < kSpecSeg; ++i) {
-        const float v = (seg[i] - mean) * tab->window[i];
-        re[bitrev8(i)] = v;
-        im[bitrev8(i)] = 0.0f;
+    const int d2 = (i >> 4) & 3, d3 = (i >> 6) & 3;
+    return (i & ~31) | ((i ^ (5 * d2) ^ (16 * d3)) & 31);
+}
+
+// PlainFFT.cpp:66-76: t = u * b; b = a - t; a = a + t
+__device__ __forceinline__ void butterfly(cpx &a, cpx &b, const cpx u)
+{
+    const float t1 = u.x * b.x - u.y * b.y;
+    const float t2 = u.x * b.y + u.y * b.x;
+    b.x = a.x - t1;
+    b.y = a.y - t2;
+    a.x = a.x + t1;
+    a.y = a.y + t2;
+}
+
+__global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restrict__ y, long n_clips, int n, long stride,
+                                                          const SpecTables *__restrict__ tab, float *__restrict__ sxx, int T,
+                                                          const float *__restrict__ means)
+{
+    __shared__ float2 lds[4][kSpecSeg];
+    // PSD columns of 16 consecutive frames are collected here and stored as 64-byte row segments: the output is
+    // [bin][time], one frame is a COLUMN of it (129 scattered dwords if stored directly)
+    __shared__ float psd_tile[4][kSpecBins * 17];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2 *buf = lds[wib];
+    float *tile = psd_tile[wib];
+    const long total = n_clips * T;
+    const long gid0 = ((long)blockIdx.x * 4 + wib) * 64;
+    if (gid0 >= total) return;
+
+    // ---- phase 1: sequential mean of this lane's frame
+    float mean = 0.0f;
+    if (means) {                      // already summed, in the same order, by the IIR kernel's lanes
+        if (gid0 + lane < total) mean = means[gid0 + lane];
+    } else {
+        const long gid = gid0 + lane;
+        if (gid < total) {
+            const long clip = gid / T;
+            const int t = (int)(gid - clip * T);
+            const float *seg = y + clip * stride + (long)t * kSpecHop;
+            float sum = 0.0f;
+            for (int i = 0; i < kSpecSeg; ++i) sum = sum + seg[i];
+            mean = sum / (float)kSpecSeg;
+        }
     }
-    // PlainFFT.cpp:50-84: levels l = 0..7, column m uses (u1,u2) = tw[l][m]
-    int l1 = 1;
-    for (int l = 0; l < 8; ++l) {
-        const int l2 = l1 << 1;
-        const float *ur = tab->tw_re + (l1 - 1), *ui = tab->tw_im + (l1 - 1);
-        for (int m = 0; m < l1; ++m) {
-            const float u1 = ur[m], u2 = ui[m];
-            for (int i = m; i < kSpecSeg; i += l2) {
-                const int i1 = i + l1;
-                const float t1 = u1 * re[i1] - u2 * im[i1];
-                const float t2 = u1 * im[i1] + u2 * re[i1];
-                re[i1] = re[i] - t1;
-                im[i1] = im[i] - t2;
-                re[i] = re[i] + t1;
-                im[i] = im[i] + t2;
+
+    // ---- per-lane constants of phase 2
+    // level pair (l, l+1), l1 = 2^l: lane g owns i_j = base + j l1, base = ((g >> l) << (l + 2)) | (g & (l1 - 1));
+    // level l uses tw[l1 - 1 + m] for both its butterflies, level l+1 tw[2 l1 - 1 + m] and tw[2 l1 - 1 + m + l1], m = g & (l1 - 1)
+    int pos[4][4];
+    cpx ua[4], ub0[4], ub1[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int l = 2 * p, l1 = 1 << l, m = lane & (l1 - 1);
+        const int base = ((lane >> l) << (l + 2)) | m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pos[p][j] = spec_swz(base + (j << l));
+        ua[p] = {tab->tw_re[l1 - 1 + m], tab->tw_im[l1 - 1 + m]};
+        ub0[p] = {tab->tw_re[2 * l1 - 1 + m], tab->tw_im[2 * l1 - 1 + m]};
+        ub1[p] = {tab->tw_re[2 * l1 - 1 + m + l1], tab->tw_im[2 * l1 - 1 + m + l1]};
+    }
+    // first pair works on bit-reversed positions 4g + j, i.e. on samples 64 bitrev2(j) + bitrev6(g) (PlainFFT.cpp:33-47)
+    int src[4];
+    float win[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        src[j] = 64 * (((j & 1) << 1) | (j >> 1)) + (int)bitrev6(lane);
+        win[j] = tab->window[src[j]];
+    }
+    const float U = tab->U;
+
+    // ---- phase 2
+    const int n_here = (int)(total - gid0 < 64 ? total - gid0 : 64);
+    long clip = gid0 / T;
+    int t = (int)(gid0 - clip * T);
+    for (int f = 0; f < n_here; ++f) {
+        const float mean_f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), f));
+        const float *seg = y + clip * stride + (long)t * kSpecHop;
+        cpx v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = {(seg[src[j]] - mean_f) * win[j], 0.0f};     // classifier.cpp:336-346
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (p > 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float2 q = buf[pos[p][j]]; v[j] = {q.x, q.y}; }
+            }
+            butterfly(v[0], v[1], ua[p]);
+            butterfly(v[2], v[3], ua[p]);
+            butterfly(v[0], v[2], ub0[p]);
+            butterfly(v[1], v[3], ub1[p]);
+            if (p < 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) buf[pos[p][j]] = make_float2(v[j].x, v[j].y);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
-        l1 = l2;
-    }
-    // classifier.cpp:350-365: PSD, one-sided doubling of bins 1..127
-    const float U = tab->U;
-    float *out = sxx + clip * (long)kSpecBins * T + t;
-    for (int k = 0; k < kSpecBins; ++k) {
-        float p = (re[k] * re[k] + im[k] * im[k]) / U;
-        if (k >= 1 && k < kSpecBins - 1) p = p * 2.0f;
-        out[(long)k * T] = p;
+        // lane g now holds X[g], X[g + 64], X[g + 128], X[g + 192]; classifier.cpp:350-365
+        {
+            const int col = f & 15;
+            float p0 = (v[0].x * v[0].x + v[0].y * v[0].y) / U;
+            if (lane >= 1) p0 = p0 * 2.0f;
+            tile[lane * 17 + col] = p0;
+            float p1 = (v[1].x * v[1].x + v[1].y * v[1].y) / U;
+            p1 = p1 * 2.0f;
+            tile[(lane + 64) * 17 + col] = p1;
+            if (lane == 0) tile[128 * 17 + col] = (v[2].x * v[2].x + v[2].y * v[2].y) / U;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if ((f & 15) == 15 || f == n_here - 1) {
+            // flush frames [f & ~15, f]: lane -> column lane % 16 (one frame, one division), rows lane / 16 + 4 k
+            const int col = lane & 15, ff = (f & ~15) + col;
+            if (ff <= f) {
+                const long g = gid0 + ff;
+                const long cl = g / T;
+                const int tt = (int)(g - cl * T);
+                float *out = sxx + cl * (long)kSpecBins * T + tt;
+                for (int row = lane >> 4; row < kSpecBins; row += 4) out[(long)row * T] = tile[row * 17 + col];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (++t == T) { t = 0; ++clip; }
     }
 }
 
 hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
-                                  float *sxx, hipStream_t stream)
+                                  float *sxx, hipStream_t stream, const float *means)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0 || T <= 0) return hipSuccess;
     const long total = n_clips * T;
-    hipLaunchKernelGGL(spectrogram_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, stream, y, n_clips, n, stride, tables, sxx, T);
+    hipLaunchKernelGGL(spectrogram_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means);
     return hipGetLastError();
 }
 
@@ -246,11 +383,9 @@ __device__ __forceinline__ float wave_maxf(float v)
     return v;
 }
 
-__device__ float sum_intense_dev(float lower, float upper, float half_range, int fs, const float *times_unused,
-                                 int T, const float *db, float midpoint)
+__device__ float sum_intense_dev(float lower, float upper, float half_range, int fs, int T, const float *db, float midpoint)
 {
     // classifier.cpp:370-431 with freqs[k] = k*fs/256 and times[t] = (224 t + 128)/fs recomputed in place
-    (void)times_unused;
     auto freq = [&](int k) { return (float)k * (float)fs / (float)kSpecSeg; };
     auto time = [&](int t) { return ((float)(t * kSpecHop + kSpecSeg / 2)) / (float)fs; };
     int f0 = 0;
@@ -276,23 +411,51 @@ __device__ float sum_intense_dev(float lower, float upper, float half_range, int
     return total;
 }
 
-__global__ __launch_bounds__(64) void classify_tail_kernel(float *__restrict__ sxx_bp, float *__restrict__ sxx_mp,
-                                                           long n_clips, int T, int fs, int *__restrict__ labels,
-                                                           ClassifyTrace *__restrict__ trace)
+// One 256-thread block per clip.  The band-pass dB map lives in LDS when it fits (129 x T <= kTailLdsCells,
+// always for 1 s clips), so the order-dependent sums of thread 0 read LDS instead of HBM.  The midpoint map
+// is never formed: "10 log10(s / 1e-12) > 70 dB" is monotone in s, so its pass compares s with the smallest
+// float that passes (SpecTables::mp_keep_min, found once on the device with the same to_db) and raises one
+// flag per time bin -- half of the path's float64 log10 evaluations disappear.
+constexpr int kTailLdsCells = 129 * 72;
+
+__global__ void spec_threshold_kernel(SpecTables *tab)
 {
+    // smallest positive float s with to_db(s) > 70: bisection on the bit pattern (positive floats order like ints)
+    unsigned lo = 0x00800000u, hi = 0x7F7FFFFFu;      // to_db(lo) <= 70 < to_db(hi)
+    while (hi - lo > 1) {
+        const unsigned mid = lo + (hi - lo) / 2;
+        if (to_db(__uint_as_float(mid)) > 70.0f) hi = mid; else lo = mid;
+    }
+    tab->mp_keep_min = __uint_as_float(hi);
+}
+
+hipError_t launch_spec_threshold(SpecTables *tables, hipStream_t stream)
+{
+    hipLaunchKernelGGL(spec_threshold_kernel, dim3(1), dim3(1), 0, stream, tables);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void classify_tail_kernel(float *__restrict__ sxx_bp, const float *__restrict__ sxx_mp,
+                                                            long n_clips, int T, int fs, int use_lds, const SpecTables *__restrict__ tab,
+                                                            int *__restrict__ labels, ClassifyTrace *__restrict__ trace)
+{
+    extern __shared__ float map_lds[];
+    __shared__ float blob[1024];
+    __shared__ int col_any[1024];
+    __shared__ float red_mn[4], red_mx[4];
     const long clip = blockIdx.x;
     if (clip >= n_clips) return;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const int cells = kSpecBins * T;
-    float *bp = sxx_bp + clip * (long)cells;
-    float *mp = sxx_mp + clip * (long)cells;
-    __shared__ float blob[1024];
-    __shared__ int n_blob;
+    float *bp_g = sxx_bp + clip * (long)cells;
+    const float *mp = sxx_mp + clip * (long)cells;
+    float *bp = use_lds ? map_lds : bp_g;
+    for (int j = tid; j < T; j += 256) col_any[j] = 0;
 
     // ---- band-pass map: dB, clip min/max, normalise, keep (0.65, 0.80)  classifier.cpp:35-80
     float mn = INFINITY, mx = -INFINITY;   // the reference starts from +-DBL_MAX stored in floats = +-inf
-    for (int i = lane; i < cells; i += 64) {
-        float v = bp[i];
+    for (int i = tid; i < cells; i += 256) {
+        float v = bp_g[i];
         if (v > 0) {
             v = to_db(v);
             mn = fminf(mn, v);
@@ -304,8 +467,12 @@ __global__ __launch_bounds__(64) void classify_tail_kernel(float *__restrict__ s
     }
     mn = wave_min(mn);
     mx = wave_maxf(mx);
+    if ((tid & 63) == 0) { red_mn[tid >> 6] = mn; red_mx[tid >> 6] = mx; }
+    __syncthreads();
+    mn = fminf(fminf(red_mn[0], red_mn[1]), fminf(red_mn[2], red_mn[3]));       // min / max are order-independent
+    mx = fmaxf(fmaxf(red_mx[0], red_mx[1]), fmaxf(red_mx[2], red_mx[3]));
     const float lo_thr = 0.65f, hi_thr = 0.80f;
-    for (int i = lane; i < cells; i += 64) {
+    for (int i = tid; i < cells; i += 256) {
         float v = bp[i];
         if (!isnan(v)) {
             v = (v - mn) / (mx - mn);
@@ -313,21 +480,22 @@ __global__ __launch_bounds__(64) void classify_tail_kernel(float *__restrict__ s
             bp[i] = v;
         }
     }
-    // ---- midpoint map: dB, keep > 70 dB, time bins with any cell   classifier.cpp:457-518
-    for (int i = lane; i < cells; i += 64) {
-        float v = mp[i];
-        v = (v > 0) ? to_db(v) : NAN;
-        mp[i] = (v > 70.0f) ? v : NAN;
+    // ---- midpoint map: keep > 70 dB, time bins with any cell   classifier.cpp:457-518
+    {
+        const float keep_min = tab->mp_keep_min;
+        int col = tid % T;
+        const int step = 256 % T;
+        for (int i = tid; i < cells; i += 256) {
+            if (mp[i] >= keep_min) col_any[col] = 1;        // same value from every writer
+            col += step;
+            if (col >= T) col -= T;
+        }
     }
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
         int nb = 0;
-        for (int j = 0; j < T && nb < 1024; ++j) {
-            bool any = false;
-            for (int i = 0; i < kSpecBins && !any; ++i) any = !isnan(mp[(long)i * T + j]);
-            if (any) blob[nb++] = ((float)(j * kSpecHop + kSpecSeg / 2)) / (float)fs;
-        }
-        n_blob = nb;
+        for (int j = 0; j < T && nb < 1024; ++j)
+            if (col_any[j]) blob[nb++] = ((float)(j * kSpecHop + kSpecSeg / 2)) / (float)fs;
         // greedy clustering, classifier.cpp:522-574
         const float tol = 0.05f, min_dur = 0.15f;
         float mids[kMaxMidpoints];
@@ -349,9 +517,9 @@ __global__ __launch_bounds__(64) void classify_tail_kernel(float *__restrict__ s
         int hit = 0;
         if (trace) trace[clip].n_midpoints = count;
         for (int k = 0; k < count; ++k) {
-            const float above = sum_intense_dev(5000, 7000, 0.18f, fs, nullptr, T, bp, mids[k]);
-            const float middle = sum_intense_dev(2500, 5000, 0.05f, fs, nullptr, T, bp, mids[k]);
-            const float below = sum_intense_dev(500, 2500, 0.18f, fs, nullptr, T, bp, mids[k]);
+            const float above = sum_intense_dev(5000, 7000, 0.18f, fs, T, bp, mids[k]);
+            const float middle = sum_intense_dev(2500, 5000, 0.05f, fs, T, bp, mids[k]);
+            const float below = sum_intense_dev(500, 2500, 0.18f, fs, T, bp, mids[k]);
             if (trace) {
                 trace[clip].midpoints[k] = mids[k];
                 trace[clip].sums[k][0] = above; trace[clip].sums[k][1] = middle; trace[clip].sums[k][2] = below;
@@ -362,13 +530,16 @@ __global__ __launch_bounds__(64) void classify_tail_kernel(float *__restrict__ s
     }
 }
 
-hipError_t launch_classify_tail(float *sxx_bp, float *sxx_mp, long n_clips, int n, int fs, int *labels,
+hipError_t launch_classify_tail(float *sxx_bp, float *sxx_mp, long n_clips, int n, int fs, const SpecTables *tables, int *labels,
                                 ClassifyTrace *trace, hipStream_t stream)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0) return hipSuccess;
     if (T <= 0 || T > 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(classify_tail_kernel, dim3((unsigned)n_clips), dim3(64), 0, stream, sxx_bp, sxx_mp, n_clips, T, fs, labels, trace);
+    const int use_lds = kSpecBins * T <= kTailLdsCells;
+    const size_t lds = use_lds ? (size_t)kSpecBins * T * sizeof(float) : 0;
+    hipLaunchKernelGGL(classify_tail_kernel, dim3((unsigned)n_clips), dim3(256), lds, stream, sxx_bp, sxx_mp, n_clips, T, fs, use_lds, tables,
+                       labels, trace);
     return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@ struct SpecTables {
     // PlainFFT twiddles: (u1,u2) for level l (8 levels) and column m < 2^l, produced by the
     // reference's own recurrence (PlainFFT.cpp:52-84) so every butterfly sees the same bits
     float tw_re[255], tw_im[255];   // level l starts at (1<<l) - 1
+    float mp_keep_min;              // smallest float s with (float)(10 log10(s / 1e-12)) > 70 (filled on the device)
 };
 
 struct IirCoef { float b[9], a[9]; };
@@ -25,8 +26,11 @@ struct IirCoefD { double b[9], a[9]; };
 
 // y[c][i] for n_clips clips of n samples (row stride `stride` floats), direct form II from
 // zero state per clip.  Two filters are run in one pass over x when y2 != nullptr.
+// With y2 and means1 / means2 != nullptr the lanes also keep the spectrogram's per-segment sequential sums of
+// their own outputs (classifier.cpp:329-333: 256 samples from 224 t, added in order) and store the segment
+// means means[c][t], so the spectrogram kernel need not walk the samples serially again.
 hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, const IirCoef &c1, float *y1,
-                          const IirCoef &c2, float *y2, hipStream_t stream);
+                          const IirCoef &c2, float *y2, hipStream_t stream, float *means1 = nullptr, float *means2 = nullptr);
 hipError_t launch_iir_f64(const double *x, long n_clips, int n, long stride, const IirCoefD &c, double *y,
                           hipStream_t stream);
 // float rows, recurrence in double, one rounding on store (per-frame prefilter of BASELINE config 3)
@@ -34,8 +38,9 @@ hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long strid
                                  hipStream_t stream);
 
 // sxx[c][129][T] (T = (n-256)/224+1) of clip rows y[c][0..n)
+// means (optional): segment means [c][T] already computed by launch_iir_f32
 hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
-                                  float *sxx, hipStream_t stream);
+                                  float *sxx, hipStream_t stream, const float *means = nullptr);
 
 struct ClassifyTrace {           // per clip, for parity tests
     int n_midpoints;
@@ -45,8 +50,10 @@ struct ClassifyTrace {           // per clip, for parity tests
 
 // labels[c] from the two spectrograms (band-pass 3000-7500 and 1000-3000), classifier.cpp:35-135.
 // Both sxx buffers are overwritten with their dB maps.  trace may be nullptr.
-hipError_t launch_classify_tail(float *sxx_bp, float *sxx_mp, long n_clips, int n, int fs, int *labels,
+hipError_t launch_classify_tail(float *sxx_bp, float *sxx_mp, long n_clips, int n, int fs, const SpecTables *tables, int *labels,
                                 ClassifyTrace *trace, hipStream_t stream);
+// fills tables->mp_keep_min (once per context)
+hipError_t launch_spec_threshold(SpecTables *tables, hipStream_t stream);
 
 void build_spec_tables(int fs, SpecTables &t);
 
