@@ -23,8 +23,9 @@ namespace dsp {
 // a9: direct form II, one lane per clip, time tiles transposed through LDS so HBM sees
 // coalesced 128-byte rows although each lane walks its own clip.
 // ---------------------------------------------------------------------------------
-constexpr int IIR_TS = 16;       // samples per tile: small tiles keep LDS per block low -> more resident waves to
-                                 // hide the serial recurrence's latency (measured 3x over 32-sample tiles at fp64)
+constexpr int IIR_TS = 32;       // samples per tile = one full 128-byte line per float row and tile (16-sample tiles
+                                 // fetch every line twice: measured memory-bound on BASELINE config 3)
+constexpr int IIR_BURST = 16;    // samples a lane carries in registers between its LDS reads and writes
 constexpr int IIR_LD = IIR_TS + 1;   // +1 word: lane l reads column i of row l -> banks (17 l + i) % 32 distinct
 
 template <typename T>
@@ -128,16 +129,19 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restri
             return o;
         };
         if (lane < rows && cols == IIR_TS) {
-            // full tile: the row goes LDS -> registers -> LDS in three bursts, so the LDS latency is paid once
-            // per 16 samples and not once per sample on top of the recurrence's own dependency chain
-            T xr[IIR_TS];
-            TIO orr[IIR_TS];
+            // full tile: the row goes LDS -> registers -> LDS in bursts, so the LDS latency is paid once per
+            // 16 samples and not once per sample on top of the recurrence's own dependency chain
 #pragma unroll
-            for (int i = 0; i < IIR_TS; ++i) xr[i] = (T)tin[lane * IIR_LD + i];
+            for (int h = 0; h < IIR_TS; h += IIR_BURST) {
+                T xr[IIR_BURST];
+                TIO orr[IIR_BURST];
 #pragma unroll
-            for (int i = 0; i < IIR_TS; ++i) orr[i] = sample(xr[i], t0 + i);
+                for (int i = 0; i < IIR_BURST; ++i) xr[i] = (T)tin[lane * IIR_LD + h + i];
 #pragma unroll
-            for (int i = 0; i < IIR_TS; ++i) to[lane * IIR_LD + i] = orr[i];
+                for (int i = 0; i < IIR_BURST; ++i) orr[i] = sample(xr[i], t0 + h + i);
+#pragma unroll
+                for (int i = 0; i < IIR_BURST; ++i) to[lane * IIR_LD + h + i] = orr[i];
+            }
         } else if (lane < rows) {
             for (int i = 0; i < cols; ++i) {
                 to[lane * IIR_LD + i] = sample((T)tin[lane * IIR_LD + i], t0 + i);
