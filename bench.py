@@ -119,6 +119,18 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         units, unit, bytes_per = n, "frames/s", FRAME * 2 + 52
         what = f"{n} x 512-sample int16 mono frames (PCM16 ingestion in the kernel's load, SURVEY 8f-1), otherwise configs[1]"
         kernel = "mfcc512_wave_kernel<IN=1>"
+    elif args.workload == "config5":
+        import numpy as np
+        from dsp_amd.scrubjay import ScrubJay
+        n = args.clips or 12_500
+        clips = torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1
+        attrs = dict(np.load(os.path.join(ROOT, "tests", "golden", "scrubjay_svm.npz")))
+        sj = ScrubJay(attrs, local)
+        step = lambda: sj(clips, 500)                          # noqa: E731
+        units, unit, bytes_per = n, "clips/s", 64_000 + 8      # label + probability out
+        what = (f"BASELINE configs[4] per-GPU share at {n} clips: 1 s 16 kHz fp32 clip -> MFCC(20) -> mean|std -> Scaler -> RBF-SVM "
+                "(scrubjay_svm.onnx attributes); three kernels, the [98][20] MFCC matrix goes through HBM")
+        kernel = "mfcc512_wave_kernel + mfcc_stats_kernel + svm_kernel"
     elif args.workload == "config3":
         n = args.clips or 1_000_000
         frames = torch.rand((n, 1024), device=dev, generator=gen) * 2 - 1
@@ -182,7 +194,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="all-gather the per-rank features every step (RCCL)")
-    ap.add_argument("--workload", choices=["frames", "clips", "classify", "config3", "pcm16"], default="frames",
+    ap.add_argument("--workload", choices=["frames", "clips", "classify", "config3", "config5", "pcm16"], default="frames",
                     help="frames = BASELINE configs[1] (the headline metric, default); clips = configs[3] per-GPU share "
                          "(12 500 x 1 s clips, reference framing 400/160); classify = the donut classifier on 1 s clips")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step for --workload clips / classify")

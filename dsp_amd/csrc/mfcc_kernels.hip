@@ -232,12 +232,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     auto flush = [&](int count) {
         wave_lds_sync();
         const int n = lane & 15, q = lane >> 4;
+        // reference shape: the tile column stays in registers between the max and the log passes; larger shapes
+        // (more k-steps or two coefficient tiles) re-read it from LDS in a rolled loop instead of spilling
         float ev[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) ev[s] = etile[64 * s + 16 * q + (n ^ s)];     // mel 4s+q of frame n
         unsigned mx = amin_u;
+        if (A_IN_REGS) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) mx = max(mx, __float_as_uint(ev[s]));
+            for (int s = 0; s < KS; ++s) ev[s] = etile[64 * s + 16 * q + (n ^ s)];     // mel 4s+q of frame n
+#pragma unroll
+            for (int s = 0; s < KS; ++s) mx = max(mx, __float_as_uint(ev[s]));
+        } else {
+#pragma unroll 2
+            for (int s = 0; s < KS; ++s) mx = max(mx, __float_as_uint(etile[64 * s + 16 * q + (n ^ s)]));
+        }
         {   // max over the four 16-lane rows (same frame, other mel residues)
             auto r = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
             mx = max(r[0], r[1]);
@@ -249,20 +256,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
         f4v acc[CT][2];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[ct][0] = acc[ct][1] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
-        float aop[CT][KS];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int s = 0; s < KS; ++s) aop[ct][s] = A_IN_REGS ? dcta[ct][s] : T->dct_a[ct][s][lane];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float ec = __uint_as_float(max(__float_as_uint(ev[s]), amin_u));
+        auto kstep = [&](int s, float e_s, int par) {
+            const float ec = __uint_as_float(max(__float_as_uint(e_s), amin_u));
             float db = k10 * __builtin_amdgcn_logf(ec * rinv);
             db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f);
             if (4 * s + q >= n_mels) db = 0.0f;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-                acc[ct][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[ct][s], db, acc[ct][s & 1], 0, 0, 0);
+            for (int ct = 0; ct < CT; ++ct) {
+                const float a = A_IN_REGS ? dcta[ct][s < KS ? s : 0] : T->dct_a[ct][s][lane];
+                acc[ct][par] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, db, acc[ct][par], 0, 0, 0);
+            }
+        };
+        if (A_IN_REGS) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) kstep(s, ev[s], s & 1);
+        } else {
+            static_assert(KS % 2 == 0, "two accumulator chains");
+#pragma unroll 1
+            for (int s = 0; s < KS; s += 2) {
+                kstep(s, etile[64 * s + 16 * q + (n ^ s)], 0);
+                kstep(s + 1, etile[64 * (s + 1) + 16 * q + (n ^ (s + 1))], 1);
+            }
         }
         const long fl = (n < 8 ? fb0 : fb1 - 8) + n;
         const bool ok = n < count && fl < n_frames;
