@@ -264,6 +264,36 @@ def test_config3_1024_point_128_mel_with_prefilter(dsp, torch_cuda):
                 assert not out[1].any()                       # silent frame stays exactly zero through the filter
 
 
+def test_config3_full_size_properties(dsp, torch_cuda):
+    """BASELINE config 3 at its full size: 10 M frames x 1024 fp32 (41 GB in HBM) through the float64 prefilter and the
+    1024-point chain.  Size-independent properties + an oracle spot check; skipped when the card lacks the memory."""
+    from oracle import oracle as O
+    torch = torch_cuda
+    n = 10_000_000
+    free, _total = torch.cuda.mem_get_info()
+    if free < 60 << 30:
+        pytest.skip("needs ~50 GB of free HBM")
+    over = dict(n_fft=1024, frame_length=1024, hop_length=1024, n_mels=128, prefilter=2)
+    plan = dsp.MfccPlan(dsp.default_config(**over))
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    x = torch.empty((n, 1024), device="cuda")
+    for c0 in range(0, n, 1_000_000):                              # generate in 4 GB pieces
+        x[c0:c0 + 1_000_000] = torch.rand((1_000_000, 1024), device="cuda", generator=gen) * 2 - 1
+    x[::100_003] = 0.0                                             # silent frames
+    x[7] = x[9_999_999]                                            # the same frame at both ends of the batch
+    out = plan.frames(x)
+    assert tuple(out.shape) == (n, 13) and bool(torch.isfinite(out).all())
+    assert not out[::100_003].any()
+    assert torch.equal(out[7], out[9_999_999])                     # position in the batch does not matter
+    assert torch.equal(plan.frames(x[5_000_000:5_000_512]), out[5_000_000:5_000_512])      # nor does the batch size
+    idx = torch.randint(0, n, (96,), device="cuda", generator=gen)
+    ref = O.mfcc_frames(x[idx].cpu().numpy(), O.default_cfg(**over), threads=8)
+    ok, worst = frame_linf_close(out[idx].cpu().numpy(), ref, RTOL, ATOL_DB)
+    assert ok, worst
+    del x, out
+    torch.cuda.empty_cache()
+
+
 def test_1024_point_clip_framing_and_other_shapes(dsp, torch_cuda):
     from oracle import oracle as O
     torch = torch_cuda

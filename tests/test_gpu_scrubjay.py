@@ -70,3 +70,37 @@ def test_clip_to_label_pipeline(golden):
         assert abs(dec[i].item() - odec) <= 2e-5 * max(1.0, abs(odec)) and abs(p1[i].item() - op1) <= 2e-5
         if abs(op1 - 0.5) > 1e-4:
             assert labels[i].item() == lab
+
+
+def test_config5_at_scale(golden):
+    """BASELINE config 5 at 100 000 clips (6.4 GB of PCM in HBM; the full 1 M is ten such batches): properties that
+    need no oracle pass + the oracle chain on a few clips."""
+    import torch
+    from dsp_amd import scrubjay
+    from oracle import oracle as O
+    free, _total = torch.cuda.mem_get_info()
+    if free < 12 << 30:
+        pytest.skip("needs ~10 GB of free HBM")
+    m = golden("scrubjay_svm.npz")
+    sj = scrubjay.ScrubJay({k: m[k] for k in m.files})
+    n = 100_000
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    clips = torch.rand((n, 16000), device="cuda", generator=gen) * 2 - 1
+    clips[::7] *= 0.001                                            # quiet clips
+    clips[::1009, 4000:] = 0.0                                     # clips that fall silent
+    labels, dec, p1, feat = sj(clips)
+    assert tuple(feat.shape) == (n, 40) and bool(torch.isfinite(feat).all()) and bool(torch.isfinite(p1).all())
+    assert bool(((p1 >= 0) & (p1 <= 1)).all())
+    l2, d2, q2, f2 = sj(clips)
+    assert torch.equal(labels, l2) and torch.equal(dec, d2) and torch.equal(feat, f2)          # deterministic
+    perm = torch.randperm(n, device="cuda", generator=gen)
+    l3, d3, q3, f3 = sj(clips[perm].contiguous())
+    assert torch.equal(f3, feat[perm]) and torch.equal(d3, dec[perm]) and torch.equal(l3, labels[perm])
+    ocfg = O.default_cfg(n_mfcc=20)
+    for i in (0, 7, 1009, 99_999):
+        of = O.mfcc_stats(O.compute_mfcc(clips[i].cpu().numpy(), 1 << 20, ocfg))
+        lab, odec, op1 = O.svm_predict(_model(m), feat[i].cpu().numpy())                      # SVM on the GPU's own features
+        assert np.abs(feat[i].cpu().numpy() - of).max() <= 1e-4 * np.abs(of).max() + 3e-4
+        assert abs(float(dec[i]) - odec) <= 2e-5 * max(1.0, abs(odec)) and abs(float(p1[i]) - op1) <= 2e-5
+        if abs(op1 - 0.5) > 1e-4:
+            assert int(labels[i]) == lab
