@@ -93,3 +93,34 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"
+
+
+def _stop_params(golden_dir, **over):
+    m = dict(np.load(os.path.join(golden_dir, "stop_model.npz")))
+    m.update(over)
+    return m
+
+
+def test_consumer_models_reject_bad_parameters_and_fail_loudly_without_a_gpu():
+    import torch
+    gd = os.path.join(ROOT, "tests", "golden")
+    m = _stop_params(gd)
+    with pytest.raises(dsp_amd.DspError, match="n_coef"):                     # scaler length does not match the shape
+        dsp_amd.StopModel(dict(m, max_frames=400))
+    with pytest.raises(dsp_amd.DspError, match="kernel1"):
+        dsp_amd.StopModel(dict(m, kernel1=np.zeros(7, np.float32)))
+    wide = dict(m, bias0=np.zeros(17, np.float32), kernel0=np.zeros(6500 * 17, np.float32), kernel1=np.zeros(17 * 2, np.float32))
+    with pytest.raises(dsp_amd.DspError, match="1..16 units"):                # the C ABI's own check
+        dsp_amd.StopModel(wide)
+    s = np.load(os.path.join(gd, "speaker_gmm_ref.npz"))
+    t = {k: s[f"target_{k}"] for k in ("means", "inv_covs", "log_consts")}
+    u = {k: s[f"ubm_{k}"] for k in ("means", "inv_covs", "log_consts")}
+    with pytest.raises(dsp_amd.DspError, match="same shape"):
+        dsp_amd.SpeakerModel(t, dict(u, means=u["means"][:16], inv_covs=u["inv_covs"][:16], log_consts=u["log_consts"][:16]))
+    with pytest.raises(dsp_amd.DspError, match="new_size"):
+        dsp_amd.upsample_linear(np.zeros(8, np.float32), 1)
+    if not torch.cuda.is_available():
+        for make in (lambda: dsp_amd.StopModel(m), lambda: dsp_amd.SpeakerModel(t, u),
+                     lambda: dsp_amd.upsample_linear(np.zeros(8, np.float32), 16)):
+            with pytest.raises(dsp_amd.DspError, match="no HIP device"):
+                make()
