@@ -171,12 +171,176 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------
+// a9 for classify(): both band-pass filters of a clip batch with the recurrence and the output
+// taps on DIFFERENT wavefronts.  Direct form II is v[n] = x[n] - sum a[j] v[n-j] (serial) followed
+// by y[n] = b0 v[n] + sum b[j] v[n-j] (an FIR over v, no feedback).  With a few thousand clips the
+// lane-per-clip kernel is bound by one wavefront's issue latency (~7 cycles per dependent VALU
+// instruction), so halving the instructions each wavefront executes per sample nearly halves the
+// time: waves 0/1 run the recurrences of filter 1/2 and hand v tiles over through LDS, waves 2/3
+// run the taps one tile behind, keep the spectrogram's segment sums and store y.  Every sample
+// sees exactly the reference's operations in the reference's order (classifier.cpp:199-216).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict__ x, long n_clips, int n, long stride,
+                                                         const IirCoef c1, float *__restrict__ y1, const IirCoef c2, float *__restrict__ y2,
+                                                         float *__restrict__ means1, float *__restrict__ means2)
+{
+    __shared__ float tin[2][64 * IIR_LD];
+    __shared__ float vbuf[2][2][64 * IIR_LD];          // [filter][tile parity]
+    __shared__ float ytile[2][64 * IIR_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = wv & 1;                               // filter
+    const bool is_r = wv < 2;                           // recurrence wave (else: taps wave)
+    const IirCoef c = f ? c2 : c1;
+    float *__restrict__ y = f ? y2 : y1;
+    float *__restrict__ means = f ? means2 : means1;
+    const long clip0 = (long)blockIdx.x * 64;
+    const int rows = (int)((n_clips - clip0) < 64 ? (n_clips - clip0) : 64);
+    const int n_tiles = (n + IIR_TS - 1) / IIR_TS;
+    const int n_seg = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
+    float d[8];                                         // v[n-1] .. v[n-8] of this lane's clip
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = 0.0f;
+    float cur = 0.0f, prev = 0.0f;                      // taps waves: running sums of the current / previous segment
+
+    // x tiles: the 128 recurrence threads load them (4 float4 each per full tile), one tile ahead in registers
+    constexpr int CH = IIR_TS / 4, NV = 64 * CH / 128;
+    float4 pre[NV];
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * 4;
+            pre[k] = r < rows ? *reinterpret_cast<const float4 *>(x + (clip0 + r) * stride + t0 + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](float *dst) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * 4;
+            dst[r * IIR_LD + cc] = pre[k].x; dst[r * IIR_LD + cc + 1] = pre[k].y;
+            dst[r * IIR_LD + cc + 2] = pre[k].z; dst[r * IIR_LD + cc + 3] = pre[k].w;
+        }
+    };
+    auto load_partial = [&](int t0, int cols, float *dst) {       // last, short tile: element-wise
+        for (int e = tid; e < 64 * IIR_TS; e += 128) {
+            const int r = e / IIR_TS, ci = e % IIR_TS;
+            dst[r * IIR_LD + ci] = (r < rows && ci < cols) ? x[(clip0 + r) * stride + t0 + ci] : 0.0f;
+        }
+    };
+    auto tile_cols = [&](int s) { const int t0 = s * IIR_TS; return n - t0 < IIR_TS ? n - t0 : IIR_TS; };
+    if (is_r) {                                                    // tile 0 into tin[0], tile 1 in flight
+        if (tile_cols(0) == IIR_TS) { issue(0); commit(tin[0]); } else load_partial(0, tile_cols(0), tin[0]);
+        if (n_tiles > 1 && tile_cols(1) == IIR_TS) issue(IIR_TS);
+    }
+    __syncthreads();
+
+    for (int s = 0; s <= n_tiles; ++s) {
+        if (is_r) {
+            if (s < n_tiles) {
+                // stage x tile s+1 for the next step, start the loads of tile s+2
+                if (s + 1 < n_tiles) {
+                    if (tile_cols(s + 1) == IIR_TS) commit(tin[(s + 1) & 1]); else load_partial((s + 1) * IIR_TS, tile_cols(s + 1), tin[(s + 1) & 1]);
+                    if (s + 2 < n_tiles && tile_cols(s + 2) == IIR_TS) issue((s + 2) * IIR_TS);
+                }
+                const float *xin = tin[s & 1];
+                float *vo = vbuf[f][s & 1];
+                const int cols = tile_cols(s);
+                auto rec = [&](float xv) {                           // classifier.cpp:199-205
+                    float v = xv;
+#pragma unroll
+                    for (int j = 1; j <= 8; ++j) v = v - c.a[j] * d[j - 1];
+#pragma unroll
+                    for (int j = 7; j > 0; --j) d[j] = d[j - 1];
+                    d[0] = v;
+                    return v;
+                };
+                if (lane < rows && cols == IIR_TS) {
+#pragma unroll
+                    for (int h = 0; h < IIR_TS; h += IIR_BURST) {
+                        float xr[IIR_BURST], vr[IIR_BURST];
+#pragma unroll
+                        for (int i = 0; i < IIR_BURST; ++i) xr[i] = xin[lane * IIR_LD + h + i];
+#pragma unroll
+                        for (int i = 0; i < IIR_BURST; ++i) vr[i] = rec(xr[i]);
+#pragma unroll
+                        for (int i = 0; i < IIR_BURST; ++i) vo[lane * IIR_LD + h + i] = vr[i];
+                    }
+                } else if (lane < rows) {
+                    for (int i = 0; i < cols; ++i) vo[lane * IIR_LD + i] = rec(xin[lane * IIR_LD + i]);
+                }
+            }
+        } else if (s >= 1) {
+            const int t0 = (s - 1) * IIR_TS, cols = tile_cols(s - 1);
+            const float *vin = vbuf[f][(s - 1) & 1];
+            float *yo = ytile[f];
+            auto taps = [&](float v, int sidx) {                     // classifier.cpp:207-216, then the segment sums
+                float o = c.b[0] * v;
+#pragma unroll
+                for (int j = 1; j <= 8; ++j) o = o + c.b[j] * d[j - 1];
+#pragma unroll
+                for (int j = 7; j > 0; --j) d[j] = d[j - 1];
+                d[0] = v;
+                if (means) {
+                    const int k = sidx / kSpecHop, pos = sidx - k * kSpecHop;
+                    if (pos == 0) { prev = cur; cur = 0.0f; }
+                    cur = cur + o;
+                    if (pos < kSpecSeg - kSpecHop && k >= 1) {
+                        prev = prev + o;
+                        if (pos == kSpecSeg - kSpecHop - 1 && k - 1 < n_seg) means[(clip0 + lane) * n_seg + k - 1] = prev / (float)kSpecSeg;
+                    }
+                }
+                return o;
+            };
+            if (lane < rows && cols == IIR_TS) {
+#pragma unroll
+                for (int h = 0; h < IIR_TS; h += IIR_BURST) {
+                    float vr[IIR_BURST], orr[IIR_BURST];
+#pragma unroll
+                    for (int i = 0; i < IIR_BURST; ++i) vr[i] = vin[lane * IIR_LD + h + i];
+#pragma unroll
+                    for (int i = 0; i < IIR_BURST; ++i) orr[i] = taps(vr[i], t0 + h + i);
+#pragma unroll
+                    for (int i = 0; i < IIR_BURST; ++i) yo[lane * IIR_LD + h + i] = orr[i];
+                }
+            } else if (lane < rows) {
+                for (int i = 0; i < cols; ++i) yo[lane * IIR_LD + i] = taps(vin[lane * IIR_LD + i], t0 + i);
+            }
+            // this wave's own tile: wave-level ordering is enough before the coalesced store
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (cols == IIR_TS) {
+                for (int e = lane; e < 64 * CH; e += 64) {
+                    const int r = e / CH, cc = (e % CH) * 4;
+                    if (r < rows)
+                        *reinterpret_cast<float4 *>(y + (clip0 + r) * stride + t0 + cc) =
+                            make_float4(yo[r * IIR_LD + cc], yo[r * IIR_LD + cc + 1], yo[r * IIR_LD + cc + 2], yo[r * IIR_LD + cc + 3]);
+                }
+            } else {
+                for (int e = lane; e < 64 * IIR_TS; e += 64) {
+                    const int r = e / IIR_TS, ci = e % IIR_TS;
+                    if (r < rows && ci < cols) y[(clip0 + r) * stride + t0 + ci] = yo[r * IIR_LD + ci];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        __syncthreads();
+    }
+}
+
 hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, const IirCoef &c1, float *y1,
                           const IirCoef &c2, float *y2, hipStream_t stream, float *means1, float *means2)
 {
     if (n_clips <= 0 || n <= 0) return hipSuccess;
     const int blocks = (int)((n_clips + 63) / 64);
-    if (y2 && means1 && means2)
+    const bool aligned = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y1) % 16 == 0 &&
+                         reinterpret_cast<uintptr_t>(y2) % 16 == 0;
+    if (y2 && aligned)       // classify(): recurrence / taps split over four wavefronts (means1 / means2 may be nullptr)
+        hipLaunchKernelGGL(iir2_split_kernel, dim3(blocks), dim3(256), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2, means1, means2);
+    else if (y2 && means1 && means2)
         hipLaunchKernelGGL((iir_kernel<float, IirCoef, true, float, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2,
                            means1, means2);
     else if (y2) hipLaunchKernelGGL((iir_kernel<float, IirCoef, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2, nullptr, nullptr);
@@ -415,6 +579,45 @@ __device__ float sum_intense_dev(float lower, float upper, float half_range, int
     return total;
 }
 
+// sum_intense for a whole wavefront: the cells are fetched 64 at a time in the reference's (row, column) order, then
+// added ONE BY ONE in that order (v_readlane + add: the float sum's order is part of the result).  NaN cells add 0.0f,
+// which leaves a float sum unchanged bit for bit, exactly like the reference's skip.  Returns the same value in every lane.
+__device__ float sum_intense_wave(float lower, float upper, float half_range, int fs, int T, const float *db, float midpoint)
+{
+    auto freq = [&](int k) { return (float)k * (float)fs / (float)kSpecSeg; };
+    auto time = [&](int t) { return ((float)(t * kSpecHop + kSpecSeg / 2)) / (float)fs; };
+    int f0 = 0;
+    while (f0 < kSpecBins && freq(f0) < lower) ++f0;
+    int f1 = kSpecBins - 1;
+    while (f1 >= 0 && freq(f1) > upper) --f1;
+    if (f0 >= kSpecBins) f0 = kSpecBins - 1;
+    if (f1 < 0) f1 = 0;
+    if (f0 > f1) { int x = f0; f0 = f1; f1 = x; }
+    int t0 = 0;
+    while (t0 < T && time(t0) < midpoint - half_range) ++t0;
+    int t1 = T - 1;
+    while (t1 >= 0 && time(t1) > midpoint + half_range) --t1;
+    if (t0 >= T) t0 = T - 1;
+    if (t1 < 0) t1 = 0;
+    if (t0 > t1) { int x = t0; t0 = t1; t1 = x; }
+    const int lane = threadIdx.x & 63;
+    const int W = t1 - t0 + 1, N = (f1 - f0 + 1) * W;
+    float total = 0.0f;
+    for (int e0 = 0; e0 < N; e0 += 64) {
+        const int e = e0 + lane;
+        float v = 0.0f;
+        if (e < N) {
+            const int r = e / W, cidx = e - r * W;
+            v = db[(long)(f0 + r) * T + t0 + cidx];
+            if (isnan(v)) v = 0.0f;
+        }
+        // lanes past the end hold 0.0f: adding them changes nothing, so every chunk is a straight line of 64 adds
+#pragma unroll
+        for (int l = 0; l < 64; ++l) total = total + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    }
+    return total;
+}
+
 // One 256-thread block per clip.  The band-pass dB map lives in LDS when it fits (129 x T <= kTailLdsCells,
 // always for 1 s clips), so the order-dependent sums of thread 0 read LDS instead of HBM.  The midpoint map
 // is never formed: "10 log10(s / 1e-12) > 70 dB" is monotone in s, so its pass compares s with the smallest
@@ -439,8 +642,13 @@ hipError_t launch_spec_threshold(SpecTables *tables, hipStream_t stream)
     return hipGetLastError();
 }
 
+// USE_LDS: the map fits the LDS budget (129 x T <= kTailLdsCells): the PSD cells of the clip are read ONCE into
+// registers (kTailPerThread per thread) and the map is written to LDS; otherwise the map is rebuilt in place in HBM.
+constexpr int kTailPerThread = (kTailLdsCells + 255) / 256;
+
+template <bool USE_LDS>
 __global__ __launch_bounds__(256) void classify_tail_kernel(float *__restrict__ sxx_bp, const float *__restrict__ sxx_mp,
-                                                            long n_clips, int T, int fs, int use_lds, const SpecTables *__restrict__ tab,
+                                                            long n_clips, int T, int fs, const SpecTables *__restrict__ tab,
                                                             int *__restrict__ labels, ClassifyTrace *__restrict__ trace)
 {
     extern __shared__ float map_lds[];
@@ -453,38 +661,12 @@ __global__ __launch_bounds__(256) void classify_tail_kernel(float *__restrict__ 
     const int cells = kSpecBins * T;
     float *bp_g = sxx_bp + clip * (long)cells;
     const float *mp = sxx_mp + clip * (long)cells;
-    float *bp = use_lds ? map_lds : bp_g;
+    __shared__ float mids[kMaxMidpoints];
+    __shared__ int n_mids;
     for (int j = tid; j < T; j += 256) col_any[j] = 0;
-
-    // ---- band-pass map: dB, clip min/max, normalise, keep (0.65, 0.80)  classifier.cpp:35-80
-    float mn = INFINITY, mx = -INFINITY;   // the reference starts from +-DBL_MAX stored in floats = +-inf
-    for (int i = tid; i < cells; i += 256) {
-        float v = bp_g[i];
-        if (v > 0) {
-            v = to_db(v);
-            mn = fminf(mn, v);
-            mx = fmaxf(mx, v);
-        } else {
-            v = NAN;
-        }
-        bp[i] = v;
-    }
-    mn = wave_min(mn);
-    mx = wave_maxf(mx);
-    if ((tid & 63) == 0) { red_mn[tid >> 6] = mn; red_mx[tid >> 6] = mx; }
     __syncthreads();
-    mn = fminf(fminf(red_mn[0], red_mn[1]), fminf(red_mn[2], red_mn[3]));       // min / max are order-independent
-    mx = fmaxf(fmaxf(red_mx[0], red_mx[1]), fmaxf(red_mx[2], red_mx[3]));
-    const float lo_thr = 0.65f, hi_thr = 0.80f;
-    for (int i = tid; i < cells; i += 256) {
-        float v = bp[i];
-        if (!isnan(v)) {
-            v = (v - mn) / (mx - mn);
-            v = (v > lo_thr && v < hi_thr) ? v : NAN;
-            bp[i] = v;
-        }
-    }
-    // ---- midpoint map: keep > 70 dB, time bins with any cell   classifier.cpp:457-518
+
+    // ---- midpoint map first: keep > 70 dB, time bins with any cell   classifier.cpp:457-518
     {
         const float keep_min = tab->mp_keep_min;
         int col = tid % T;
@@ -502,36 +684,98 @@ __global__ __launch_bounds__(256) void classify_tail_kernel(float *__restrict__ 
             if (col_any[j]) blob[nb++] = ((float)(j * kSpecHop + kSpecSeg / 2)) / (float)fs;
         // greedy clustering, classifier.cpp:522-574
         const float tol = 0.05f, min_dur = 0.15f;
-        float mids[kMaxMidpoints];
         int count = 0, i0 = 0;
         while (i0 < nb) {
             int i1 = i0;
             while (i1 + 1 < nb && (blob[i1 + 1] - blob[i1]) <= tol) ++i1;
             const float dur = blob[i1] - blob[i0];
             if (dur >= min_dur) {
-                float s = 0.0f;
-                for (int k = i0; k <= i1; ++k) s = s + blob[k];
-                if (count < kMaxMidpoints) mids[count] = s / (float)(i1 - i0 + 1);
+                float sm = 0.0f;
+                for (int k = i0; k <= i1; ++k) sm = sm + blob[k];
+                if (count < kMaxMidpoints) mids[count] = sm / (float)(i1 - i0 + 1);
                 ++count;
             }
             i0 = i1 + 1;
         }
         if (count > kMaxMidpoints) count = kMaxMidpoints;
-        // classifier.cpp:93-114
-        int hit = 0;
+        n_mids = count;
         if (trace) trace[clip].n_midpoints = count;
-        for (int k = 0; k < count; ++k) {
-            const float above = sum_intense_dev(5000, 7000, 0.18f, fs, T, bp, mids[k]);
-            const float middle = sum_intense_dev(2500, 5000, 0.05f, fs, T, bp, mids[k]);
-            const float below = sum_intense_dev(500, 2500, 0.18f, fs, T, bp, mids[k]);
-            if (trace) {
-                trace[clip].midpoints[k] = mids[k];
-                trace[clip].sums[k][0] = above; trace[clip].sums[k][1] = middle; trace[clip].sums[k][2] = below;
-            }
-            if (middle < 100 && above > 200 && below > 80) { hit = 1; break; }
-        }
-        labels[clip] = hit;
+        if (count == 0) labels[clip] = 0;                   // classifier.cpp:93-114: no midpoint can fire the rule
     }
+    __syncthreads();
+    // no midpoints: the band-pass dB map would never be read (the reference builds it anyway; the label and the trace
+    // are the same), so the block stops here -- the whole map pass below is paid only by clips that have midpoints
+    if (n_mids == 0) return;
+
+    // ---- band-pass map: dB, clip min/max, normalise, keep (0.65, 0.80)  classifier.cpp:35-80
+    // to_db is monotone in the PSD value s, so the clip's dB minimum / maximum are to_db of the smallest / largest
+    // positive s (two float64 log10 instead of one per cell), and only cells whose s lies in the (0.65, 0.80) band
+    // widened by a safety margin can survive the reference's test: those get the exact dB value and the reference's
+    // own float comparison, all others are NaN in the reference as well.
+    float smn = INFINITY, smx = -INFINITY;
+    float cell[USE_LDS ? kTailPerThread : 1];
+    if (USE_LDS) {
+#pragma unroll
+        for (int k = 0; k < kTailPerThread; ++k) cell[k] = tid + 256 * k < cells ? bp_g[tid + 256 * k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < kTailPerThread; ++k)
+            if (cell[k] > 0) { smn = fminf(smn, cell[k]); smx = fmaxf(smx, cell[k]); }
+    } else {
+        for (int i = tid; i < cells; i += 256) {
+            const float sv = bp_g[i];
+            if (sv > 0) { smn = fminf(smn, sv); smx = fmaxf(smx, sv); }
+        }
+    }
+    smn = wave_min(smn);
+    smx = wave_maxf(smx);
+    if ((tid & 63) == 0) { red_mn[tid >> 6] = smn; red_mx[tid >> 6] = smx; }
+    __syncthreads();
+    smn = fminf(fminf(red_mn[0], red_mn[1]), fminf(red_mn[2], red_mn[3]));      // min / max are order-independent
+    smx = fmaxf(fmaxf(red_mx[0], red_mx[1]), fmaxf(red_mx[2], red_mx[3]));
+    // the reference starts its running min / max from +-DBL_MAX stored in floats = +-inf
+    const float mn = smn <= smx ? to_db(smn) : INFINITY, mx = smn <= smx ? to_db(smx) : -INFINITY;
+    const float lo_thr = 0.65f, hi_thr = 0.80f;
+    const double range = (double)mx - (double)mn, slack = 1e-4 * range + 1e-4;       // dB; float rounding of v is ~1e-6 range
+    const float s_lo = (float)(1e-12 * pow(10.0, ((double)mn + 0.65 * range - slack) / 10.0) * (1.0 - 1e-6));
+    const float s_hi = (float)(1e-12 * pow(10.0, ((double)mn + 0.80 * range + slack) / 10.0) * (1.0 + 1e-6));
+    auto keep = [&](float sv) {
+        float v = NAN;
+        if (sv >= s_lo && sv <= s_hi) {                 // (false for s <= 0 and NaN)
+            v = (to_db(sv) - mn) / (mx - mn);
+            v = (v > lo_thr && v < hi_thr) ? v : NAN;
+        }
+        return v;
+    };
+    if (USE_LDS) {
+#pragma unroll
+        for (int k = 0; k < kTailPerThread; ++k)
+            if (tid + 256 * k < cells) map_lds[tid + 256 * k] = keep(cell[k]);
+    } else {
+        for (int i = tid; i < cells; i += 256) bp_g[i] = keep(bp_g[i]);
+    }
+    const float *bp = USE_LDS ? map_lds : bp_g;
+    __syncthreads();
+    // classifier.cpp:93-114: per midpoint the three band sums, one wavefront each (the fourth idles), then the rule
+    __shared__ float band[3];
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int count = n_mids;
+    int hit = 0;
+    for (int k = 0; k < count; ++k) {
+        const float mid = mids[k];
+        if (wv == 0) { const float v = sum_intense_wave(5000, 7000, 0.18f, fs, T, bp, mid); if ((tid & 63) == 0) band[0] = v; }
+        if (wv == 1) { const float v = sum_intense_wave(2500, 5000, 0.05f, fs, T, bp, mid); if ((tid & 63) == 0) band[1] = v; }
+        if (wv == 2) { const float v = sum_intense_wave(500, 2500, 0.18f, fs, T, bp, mid); if ((tid & 63) == 0) band[2] = v; }
+        __syncthreads();
+        const float above = band[0], middle = band[1], below = band[2];
+        if (tid == 0 && trace) {
+            trace[clip].midpoints[k] = mid;
+            trace[clip].sums[k][0] = above; trace[clip].sums[k][1] = middle; trace[clip].sums[k][2] = below;
+        }
+        hit = (middle < 100 && above > 200 && below > 80) ? 1 : 0;
+        __syncthreads();
+        if (hit) break;                                      // uniform: every thread read the same three sums
+    }
+    if (tid == 0) labels[clip] = hit;
 }
 
 hipError_t launch_classify_tail(float *sxx_bp, float *sxx_mp, long n_clips, int n, int fs, const SpecTables *tables, int *labels,
@@ -540,10 +784,12 @@ hipError_t launch_classify_tail(float *sxx_bp, float *sxx_mp, long n_clips, int 
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0) return hipSuccess;
     if (T <= 0 || T > 1024) return hipErrorInvalidValue;
-    const int use_lds = kSpecBins * T <= kTailLdsCells;
-    const size_t lds = use_lds ? (size_t)kSpecBins * T * sizeof(float) : 0;
-    hipLaunchKernelGGL(classify_tail_kernel, dim3((unsigned)n_clips), dim3(256), lds, stream, sxx_bp, sxx_mp, n_clips, T, fs, use_lds, tables,
-                       labels, trace);
+    if (kSpecBins * T <= kTailLdsCells)
+        hipLaunchKernelGGL(classify_tail_kernel<true>, dim3((unsigned)n_clips), dim3(256), (size_t)kSpecBins * T * sizeof(float), stream, sxx_bp,
+                           sxx_mp, n_clips, T, fs, tables, labels, trace);
+    else
+        hipLaunchKernelGGL(classify_tail_kernel<false>, dim3((unsigned)n_clips), dim3(256), 0, stream, sxx_bp, sxx_mp, n_clips, T, fs, tables,
+                           labels, trace);
     return hipGetLastError();
 }
 
