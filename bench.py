@@ -122,15 +122,15 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
     elif args.workload == "config5":
         import numpy as np
         from dsp_amd.scrubjay import ScrubJay
-        n = args.clips or 12_500
+        n = args.clips or 125_000                              # 1 M clips over 8 GPUs
         clips = torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1
         attrs = dict(np.load(os.path.join(ROOT, "tests", "golden", "scrubjay_svm.npz")))
         sj = ScrubJay(attrs, local)
-        step = lambda: sj(clips, 500)                          # noqa: E731
+        step = lambda: sj(clips, 500, fused=True)              # noqa: E731
         units, unit, bytes_per = n, "clips/s", 64_000 + 8      # label + probability out
-        what = (f"BASELINE configs[4] per-GPU share at {n} clips: 1 s 16 kHz fp32 clip -> MFCC(20) -> mean|std -> Scaler -> RBF-SVM "
-                "(scrubjay_svm.onnx attributes); three kernels, the [98][20] MFCC matrix goes through HBM")
-        kernel = "mfcc512_wave_kernel + mfcc_stats_kernel + svm_kernel"
+        what = (f"BASELINE configs[4] per-GPU share ({n} clips): 1 s 16 kHz fp32 clip -> MFCC(20) -> mean|std -> Scaler -> RBF-SVM "
+                "(scrubjay_svm.onnx attributes) fused in ONE kernel, one wavefront per clip; the MFCC matrix never reaches HBM")
+        kernel = "mfcc512_wave_kernel<POOL>"
     elif args.workload == "config3":
         n = args.clips or 1_000_000
         frames = torch.rand((n, 1024), device=dev, generator=gen) * 2 - 1

@@ -727,6 +727,47 @@ void dsp_svm_destroy(dsp_svm *s)
     delete s;
 }
 
+int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signal, long n_clips, int samples_per_clip,
+                              long clip_stride, int max_frames, int *d_labels, float *d_decision, float *d_prob1, float *d_feat,
+                              void *stream)
+{
+    if (!p || !s || n_clips < 0) return fail(DSP_EINVAL, "bad argument");
+    if (p->cfg.n_fft != 512 || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX || p->cfg.prefilter != DSP_PREFILTER_NONE || p->kernel != DSP_KERNEL_WAVE)
+        return fail(DSP_EINVAL, "the fused clip -> label path runs on the 512-point wave-per-frame kernel, per-frame log mode");
+    if (s->m.n_features != 2 * p->cfg.n_mfcc || s->m.n_features > 64) return fail(DSP_EINVAL, "SVM n_features must equal 2 * n_mfcc (<= 64)");
+    const int t = dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
+    if (n_clips == 0) return 0;
+    if (t == 0) return fail(DSP_EINVAL, "clips shorter than one frame have no features to pool");
+    if (!d_signal || !d_labels) return fail(DSP_EINVAL, "NULL buffer");
+    if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
+    if ((reinterpret_cast<uintptr_t>(d_signal) & 7) || (n_clips > 1 && (clip_stride & 1))) return fail(DSP_EINVAL, "input must be 8-byte aligned with an even clip stride");
+    dsp::Mfcc512Args a{};
+    a.in = d_signal;
+    a.in_kind = 0;
+    a.out = nullptr;
+    a.tables = p->d_tables;
+    a.n_frames = n_clips * (long)t;
+    a.clip_stride = clip_stride;
+    a.frames_per_clip = t;
+    a.hop = p->cfg.hop_length;
+    a.frame_len = p->cfg.frame_length;
+    a.chunk = t;                                  // one wavefront walks one clip
+    a.n_mels = p->cfg.n_mels;
+    a.n_mfcc = p->cfg.n_mfcc;
+    a.amin = p->cfg.amin;
+    a.top_db = p->cfg.top_db;
+    a.log_mode = 0;
+    a.pool.svm = s->m;
+    a.pool.labels = d_labels;
+    a.pool.decision = d_decision;
+    a.pool.prob1 = d_prob1;
+    a.pool.feat = d_feat;
+    const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks;
+    long blocks = std::max(1L, std::min((long)p->n_cu * per_cu, (n_clips + 3) / 4));
+    DSP_HIP(dsp::launch_mfcc512_pool(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+    return t;
+}
+
 int dsp_svm_predict_device(dsp_svm *s, const float *d_feat, long n_clips, int *d_labels, float *d_decision,
                            float *d_prob1, void *stream)
 {

@@ -117,9 +117,15 @@ __device__ __forceinline__ void load_frame(const void *__restrict__ base, long o
 // with the log-mels as B straight from registers.  The MFMA pipe is otherwise idle; this is
 // not a reshaping of the chain into a GEMM but the one dense 13x40 product it already contains.
 // Saves ~45 of ~225 VALU issue slots and 10 LDS dwords per frame.
-template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL, int IN, int TILE, bool CLIPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void mfcc512_wave_kernel(const Mfcc512Args args)
+// POOL (TILE, CLIPS, chunk = frames per clip: one wavefront walks one clip): instead of storing the coefficients the
+// tile epilogue pools them per clip and the clip ends with the SVM (PoolSvmArgs) -- BASELINE config 5 in one kernel.
+template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL, int IN, int TILE, bool CLIPS, bool POOL = false>
+#ifndef DSP_WAVES_PER_EU
+#define DSP_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_PER_EU))) void mfcc512_wave_kernel(const Mfcc512Args args)
 {
+    static_assert(!POOL || (TILE && CLIPS), "pooling lives in the tile epilogue of the clip-mode kernel");
     constexpr int KS = DCT_SPLIT == 2 ? DCT_LEN / 2 : DCT_LEN;    // MFMA k-steps (4 mel filters each)
     constexpr int CT = DCT_SPLIT == 2 ? 2 : 1;                    // 16-coefficient output tiles
     constexpr int WAVE_BYTES = LDS_WAVE_BYTES + (TILE ? LDS_TILE_BYTES : 0);
@@ -213,18 +219,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
     pre.init(wave, n_waves, args.chunk, n_frames, args.frames_per_clip, CLIPS ? args.hop : frame_len, args.clip_stride);
     c32 ring[DSP_PREFETCH][4] = {};
     long fq[DSP_PREFETCH], cq[DSP_PREFETCH];
+    bool lastq[DSP_PREFETCH];           // POOL: the frame closes its chunk (= its clip)
     auto refill = [&](int d) {
         if (pre.valid()) {
             load_frame<FULL, IN>(args.in, pre.off, lane, frame_len, ring[d]);
-            fq[d] = pre.f; cq[d] = pre.clip;
+            fq[d] = pre.f; cq[d] = pre.clip; lastq[d] = pre.left == 0 || pre.remaining == 1;
             pre.next();
         } else {
-            fq[d] = -1; cq[d] = 0;
+            fq[d] = -1; cq[d] = 0; lastq[d] = false;
         }
     };
 #pragma unroll
     for (int d = 0; d < DSP_PREFETCH; ++d) refill(d);
     if (fq[0] < 0) return;
+
+    // ---- POOL: per-clip running sums of lane c's coefficient (float64, frames in order), the clip's end -------------
+    double pool_s = 0.0, pool_q = 0.0;
+    int pool_t = 0;
+    auto pool_tile = [&](const f4v (&d)[CT], int count) {
+        // coefficients of the tile -> LDS as Dt[c][n] (the mel-energy tile has been consumed), then lane c adds its
+        // row frame by frame: the same order of float64 additions as mfcc_stats (svm_kernels.hip / scrubjay_infer.c:36-66)
+        const int n = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) etile[(16 * ct + 4 * q + j) * 16 + n] = d[ct][j];
+        wave_lds_sync();
+        if (lane < n_mfcc) {
+#pragma clang fp contract(off)
+            for (int t = 0; t < count; ++t) {
+                const double v = (double)etile[lane * 16 + t];
+                pool_s = pool_s + v;
+                pool_q = pool_q + v * v;
+            }
+        }
+        pool_t += count;
+        wave_lds_sync();
+    };
+    auto pool_finish = [&](long clip) {
+#pragma clang fp contract(off)
+        const SvmModelDev &m = args.pool.svm;
+        float *z = etile;                                    // 2 * n_mfcc standardised features
+        if (lane < n_mfcc) {
+            const double mean = pool_s / (double)pool_t;
+            const double var = pool_q / (double)pool_t - mean * mean;
+            const float f_mean = (float)mean, f_std = sqrtf((float)(var > 0 ? var : 0));
+            if (args.pool.feat) {
+                args.pool.feat[clip * 2L * n_mfcc + lane] = f_mean;
+                args.pool.feat[clip * 2L * n_mfcc + n_mfcc + lane] = f_std;
+            }
+            z[lane] = (f_mean - m.offset[lane]) * m.scale[lane];
+            z[n_mfcc + lane] = (f_std - m.offset[n_mfcc + lane]) * m.scale[n_mfcc + lane];
+        }
+        wave_lds_sync();
+        float term = 0.0f;                                   // same arithmetic as svm_kernel (svm_kernels.hip)
+        for (int sidx = lane; sidx < m.n_sv; sidx += 64) {
+            const float *sv = m.sv + (long)sidx * m.n_features;
+            float d2 = 0.0f;
+            for (int j = 0; j < m.n_features; ++j) {
+                const float dd = z[j] - sv[j];
+                d2 = d2 + dd * dd;
+            }
+            term = term + m.coef[sidx] * expf(-m.gamma * d2);
+        }
+        for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o);
+        if (lane == 0) {
+            const float score = term + m.rho;
+            const float fx = score * m.prob_a + m.prob_b;
+            const float p0 = fx >= 0.0f ? expf(-fx) / (1.0f + expf(-fx)) : 1.0f / (1.0f + expf(fx));
+            const float p1 = 1.0f - p0;
+            args.pool.labels[clip] = p1 > p0 ? 1 : 0;
+            if (args.pool.decision) args.pool.decision[clip] = score;
+            if (args.pool.prob1) args.pool.prob1[clip] = p1;
+        }
+        pool_s = 0.0; pool_q = 0.0; pool_t = 0;
+        wave_lds_sync();
+    };
+    (void)pool_tile; (void)pool_finish; (void)pool_s; (void)pool_q; (void)pool_t;
 
     // ---- 16-frame tile epilogue (TILE): log + DCT for the frames in slots [0, count) ----
     int slot = 0;               // frames in the tile
@@ -278,6 +349,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
                 kstep(s + 1, etile[64 * (s + 1) + 16 * q + (n ^ (s + 1))], 1);
             }
         }
+        if (POOL) {
+            f4v dd[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) dd[ct] = acc[ct][0] + acc[ct][1];
+            wave_lds_sync();                                 // every lane has read its tile column
+            pool_tile(dd, count);
+            return;
+        }
         const long fl = (n < 8 ? fb0 : fb1 - 8) + n;
         const bool ok = n < count && fl < n_frames;
 #pragma unroll
@@ -298,7 +377,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
         c32 (&nxt)[4] = ring[rd];
         const long f = fq[rd];
         const long clip_f = cq[rd];          // clip of frame f (clip mode)
-        (void)clip_f;
+        const bool last_f = lastq[rd];      // POOL: f closes its clip
+        (void)clip_f; (void)last_f;
         c32 s[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) s[a] = {nxt[a].x * win[2 * a], nxt[a].y * win[2 * a + 1]};
@@ -444,7 +524,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void m
         if (TILE) {
             if ((slot & 7) == 0) { if (slot == 0) fb0 = f; else fb1 = f; }
             etile[16 * lane + (slot ^ (lane >> 2))] = e;
-            if (++slot == 16 || !more) { flush(slot); slot = 0; }
+            const bool clip_ends = POOL && last_f;
+            if (++slot == 16 || !more || clip_ends) { flush(slot); slot = 0; }
+            if (clip_ends) pool_finish(clip_f);
             return more;
         }
 
@@ -529,6 +611,25 @@ static hipError_t launch_one(const Mfcc512Args &args, bool full, bool clips, int
         else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false, IN, TILE, true>), g, b, lds, stream, args);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream)
+{
+    const bool full = args.frame_len == 512;
+    if (args.frames_per_clip <= 0 || args.chunk != args.frames_per_clip || args.log_mode != 0 || args.in_kind != 0 || !args.pool.labels ||
+        args.pool.svm.n_features != 2 * args.n_mfcc || args.pool.svm.n_features > 64)
+        return hipErrorInvalidConfiguration;
+    const size_t lds = lds_bytes(true);
+    const dim3 g(blocks), b(256);
+#define DSP_LAUNCH_POOL(S, L, G)                                                                                        \
+    if (dct_split == S && dct_len == L && gather == G) {                                                                \
+        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true, 0, 1, true, true>), g, b, lds, stream, args);  \
+        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false, 0, 1, true, true>), g, b, lds, stream, args);      \
+        return hipGetLastError();                                                                                       \
+    }
+    DSP_FOR_SHAPES(DSP_LAUNCH_POOL)
+#undef DSP_LAUNCH_POOL
+    return hipErrorInvalidConfiguration;
 }
 
 hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks,

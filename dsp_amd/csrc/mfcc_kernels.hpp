@@ -3,9 +3,21 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "svm_kernels.hpp"
 #include "tables.hpp"
 
 namespace dsp {
+
+// BASELINE config 5 in ONE kernel (clip mode, one wavefront per clip): the MFCC matrix is never written; the
+// tile epilogue pools mean | std per coefficient (cepstrum/scrubjay_infer.c:36-66, float64 sums in frame order)
+// and the clip ends with Scaler -> RBF-SVM -> Platt (scrubjay_svm.onnx, scrubjay_infer.c:105-141).
+struct PoolSvmArgs {
+    SvmModelDev svm;       // n_features = 2 * n_mfcc
+    int *labels;           // [n_clips]
+    float *decision;       // [n_clips] or nullptr
+    float *prob1;          // [n_clips] or nullptr
+    float *feat;           // [n_clips][2 * n_mfcc] or nullptr
+};
 
 struct Mfcc512Args {
     const void *in;                // HBM: frames or clips; float32, or int16 PCM (in_kind)
@@ -27,6 +39,7 @@ struct Mfcc512Args {
     int log_mode;
     float *frame_max;
     const float *clip_floor;
+    PoolSvmArgs pool;              // only read by the POOL instantiations (launch_mfcc512_pool)
 };
 
 // clip_floor[c] = max_t frame_max[c][t] - top_db
@@ -36,6 +49,8 @@ hipError_t launch_clip_floor(const float *frame_max, long n_clips, int frames_pe
 // tile: 16-frame log + MFMA-DCT epilogue (per-frame log mode, chunk % 8 == 0); false: per-frame epilogue
 hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks,
                           hipStream_t stream, bool tile);
+// fused clip -> label path: args.chunk must equal args.frames_per_clip, args.out is not written
+hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream);
 hipError_t launch_mfcc512_row(const Mfcc512Args &args, const RowTables512 *row_tables, int dct_split, int dct_len,
                               int gather, int blocks, hipStream_t stream);
 int mfcc512_row_blocks_per_cu(int dct_split, int dct_len, int gather, bool full);

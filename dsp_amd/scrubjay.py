@@ -76,7 +76,22 @@ class ScrubJay:
         self.plan = MfccPlan(default_config(n_mfcc=n_mfcc), device)
         self.svm = SvmModel(svm_attrs, device)
 
-    def __call__(self, clips, max_frames: int = 1 << 20):
-        mfcc = self.plan.clips(clips, max_frames)
-        feat = mfcc_stats(mfcc)
-        return self.svm.predict(feat) + (feat,)
+    def __call__(self, clips, max_frames: int = 1 << 20, fused: bool = True):
+        """-> (labels int32, decision float32, prob1 float32, features float32 [n][2 n_mfcc]).  fused: one kernel from PCM to
+        label (dsp_scrubjay_fused_device, BASELINE config 5); otherwise MFCC -> pooling -> SVM as three kernels."""
+        if not fused:
+            mfcc = self.plan.clips(clips, max_frames)
+            feat = mfcc_stats(mfcc)
+            return self.svm.predict(feat) + (feat,)
+        import torch
+        n = clips.shape[0]
+        labels = torch.empty(n, dtype=torch.int32, device=clips.device)
+        dec = torch.empty(n, dtype=torch.float32, device=clips.device)
+        p1 = torch.empty(n, dtype=torch.float32, device=clips.device)
+        feat = torch.empty((n, self.svm.n_features), dtype=torch.float32, device=clips.device)
+        st = C.c_void_p(torch.cuda.current_stream(clips.device).cuda_stream)
+        assert clips.dim() == 2 and clips.stride(1) == 1
+        _lib.check(_lib.load().dsp_scrubjay_fused_device(self.plan._h, self.svm._h, clips.data_ptr(), n, clips.shape[1], clips.stride(0),
+                                                         int(min(max_frames, 1 << 30)), labels.data_ptr(), dec.data_ptr(), p1.data_ptr(),
+                                                         feat.data_ptr(), st), "dsp_scrubjay_fused_device")
+        return labels, dec, p1, feat

@@ -190,6 +190,14 @@ void dsp_svm_destroy(dsp_svm *svm);
 int dsp_svm_predict_device(dsp_svm *svm, const float *d_feat, long n_clips, int *d_labels, float *d_decision,
                            float *d_prob1, void *stream);
 
+/* BASELINE config 5 in ONE kernel: clip -> MFCC(n_mfcc) -> mean | std -> Scaler -> RBF-SVM -> label, the MFCC
+ * matrix never leaves the chip (one wavefront walks one clip; pooling in the kernel's tile epilogue).  The plan's
+ * 2 * n_mfcc must equal the SVM's n_features (<= 64); equal results to dsp_mfcc_clips_device +
+ * dsp_mfcc_stats_device + dsp_svm_predict_device.  d_decision, d_prob1, d_feat ([n_clips][2 n_mfcc]) may be NULL. */
+int dsp_scrubjay_fused_device(dsp_mfcc_plan *plan, dsp_svm *svm, const float *d_signal, long n_clips,
+                              int samples_per_clip, long clip_stride, int max_frames, int *d_labels,
+                              float *d_decision, float *d_prob1, float *d_feat, void *stream);
+
 /* --- consumers of the MFCC matrix and the resampler (8f-4) ------- */
 
 /* The stop-word net behind classify_signal (2fa/audio/word/c/stop_detector.h:10,

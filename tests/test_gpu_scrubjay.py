@@ -104,3 +104,27 @@ def test_config5_at_scale(golden):
         assert abs(float(dec[i]) - odec) <= 2e-5 * max(1.0, abs(odec)) and abs(float(p1[i]) - op1) <= 2e-5
         if abs(op1 - 0.5) > 1e-4:
             assert int(labels[i]) == lab
+
+
+def test_fused_kernel_equals_the_three_kernel_path(golden):
+    """BASELINE config 5 "in one kernel": pooled features, decision values, probabilities and labels of
+    dsp_scrubjay_fused_device are those of MFCC -> mfcc_stats -> SVM (same arithmetic in the same order)."""
+    import torch
+    from dsp_amd import scrubjay
+    m = golden("scrubjay_svm.npz")
+    sj = scrubjay.ScrubJay({k: m[k] for k in m.files})
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    for n, samples in ((1, 16000), (5, 16000), (700, 16000), (33, 8000), (64, 1200), (3, 400)):
+        clips = torch.rand((n, samples), device="cuda", generator=gen) * 2 - 1
+        clips[::3] *= 0.01
+        if n > 4:
+            clips[4] = 0.0                                           # a silent clip: all coefficients 0, std 0
+        a = sj(clips, fused=False)
+        b = sj(clips, fused=True)
+        assert torch.equal(a[3], b[3]), (n, samples)                 # features
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[0], b[0]), (n, samples)
+    # strided rows and a max_frames clamp
+    wide = torch.rand((40, 16384), device="cuda", generator=gen) * 2 - 1
+    a = sj(wide[:, :16000].contiguous(), 50, fused=False)
+    b = sj(wide[:, :16000], 50, fused=True)
+    assert torch.equal(a[3], b[3]) and torch.equal(a[0], b[0])
