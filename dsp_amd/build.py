@@ -10,7 +10,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.environ.get("DSP_AMD_LIB") or os.path.join(PKG, "libdsp_amd.so")
 SOURCES = ["capi.cpp", "capi_consumers.cpp", "tables.cpp", "mfcc_kernels.hip", "mfcc_row_kernel.hip", "mfcc1024_kernel.hip", "classify_kernels.hip",
            "svm_kernels.hip", "consumer_kernels.hip"]
-HEADERS = ["tables.hpp", "mfcc_kernels.hpp", "mfcc_device.hpp", "classify_kernels.hpp", "svm_kernels.hpp", os.path.join("..", "..", "include", "dsp_amd.h")]
+HEADERS = ["tables.hpp", "mfcc_kernels.hpp", "mfcc_device.hpp", "classify_kernels.hpp", "svm_kernels.hpp", "consumer_kernels.hpp", "capi_util.hpp",
+           os.path.join("..", "..", "include", "dsp_amd.h")]
 
 
 def _hipcc() -> str:
@@ -32,16 +33,37 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source into dsp_amd/libdsp_amd.so (cross-compiles without a GPU)."""
     if not force and not is_stale():
         return LIB
+    # several ranks of one job may get here together (bench.py under torch.distributed.run): one of them builds
+    # into a temporary file that is renamed into place, the others wait on the lock and find the library fresh
+    import fcntl
+    lock = open(LIB + ".lock", "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not is_stale():
+            return LIB
+        return _build_locked(verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(verbose: bool) -> str:
+    tmp = LIB + f".tmp{os.getpid()}"
     # -fno-slp-vectorize: packed fp32 VALU (v_pk_fma_f32 ...) issues at half rate on
     # gfx950, so SLP packing only adds register shuffles (measured: 292 -> 222
     # issue slots per frame, 126 -> 108 VGPRs).
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-slp-vectorize", "-Wno-unused-value", "-o", LIB]
+           "-fno-slp-vectorize", "-Wno-unused-value", "-o", tmp]
     cmd += os.environ.get("DSP_AMD_EXTRA_FLAGS", "").split()
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd, cwd=CSRC)
+    try:
+        subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 
