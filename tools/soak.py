@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Determinism soak (development aid): many launches of every MFCC kernel form on the same inputs, every output
+compared bit for bit with the first one.  The kernels order their per-wave LDS traffic with wavefront-scope fences
+only (no s_barrier), so a rare ordering bug would show up here as a flipped bit.   python tools/soak.py [launches]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dsp_amd  # noqa: E402
+from dsp_amd.scrubjay import ScrubJay  # noqa: E402
+
+
+def main():
+    n_launch = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    cases = []
+    x = torch.rand((200_000, 512), device="cuda", generator=gen) * 2 - 1
+    p = dsp_amd.MfccPlan(dsp_amd.default_config(frame_length=512, hop_length=512))
+    cases.append(("frames 512", lambda: p.frames(x)))
+    clips = torch.rand((3000, 16000), device="cuda", generator=gen) * 2 - 1
+    pc = dsp_amd.MfccPlan()
+    cases.append(("clips 400/160", lambda: pc.clips(clips, 500)))
+    pcm = torch.randint(-32768, 32768, (3000, 16000), dtype=torch.int16, device="cuda", generator=gen)
+    cases.append(("pcm16 clips", lambda: pc.clips_pcm16(pcm, 500)))
+    pf = dsp_amd.MfccPlan(dsp_amd.default_config())
+    pf.set_kernel(2)
+    cases.append(("per-frame epilogue", lambda: pf.clips(clips, 500)))
+    attrs = dict(np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "scrubjay_svm.npz")))
+    sj = ScrubJay(attrs)
+    cases.append(("fused config 5", lambda: torch.cat([t.float().reshape(clips.shape[0], -1) for t in sj(clips, 500, fused=True)], 1)))
+    x1024 = torch.rand((50_000, 1024), device="cuda", generator=gen) * 2 - 1
+    p3 = dsp_amd.MfccPlan(dsp_amd.default_config(n_fft=1024, frame_length=1024, hop_length=1024, n_mels=128, prefilter=2))
+    cases.append(("config 3 (IIR + 1024)", lambda: p3.frames(x1024)))
+    cl = (torch.rand((4096, 16000), device="cuda", generator=gen) * 2 - 1) * 0.05
+    lab = torch.empty(4096, dtype=torch.int32, device="cuda")
+
+    def cls():
+        dsp_amd.classify_device(cl, lab)
+        return lab.clone()
+    cases.append(("classify", cls))
+    bad = 0
+    for name, fn in cases:
+        ref = fn().clone()
+        mism = 0
+        for i in range(n_launch):
+            out = fn()
+            if i % 10 == 9 or i == n_launch - 1:
+                if not torch.equal(out, ref):
+                    mism += 1
+        torch.cuda.synchronize()
+        print(f"{name:24s} {n_launch} launches, mismatching checks: {mism}", flush=True)
+        bad += mism
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
