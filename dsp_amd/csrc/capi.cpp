@@ -76,6 +76,8 @@ struct dsp_mfcc_plan {
     dsp::RowTables512 *d_row_tables = nullptr;
     dsp::GenTables1024 *d_gen_tables = nullptr;   // n_fft = 1024
     int resident_blocks_gen = 3;
+    int gen_slots = 0;                            // mel chunk slots per lane the 1024-point tables use (<= 3: wave kernel)
+    int resident_blocks_gen_wave = 2;
     float *d_filtered = nullptr;                  // per-frame prefilter output (sub-batch)
     size_t filtered_cap = 0;
     float *d_frame_max = nullptr, *d_clip_floor = nullptr;   // DSP_LOG_GLOBAL_REF1 two-pass workspace
@@ -201,6 +203,7 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
         e = hipMalloc(&p->d_gen_tables, sizeof(dsp::GenTables1024));
         if (e == hipSuccess) e = hipMemcpy(p->d_gen_tables, gen, sizeof(*gen), hipMemcpyHostToDevice);
     }
+    if (gen) p->gen_slots = gen->n_chunk_slots;
     delete gen;
     if (e == hipSuccess) e = hipMalloc(&p->d_row_tables, sizeof(dsp::RowTables512));
     if (e == hipSuccess && cfg->n_fft == 512) {
@@ -225,6 +228,7 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
                                                                 cfg->frame_length == 512);
     } else {
         p->resident_blocks_gen = dsp::mfcc1024_blocks_per_cu(cfg->frame_length == 1024);
+        p->resident_blocks_gen_wave = dsp::mfcc1024_wave_blocks_per_cu(cfg->frame_length == 1024);
     }
     if (const char *k = std::getenv("DSP_AMD_KERNEL")) {
         const int id = std::atoi(k);
@@ -303,7 +307,10 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     const bool row = !gen && p->kernel == DSP_KERNEL_ROW;
     // 16-frame tile epilogue: per-frame log mode on the wave-per-frame kernel
     const bool tile = !gen && p->kernel == DSP_KERNEL_WAVE && p->cfg.log_mode == DSP_LOG_PER_FRAME_MAX;
-    const int nf = gen ? 1 : (row ? 4 : (tile ? 8 : 1));
+    // 1024-point: the register-resident wave kernel when the filterbank fits two chunk slots per lane (DSP_KERNEL_ROW selects
+    // the general Stockham kernel for A/B)
+    const bool gen_wave = gen && p->gen_slots <= 3 && p->kernel != DSP_KERNEL_ROW;
+    const int nf = gen ? (gen_wave ? 8 : 1) : (row ? 4 : (tile ? 8 : 1));
     a.chunk = p->chunk > 0 ? p->chunk : 8;
     a.chunk = ((a.chunk + nf - 1) / nf) * nf;   // whole items (tile: half-tiles of 8 frames) per chunk
     a.n_mels = p->cfg.n_mels;
@@ -317,7 +324,7 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     // extra block per CU would run as a second, mostly idle round: measured +14 %),
     // never more blocks than there are chunks of work
     const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu
-                       : (gen ? p->resident_blocks_gen
+                       : (gen ? (gen_wave ? p->resident_blocks_gen_wave : p->resident_blocks_gen)
                               : (row ? p->resident_blocks_row : (tile ? p->resident_blocks : p->resident_blocks_frame)));
     long blocks = (long)p->n_cu * per_cu;
     const long chunks = (n_frames + a.chunk - 1) / a.chunk;
@@ -341,7 +348,9 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
         DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream, false));
         return DSP_OK;
     }
-    if (gen)
+    if (gen_wave)
+        DSP_HIP(dsp::launch_mfcc1024_wave(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream));
+    else if (gen)
         DSP_HIP(dsp::launch_mfcc1024(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream));
     else if (row)
         DSP_HIP(dsp::launch_mfcc512_row(a, p->d_row_tables, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks,

@@ -1,0 +1,291 @@
+// mfcc1024_wave_kernel.hip -- the n_fft = 1024 MFCC chain (BASELINE config 3: 1024-point FFT, up to 128 mel
+// bins) built like the 512-point kernel of mfcc_kernels.hip: one 64-lane wavefront owns one frame, every
+// butterfly stage runs in registers, constants live in registers, log + DCT run once per 16-frame tile.
+//
+//   load      8 x global_load_dwordx2 per lane: z[l + 64 a] = x[2n] + i x[2n+1], one frame ahead
+//   FFT       1024-point real FFT as a 512-point complex radix-8 DIF, 8 points per lane:
+//               stage A  radix-8 over a,        twiddle W512^(l q)
+//               exchange 1 (LDS): slot q <-> lane bits 5:3
+//               stage B  radix-8 over l_hi,     twiddle W64^(l_lo p)
+//               exchange 2 (LDS): slot p <-> lane bits 2:0, readers in natural order (lane = k mod 64)
+//               stage C  radix-8 over l_lo  ->  lane l holds Z[l + 64 r], r = 0..7
+//             both exchanges XOR-swizzled: ds_write_b64 (16-lane groups) and ds_read_b64 (32-lane groups) conflict-free
+//   untangle  lane l pairs Z[l + 64 t] with Z[512 - l - 64 t] (lane 64 - l, slot 7 - t; 8 ds_bpermute), t = 0..3
+//   power     513 bins -> LDS
+//   mel       sparse: <= 3 chunks of 12 bins per lane (weights in registers), partial sums -> LDS -> 6-way gather, 2 filters per lane
+//   tile      E[mel][16 frames] in LDS; every 16 frames per-frame max + log + DCT on v_mfma_f32_16x16x4_f32
+//
+// The general Stockham kernel (mfcc1024_kernel.hip) stays as the fallback for filterbanks that need more than three
+// chunk slots per lane.  Reference chain: 2fa/audio/word/c/mfcc.c:142-221 with the constants as parameters.
+#include <hip/hip_runtime.h>
+
+#include "mfcc_device.hpp"
+
+namespace dsp {
+
+namespace {
+
+constexpr int W_ZBUF = 0;                           // 512 x float2 exchange image; later P[0..512]
+constexpr int W_PART = 4096;                        // 192 partial sums + zero slot (kGenZeroSlot = 256 is remapped to 192)
+constexpr int W_ETILE = W_PART + 208 * 4;           // mel energies of 16 frames: E[mel][frame ^ ((mel >> 1) & 15)]
+constexpr int W_WAVE_BYTES = W_ETILE + 128 * 16 * 4;
+static_assert(W_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
+constexpr int kWaveSlots = 3;                       // chunk slots per lane this kernel holds in registers (128 HTK filters on 513 bins: 155 chunks)
+constexpr int kWaveZero = 192;                      // partial slot that always reads 0
+
+// forward radix-8 butterfly: u[q] = sum_a v[a] W8^(a q)
+__device__ __forceinline__ void radix8w(c32 (&v)[8])
+{
+    c32 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+    radix4(e);
+    radix4(o);
+    constexpr float R2 = 0.70710678118654752f;
+    const c32 t1 = {(o[1].x + o[1].y) * R2, (o[1].y - o[1].x) * R2};        // W8^1 = (1 - i)/sqrt2
+    const c32 t2 = {o[2].y, -o[2].x};                                        // W8^2 = -i
+    const c32 t3 = {(o[3].y - o[3].x) * R2, -(o[3].x + o[3].y) * R2};       // W8^3 = (-1 - i)/sqrt2
+    v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
+    v[1] = cadd(e[1], t1);   v[5] = csub(e[1], t1);
+    v[2] = cadd(e[2], t2);   v[6] = csub(e[2], t2);
+    v[3] = cadd(e[3], t3);   v[7] = csub(e[3], t3);
+}
+
+}  // namespace
+
+template <bool FULL, bool CLIPS>
+__global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args args, const GenTables1024 *__restrict__ G)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *wl = smem + wib * W_WAVE_BYTES;
+    float2 *zbuf = reinterpret_cast<float2 *>(wl + W_ZBUF);
+    float *pbuf = reinterpret_cast<float *>(wl + W_ZBUF);
+    float *part = reinterpret_cast<float *>(wl + W_PART);
+    float *etile = reinterpret_cast<float *>(wl + W_ETILE);
+
+    // ---- per-lane constants ------------------------------------------------------------------------------------
+    float win[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) win[i] = G->win[i][lane];
+    c32 tw1[7], tw2[7], twp[4];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        tw1[q] = {G->tw1[2 * q][lane], G->tw1[2 * q + 1][lane]};
+        tw2[q] = {G->tw2[2 * q][lane], G->tw2[2 * q + 1][lane]};
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) twp[t] = {G->twp[2 * t][lane], G->twp[2 * t + 1][lane]};
+    float melw[kWaveSlots][kMelChunk];
+    int mel_k0[kWaveSlots];
+#pragma unroll
+    for (int c = 0; c < kWaveSlots; ++c) {
+        mel_k0[c] = G->mel_k0[c][lane];
+#pragma unroll
+        for (int i = 0; i < kMelChunk; ++i) melw[c][i] = G->mel_w[c][i][lane];
+    }
+    int gat[kGenMelsPerLane][kGenGather];           // partial slots of filters lane and lane + 64 (slots >= 128 read the zero slot)
+#pragma unroll
+    for (int i = 0; i < kGenMelsPerLane; ++i)
+#pragma unroll
+        for (int g = 0; g < kGenGather; ++g) {
+            const int sidx = G->mel_src[i][g][lane];
+            gat[i][g] = sidx < kWaveSlots * 64 ? sidx : kWaveZero;
+        }
+    const int n_mels = args.n_mels, n_mfcc = args.n_mfcc;
+    const int l_hi = lane >> 3, l_lo = lane & 7;
+    const int partner = ((64 - lane) & 63) << 2;     // byte index for ds_bpermute
+    const bool self_paired = lane == 0;
+    if (lane == 0) part[kWaveZero] = 0.0f;
+    wave_lds_sync();
+
+    const long wave = (long)blockIdx.x * 4 + wib;
+    const long n_waves = (long)gridDim.x * 4;
+    const unsigned amin_u = __float_as_uint(args.amin);
+    const float neg_top_db = -args.top_db;
+    const int frame_len = args.frame_len;
+    const long n_frames = args.n_frames;
+
+    auto load_frame8 = [&](long off, c32 (&z)[8]) {
+        const float *src = static_cast<const float *>(args.in) + off;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const int i = 2 * (lane + 64 * a);
+            if (FULL || i + 1 < frame_len) {
+                const f2v x = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));
+                z[a] = {x.x, x.y};
+            } else if (i < frame_len) {
+                z[a] = {src[i], 0.0f};
+            } else {
+                z[a] = {0.0f, 0.0f};
+            }
+        }
+    };
+
+    // one cursor, one frame of look-ahead (8 more VGPRs per lane would buy a second one; not needed at 3 waves/SIMD)
+    WaveCursor<CLIPS> pre;
+    pre.init(wave, n_waves, args.chunk, n_frames, args.frames_per_clip, CLIPS ? args.hop : frame_len, args.clip_stride);
+    if (!pre.valid()) return;
+    c32 nxt[8];
+    long f_next = pre.f;
+    load_frame8(pre.off, nxt);
+    pre.next();
+
+    // ---- 16-frame tile epilogue --------------------------------------------------------------------------------
+    int slot = 0;
+    long fb0 = 0, fb1 = 0;
+    auto flush = [&](int count) {
+        wave_lds_sync();
+        const int n = lane & 15, q = lane >> 4;
+        unsigned mx = amin_u;
+#pragma unroll 4
+        for (int s = 0; s < kGenDctSteps; ++s) mx = max(mx, __float_as_uint(etile[16 * (4 * s + q) + (n ^ ((2 * s + (q >> 1)) & 15))]));
+        {
+            auto r = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
+            mx = max(r[0], r[1]);
+            r = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
+            mx = max(r[0], r[1]);
+        }
+        const float rinv = __builtin_amdgcn_rcpf(__uint_as_float(mx));
+        f4v acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto kstep = [&](int s, f4v &acc) {
+            const float e_s = etile[16 * (4 * s + q) + (n ^ ((2 * s + (q >> 1)) & 15))];
+            const float ec = __uint_as_float(max(__float_as_uint(e_s), amin_u));
+            float db = 3.01029995663981195f * __builtin_amdgcn_logf(ec * rinv);
+            db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f);
+            if (4 * s + q >= n_mels) db = 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(G->dct_a[s][lane], db, acc, 0, 0, 0);
+        };
+#pragma unroll 1
+        for (int s = 0; s < kGenDctSteps; s += 2) { kstep(s, acc0); kstep(s + 1, acc1); }
+        const f4v d = acc0 + acc1;
+        const long fl = (n < 8 ? fb0 : fb1 - 8) + n;
+        const bool ok = n < count && fl < n_frames;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * q + j;
+            if (ok && c < n_mfcc) args.out[fl * n_mfcc + c] = d[j];
+        }
+        wave_lds_sync();
+    };
+
+    while (true) {
+        const long f = f_next;
+        c32 v[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) v[a] = {nxt[a].x * win[2 * a], nxt[a].y * win[2 * a + 1]};
+        const bool more = pre.valid();
+        if (more) { f_next = pre.f; load_frame8(pre.off, nxt); pre.next(); }
+
+        // ---- stage A: radix-8 over a, twiddle W512^(l q) -----------------------------------------------------------
+        radix8w(v);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw1[q - 1]);
+        // exchange 1: element (q, l_hi, l_lo) at (64 q + 8 l_hi + l_lo) ^ 8 (q & 3): writer lane (l_hi, l_lo) slot q,
+        // reader lane (q, l_lo) slot l_hi
+#pragma unroll
+        for (int q = 0; q < 8; ++q) zbuf[(64 * q + lane) ^ (8 * (q & 3))] = make_float2(v[q].x, v[q].y);
+        wave_lds_sync();
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const float2 x = zbuf[(64 * l_hi + 8 * h + l_lo) ^ (8 * (l_hi & 3))];
+            v[h] = {x.x, x.y};
+        }
+        wave_lds_sync();
+        // ---- stage B: radix-8 over l_hi, twiddle W64^(l_lo p) -----------------------------------------------------
+        radix8w(v);
+#pragma unroll
+        for (int p = 1; p < 8; ++p) v[p] = cmul(v[p], tw2[p - 1]);
+        // exchange 2: element (q, p, l_lo) at (64 p + 8 q + l_lo) ^ ((p & 3) << 1 | q >> 2): writer lane (q, l_lo) slot p,
+        // reader lane (p, q) slot l_lo -> after stage C lane l holds bins l + 64 r
+        // (here this lane's l_hi is its q)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) zbuf[(64 * p + lane) ^ (((p & 3) << 1) | (l_hi >> 2))] = make_float2(v[p].x, v[p].y);
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            // reader lane = 8 p' + q' with p' = l_hi, q' = l_lo; slot m = l_lo of the element
+            const float2 x = zbuf[(64 * l_hi + 8 * l_lo + m) ^ (((l_hi & 3) << 1) | (l_lo >> 2))];
+            v[m] = {x.x, x.y};
+        }
+        wave_lds_sync();
+        // ---- stage C: radix-8 over l_lo: v[r] = Z[lane + 64 r] / 2 ------------------------------------------------
+        radix8w(v);
+
+        // ---- untangle + power: pairs (k, 512 - k), k = lane + 64 t, t = 0..3 ----------------------------------------
+        float P[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            c32 b;
+            b.x = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[7 - t].x)));
+            b.y = __int_as_float(__builtin_amdgcn_ds_bpermute(partner, __float_as_int(v[7 - t].y)));
+            // lane 0: Z[512 - 64 t] = Z[64 (8 - t)] is its own slot (8 - t) % 8
+            const c32 own = v[(8 - t) & 7];
+            b.x = self_paired ? own.x : b.x;
+            b.y = self_paired ? own.y : b.y;
+            const c32 a = v[t];
+            const c32 E = {a.x + b.x, a.y - b.y};
+            const c32 O = {a.x - b.x, a.y + b.y};
+            const c32 Tw = cmul(O, twp[t]);
+            const float xr = E.x + Tw.y, xi = E.y - Tw.x;
+            const float mr = E.x - Tw.y, mi = E.y + Tw.x;
+            P[2 * t] = xr * xr + xi * xi;
+            P[2 * t + 1] = mr * mr + mi * mi;
+        }
+        const float p256 = 4.0f * (v[4].x * v[4].x + v[4].y * v[4].y);     // lane 0: bin 256 pairs with itself
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            pbuf[lane + 64 * t] = P[2 * t];
+            pbuf[512 - lane - 64 * t] = P[2 * t + 1];
+        }
+        if (self_paired) pbuf[256] = p256;
+        wave_lds_sync();
+
+        // ---- sparse mel: two chunk slots per lane, weights in registers ---------------------------------------------
+#pragma unroll
+        for (int c = 0; c < kWaveSlots; ++c) {
+            const float *rd = pbuf + mel_k0[c];
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < kMelChunk; ++i) acc = fmaf(melw[c][i], rd[i], acc);
+            part[c * 64 + lane] = acc;
+        }
+        wave_lds_sync();
+        if ((slot & 7) == 0) { if (slot == 0) fb0 = f; else fb1 = f; }
+#pragma unroll
+        for (int i = 0; i < kGenMelsPerLane; ++i) {
+            float s = 0.0f;
+#pragma unroll
+            for (int g = 0; g < kGenGather; ++g) s += part[gat[i][g]];
+            const int m = lane + 64 * i;
+            if (m >= n_mels) s = 0.0f;
+            etile[16 * m + (slot ^ ((m >> 1) & 15))] = s;
+        }
+        if (++slot == 16 || !more) { flush(slot); slot = 0; }
+        else wave_lds_sync();
+        if (!more) return;
+    }
+}
+
+hipError_t launch_mfcc1024_wave(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream)
+{
+    const bool full = args.frame_len == 1024, clips = args.frames_per_clip > 0;
+    if (args.chunk % 8 != 0) return hipErrorInvalidConfiguration;
+    const size_t lds = (size_t)4 * W_WAVE_BYTES;
+    const dim3 g(blocks), b(256);
+    if (full && !clips) hipLaunchKernelGGL((mfcc1024_wave_kernel<true, false>), g, b, lds, stream, args, tables);
+    else if (full) hipLaunchKernelGGL((mfcc1024_wave_kernel<true, true>), g, b, lds, stream, args, tables);
+    else if (!clips) hipLaunchKernelGGL((mfcc1024_wave_kernel<false, false>), g, b, lds, stream, args, tables);
+    else hipLaunchKernelGGL((mfcc1024_wave_kernel<false, true>), g, b, lds, stream, args, tables);
+    return hipGetLastError();
+}
+
+int mfcc1024_wave_blocks_per_cu(bool full)
+{
+    int n = 0;
+    const size_t lds = (size_t)4 * W_WAVE_BYTES;
+    hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc1024_wave_kernel<true, false>, 256, lds)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc1024_wave_kernel<false, false>, 256, lds);
+    return e == hipSuccess && n > 0 ? n : 2;
+}
+
+}  // namespace dsp

@@ -56,6 +56,9 @@ hipError_t launch_mfcc512_row(const Mfcc512Args &args, const RowTables512 *row_t
 int mfcc512_row_blocks_per_cu(int dct_split, int dct_len, int gather, bool full);
 hipError_t launch_mfcc1024(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream);
 int mfcc1024_blocks_per_cu(bool full);
+// register-resident wave-per-frame form (mfcc1024_wave_kernel.hip): tables->n_chunk_slots <= 3, chunk % 8 == 0
+hipError_t launch_mfcc1024_wave(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream);
+int mfcc1024_wave_blocks_per_cu(bool full);
 int mfcc512_lds_bytes_per_block(bool tile);
 int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full, bool tile);
 

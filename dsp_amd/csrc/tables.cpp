@@ -147,6 +147,18 @@ bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::st
                 const int m = q * kGenDctLen + i;
                 t.dct_w[i][4 * c + q] = m < cfg.n_mels ? dct[(size_t)c * cfg.n_mels + m] : 0.0f;
             }
+    for (int st = 0; st < kGenDctSteps; ++st)
+        for (int l = 0; l < kLanes; ++l) {
+            const int c = l % 16, m = 4 * st + l / 16;
+            t.dct_a[st][l] = (c < cfg.n_mfcc && m < cfg.n_mels) ? dct[(size_t)c * cfg.n_mels + m] : 0.0f;
+        }
+    for (int l = 0; l < kLanes; ++l) {
+        for (int q = 1; q < 8; ++q) {
+            unit((double)(l * q) / 512.0, t.tw1[2 * (q - 1)][l], t.tw1[2 * (q - 1) + 1][l]);
+            unit((double)((l % 8) * q) / 64.0, t.tw2[2 * (q - 1)][l], t.tw2[2 * (q - 1) + 1][l]);
+        }
+        for (int tt = 0; tt < 4; ++tt) unit((double)(l + 64 * tt) / 1024.0, t.twp[2 * tt][l], t.twp[2 * tt + 1][l]);
+    }
     return true;
 }
 

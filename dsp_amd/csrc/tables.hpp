@@ -84,6 +84,7 @@ constexpr int kGenChunks = 4;      // mel chunks (12 bins) per lane  -> up to 25
 constexpr int kGenGather = 6;      // partial sums per filter (filters up to 72 bins wide)
 constexpr int kGenMelsPerLane = 2; // filters per lane -> n_mels <= 128
 constexpr int kGenDctLen = 32;     // log-mel values per DCT lane (split 4)
+constexpr int kGenDctSteps = 32;   // MFMA k-steps of 4 mel filters (n_mels <= 128)
 struct GenTables1024 {
     float win[16][kLanes];                 // x0.5 window for samples 2(l+64a), 2(l+64a)+1
     float w512[2][512];                    // W512^i (cos, sin): stage twiddles
@@ -94,6 +95,11 @@ struct GenTables1024 {
     float dct_w[kGenDctLen][kLanes];       // lane 4c+q: row c, mels [32q, 32q+32)
     int32_t n_chunk_slots;                 // chunk slots per lane in use (1..4)
     int32_t n_mels, n_mfcc;
+    // per-lane tables of the register-resident wave kernel (mfcc1024_wave_kernel.hip), all (cos, sin) pairs of exp(-2 pi i x):
+    float tw1[14][kLanes];                 // W512^(l q),        q = 1..7 at [2(q-1)], [2(q-1)+1]: after the first radix-8 stage
+    float tw2[14][kLanes];                 // W64^((l % 8) p),   p = 1..7: after the second stage
+    float twp[8][kLanes];                  // W1024^(l + 64 t),  t = 0..3: untangling the packed real transform
+    float dct_a[kGenDctSteps][kLanes];     // MFMA A operand of the tile epilogue: lane (c = l % 16, q = l / 16), step s: D[c][4 s + q]
 };
 constexpr int kGenZeroSlot = kGenChunks * kLanes;   // partial slot that always reads 0
 bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::string &why);
