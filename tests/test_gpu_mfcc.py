@@ -264,6 +264,28 @@ def test_config3_1024_point_128_mel_with_prefilter(dsp, torch_cuda):
                 assert not out[1].any()                       # silent frame stays exactly zero through the filter
 
 
+def test_1024_general_fallback_kernel_agrees_with_the_wave_kernel(dsp, torch_cuda):
+    """n_fft = 1024 has two kernels: the register-resident wave kernel (default) and the general Stockham kernel (fallback
+    for filterbanks with more than three chunks per lane; forced here through set_kernel(1)).  Both against the oracle."""
+    from oracle import oracle as O
+    torch = torch_cuda
+    over = dict(n_fft=1024, frame_length=1024, hop_length=1024, n_mels=128)
+    fr = S.uniform_pm1(1024 * 200, 4242).reshape(200, 1024)
+    fr[3] = 0.0
+    x = torch.from_numpy(fr).cuda()
+    ref = O.mfcc_frames(fr, O.default_cfg(**over), threads=4)
+    outs = []
+    for kern in (0, 1):
+        plan = dsp.MfccPlan(dsp.default_config(**over))
+        plan.set_kernel(kern)
+        out = plan.frames(x).cpu().numpy()
+        ok, worst = frame_linf_close(out, ref, RTOL, ATOL_DB)
+        assert ok, (kern, worst)
+        assert not out[3].any()
+        outs.append(out)
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-3        # two different FFT factorisations of the same chain
+
+
 def test_config3_full_size_properties(dsp, torch_cuda):
     """BASELINE config 3 at its full size: 10 M frames x 1024 fp32 (41 GB in HBM) through the float64 prefilter and the
     1024-point chain.  Size-independent properties + an oracle spot check; skipped when the card lacks the memory."""
