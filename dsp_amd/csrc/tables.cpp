@@ -109,12 +109,16 @@ bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::st
     for (int i = 0; i < 512; ++i) unit((double)i / 512.0, t.w512[0][i], t.w512[1][i]);
     for (int k = 0; k < 256; ++k) unit((double)k / 1024.0, t.w1024[0][k], t.w1024[1][k]);
 
-    // sparse mel: chunks of <= 12 bins dealt to (slot, lane); no bank placement here (general path)
+    // sparse mel: every filter's non-zero run is cut into chunks of <= 12 bins; a chunk goes to one (slot, lane) and is read
+    // as a 12-bin window pbuf[k0 .. k0+12).  ds_read_b32 serves lanes 0-31 and 32-63 in separate passes over 32 banks, so
+    // the reads of one slot are conflict free iff the windows of each 32-lane half start at distinct addresses mod 32:
+    // one bipartite matching (Kuhn) chunk -> (slot, half, start mod 32) over the fewest slots that hold all chunks.
     const std::vector<float> fb = make_mel_filterbank(cfg.sample_rate, n_fft, cfg.n_mels, cfg.fmin, cfg.fmax, cfg.mel_norm);
     for (int i = 0; i < kGenMelsPerLane; ++i)
         for (int g = 0; g < kGenGather; ++g)
             for (int l = 0; l < kLanes; ++l) t.mel_src[i][g][l] = kGenZeroSlot;
-    int next = 0;
+    struct Chunk { int m, g, first, len, lo, hi; };
+    std::vector<Chunk> chunks;
     for (int m = 0; m < cfg.n_mels; ++m) {
         const float *row = &fb[(size_t)m * n_bins];
         int first = -1, last = -1;
@@ -126,20 +130,58 @@ bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::st
         int k = first;
         for (int g = 0; g < pieces; ++g) {
             const int len = run / pieces + (g < run % pieces ? 1 : 0);
-            if (next >= kGenChunks * kLanes) { why = "mel filterbank needs more than 256 chunks of 12 bins"; return false; }
-            const int slot = next / kLanes, lane = next % kLanes;
-            const int k0 = std::min(k, n_bins - kMelChunk);
-            t.mel_k0[slot][lane] = k0;
-            for (int i = 0; i < kMelChunk; ++i) {
-                const int kk = k0 + i;
-                t.mel_w[slot][i][lane] = (kk >= k && kk < k + len) ? row[kk] : 0.0f;
-            }
-            t.mel_src[m / kLanes][g][m % kLanes] = next;     // partial index = slot * 64 + lane
-            ++next;
+            // the window [k0, k0+12) must cover the chunk and stay inside [0, 512]
+            chunks.push_back({m, g, k, len, std::max(0, k + len - kMelChunk), std::min(k, n_bins - kMelChunk)});
             k += len;
         }
     }
-    t.n_chunk_slots = std::max(1, (next + kLanes - 1) / kLanes);
+    const int nc = (int)chunks.size();
+    if (nc > kGenChunks * kLanes) { why = "mel filterbank needs more than 256 chunks of 12 bins"; return false; }
+    const int n_slots = std::max(1, (nc + kLanes - 1) / kLanes);
+    const int n_pos = n_slots * 64;                          // position = (slot * 2 + half) * 32 + start mod 32
+    std::vector<int> owner(n_pos, -1), pos(nc, -1), k0(nc, -1);
+    std::vector<char> seen;
+    struct Rec { static bool go(int i, const std::vector<Chunk> &c, int n_groups, std::vector<int> &owner, std::vector<char> &seen,
+                                std::vector<int> &pos, std::vector<int> &k0) {
+        for (int g = 0; g < n_groups; ++g)
+            for (int k = c[i].hi; k >= c[i].lo; --k) {
+                const int p = 32 * g + (k & 31);
+                if (seen[p]) continue;
+                seen[p] = 1;
+                if (owner[p] < 0 || go(owner[p], c, n_groups, owner, seen, pos, k0)) {
+                    owner[p] = i; pos[i] = p; k0[i] = k;
+                    return true;
+                }
+            }
+        return false; } };
+    bool placed = true;
+    for (int i = 0; i < nc && placed; ++i) {
+        seen.assign(n_pos, 0);
+        placed = Rec::go(i, chunks, 2 * n_slots, owner, seen, pos, k0);
+    }
+    std::vector<int> used(2 * n_slots, 0);
+    int next = 0;
+    for (int i = 0; i < nc; ++i) {
+        const Chunk &c = chunks[i];
+        int slot, lane;
+        if (placed) {
+            const int g = pos[i] / 32;
+            slot = g / 2;
+            lane = 32 * (g % 2) + used[g]++;
+        } else {                                             // still correct, just not conflict free
+            slot = next / kLanes; lane = next % kLanes; k0[i] = c.hi;
+        }
+        ++next;
+        const float *row = &fb[(size_t)c.m * n_bins];
+        t.mel_k0[slot][lane] = k0[i];
+        for (int j = 0; j < kMelChunk; ++j) {
+            const int kk = k0[i] + j;
+            t.mel_w[slot][j][lane] = (kk >= c.first && kk < c.first + c.len) ? row[kk] : 0.0f;
+        }
+        t.mel_src[c.m / kLanes][c.g][c.m % kLanes] = slot * kLanes + lane;     // partial index
+    }
+    t.n_chunk_slots = n_slots;
+    // idle lanes (weights all 0) still issue the 12 reads: leave their windows at 0 (broadcast-free but harmless)
     const std::vector<float> dct = make_dct_ortho(cfg.n_mfcc, cfg.n_mels);
     for (int c = 0; c < cfg.n_mfcc; ++c)
         for (int q = 0; q < 4; ++q)
