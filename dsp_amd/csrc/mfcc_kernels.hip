@@ -57,13 +57,15 @@ namespace {
 //   3 int16 stereo, channel average  x = 0.5 (L/32768 + R/32768)  (main_test.c:205-217)
 // The power-of-two scale is folded into the window (exact), so a lane only converts int -> float.
 // `off` is the frame's first sample (per channel).
-template <bool FULL, int IN>
+template <int FLEN, int IN>
 __device__ __forceinline__ void load_frame(const void *__restrict__ base, long off, int lane, int frame_len, c32 (&z)[4])
 {
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int i = 2 * (lane + 64 * a);
-        const bool both = FULL || i + 1 < frame_len, one = i < frame_len;
+        // FLEN: frame length known at compile time (512: no predicate at all; 400: only lanes 0-7 of a = 3 are live) or 0 = run time
+        const int flen = FLEN ? FLEN : frame_len;
+        const bool both = i + 1 < flen, one = i < flen;
         if (IN == 0) {
             const float *src = static_cast<const float *>(base) + off;
             if (both) {
@@ -107,7 +109,7 @@ __device__ __forceinline__ c32 unpack_pcm16(c32 raw)
 }  // namespace
 
 // DCT_SPLIT lanes per coefficient, DCT_LEN log-mel values per lane.  GATHER: partial
-// sums per mel filter.  FULL: frame_length == 512 (no tail predicate on the loads).
+// sums per mel filter.  FLEN: frame_length at compile time (512, the reference's 400) or 0 = run time (tail predicate on the loads).
 // IN: input element type (see load_frame).  CLIPS: frames overlap inside clips (hop < frame).
 // Every frame runs the same instructions whatever its position (results do not depend on
 // where a frame sits in the batch).  (Carrying two frames per wave through the pipeline
@@ -123,7 +125,7 @@ __device__ __forceinline__ c32 unpack_pcm16(c32 raw)
 // Saves ~45 of ~225 VALU issue slots and 10 LDS dwords per frame.
 // POOL (TILE, CLIPS, chunk = frames per clip: one wavefront walks one clip): instead of storing the coefficients the
 // tile epilogue pools them per clip and the clip ends with the SVM (PoolSvmArgs) -- BASELINE config 5 in one kernel.
-template <int DCT_SPLIT, int DCT_LEN, int GATHER, bool FULL, int IN, int TILE, bool CLIPS, bool POOL = false>
+template <int DCT_SPLIT, int DCT_LEN, int GATHER, int FLEN, int IN, int TILE, bool CLIPS, bool POOL = false>
 #ifndef DSP_WAVES_PER_EU
 #define DSP_WAVES_PER_EU 4
 #endif
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
     bool lastq[DSP_PREFETCH];           // POOL: the frame closes its chunk (= its clip)
     auto refill = [&](int d) {
         if (pre.valid()) {
-            load_frame<FULL, IN>(args.in, pre.off, lane, frame_len, ring[d]);
+            load_frame<FLEN, IN>(args.in, pre.off, lane, frame_len, ring[d]);
             fq[d] = pre.f; cq[d] = pre.clip; lastq[d] = pre.left == 0 || pre.remaining == 1;
             pre.next();
         } else {
@@ -599,40 +601,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 
 // -----------------------------------------------------------------------------
 
-// Instantiations: (DCT_SPLIT, DCT_LEN, GATHER) x FULL x TILE x CLIPS for float input; PCM16 input
-// (always clips, tile epilogue) for the reference's shape (13 x 40) only.
+// Instantiations: (DCT_SPLIT, DCT_LEN, GATHER) x FLEN x TILE x CLIPS for float input; PCM16 input (always clips, tile
+// epilogue) for the reference's shape (13 x 40) only.  FLEN = 400 (the reference's framing, -5 % in clip mode) exists for the
+// shapes of BASELINE configs 4 and 5; other frame lengths below 512 take the run-time predicate (FLEN = 0).
 #define DSP_FOR_SHAPES(X) X(4, 10, 3) X(4, 10, 6) X(4, 16, 3) X(4, 16, 6) X(2, 20, 3) X(2, 20, 6)
 
 static size_t lds_bytes(bool tile) { return (size_t)4 * (LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0)); }
 
+template <int S, int L, int G>
+constexpr bool kHas400 = (S == 4 && L == 10 && G == 3) || (S == 2 && L == 20 && G == 3);
+
+// 512 -> 512, 400 -> 400 where instantiated, anything else -> 0 (run-time predicate)
+template <int S, int L, int G>
+static int flen_of(int frame_len) { return frame_len == 512 ? 512 : (frame_len == 400 && kHas400<S, L, G> ? 400 : 0); }
+
+template <int S, int L, int G, int FLEN, int IN, int TILE>
+static void launch_flen(const Mfcc512Args &args, bool clips, dim3 g, dim3 b, size_t lds, hipStream_t stream)
+{
+    if (IN == 0 && !clips) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, FLEN, 0, TILE, false>), g, b, lds, stream, args);
+    else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, FLEN, IN, TILE, true>), g, b, lds, stream, args);
+}
+
 template <int S, int L, int G, int IN, int TILE>
-static hipError_t launch_one(const Mfcc512Args &args, bool full, bool clips, int blocks, hipStream_t stream)
+static hipError_t launch_one(const Mfcc512Args &args, bool clips, int blocks, hipStream_t stream)
 {
     const size_t lds = lds_bytes(TILE);
     const dim3 g(blocks), b(256);
-    if (IN == 0 && !clips) {
-        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true, 0, TILE, false>), g, b, lds, stream, args);
-        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false, 0, TILE, false>), g, b, lds, stream, args);
-    } else {
-        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true, IN, TILE, true>), g, b, lds, stream, args);
-        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false, IN, TILE, true>), g, b, lds, stream, args);
-    }
+    const int flen = flen_of<S, L, G>(args.frame_len);
+    if (flen == 512) launch_flen<S, L, G, 512, IN, TILE>(args, clips, g, b, lds, stream);
+    else if (flen == 400) { if constexpr (kHas400<S, L, G>) launch_flen<S, L, G, 400, IN, TILE>(args, clips, g, b, lds, stream); }
+    else launch_flen<S, L, G, 0, IN, TILE>(args, clips, g, b, lds, stream);
     return hipGetLastError();
 }
 
 hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream)
 {
-    const bool full = args.frame_len == 512;
     if (args.frames_per_clip <= 0 || args.chunk != args.frames_per_clip || args.log_mode != 0 || args.in_kind != 0 || !args.pool.labels ||
         args.pool.svm.n_features != 2 * args.n_mfcc || args.pool.svm.n_features > 64)
         return hipErrorInvalidConfiguration;
     const size_t lds = lds_bytes(true);
     const dim3 g(blocks), b(256);
-#define DSP_LAUNCH_POOL(S, L, G)                                                                                        \
-    if (dct_split == S && dct_len == L && gather == G) {                                                                \
-        if (full) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, true, 0, 1, true, true>), g, b, lds, stream, args);  \
-        else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, false, 0, 1, true, true>), g, b, lds, stream, args);      \
-        return hipGetLastError();                                                                                       \
+#define DSP_LAUNCH_POOL(S, L, G)                                                                                            \
+    if (dct_split == S && dct_len == L && gather == G) {                                                                    \
+        const int flen = flen_of<S, L, G>(args.frame_len);                                                                  \
+        if (flen == 512) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 512, 0, 1, true, true>), g, b, lds, stream, args); \
+        else if (flen == 400) {                                                                                             \
+            if constexpr (kHas400<S, L, G>) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 400, 0, 1, true, true>), g, b, lds, stream, args); \
+        } else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 0, 0, 1, true, true>), g, b, lds, stream, args);          \
+        return hipGetLastError();                                                                                           \
     }
     DSP_FOR_SHAPES(DSP_LAUNCH_POOL)
 #undef DSP_LAUNCH_POOL
@@ -642,20 +658,19 @@ hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_l
 hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks,
                           hipStream_t stream, bool tile)
 {
-    const bool full = args.frame_len == 512;
     const bool clips = args.frames_per_clip > 0;
     if (tile && (args.log_mode != 0 || args.chunk % 8 != 0)) return hipErrorInvalidConfiguration;
     if (args.in_kind != 0) {
         if (!(dct_split == 4 && dct_len == 10 && gather == 3) || !tile || !clips) return hipErrorInvalidConfiguration;
-        if (args.in_kind == 1) return launch_one<4, 10, 3, 1, 1>(args, full, true, blocks, stream);
-        if (args.in_kind == 2) return launch_one<4, 10, 3, 2, 1>(args, full, true, blocks, stream);
-        if (args.in_kind == 3) return launch_one<4, 10, 3, 3, 1>(args, full, true, blocks, stream);
+        if (args.in_kind == 1) return launch_one<4, 10, 3, 1, 1>(args, true, blocks, stream);
+        if (args.in_kind == 2) return launch_one<4, 10, 3, 2, 1>(args, true, blocks, stream);
+        if (args.in_kind == 3) return launch_one<4, 10, 3, 3, 1>(args, true, blocks, stream);
         return hipErrorInvalidConfiguration;
     }
 #define DSP_LAUNCH(S, L, G)                                                                  \
     if (dct_split == S && dct_len == L && gather == G)                                       \
-        return tile ? launch_one<S, L, G, 0, 1>(args, full, clips, blocks, stream)           \
-                    : launch_one<S, L, G, 0, 0>(args, full, clips, blocks, stream);
+        return tile ? launch_one<S, L, G, 0, 1>(args, clips, blocks, stream)                 \
+                    : launch_one<S, L, G, 0, 0>(args, clips, blocks, stream);
     DSP_FOR_SHAPES(DSP_LAUNCH)
 #undef DSP_LAUNCH
     return hipErrorInvalidConfiguration;
@@ -687,8 +702,8 @@ static int occupancy_one(bool full)
 {
     int n = 0;
     const size_t lds = lds_bytes(TILE);
-    hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, true, 0, TILE, false>, 256, lds)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, false, 0, TILE, false>, 256, lds);
+    hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, 512, 0, TILE, false>, 256, lds)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, 0, 0, TILE, false>, 256, lds);
     return e == hipSuccess && n > 0 ? n : 4;
 }
 
