@@ -151,7 +151,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         what = f"BASELINE configs[3] per-GPU share: {n} x 1 s 16 kHz fp32 clips, frame 400 / hop 160 -> [98][13] per clip"
         kernel = "mfcc512_wave_kernel"
     else:
-        n = args.clips or 32768
+        n = args.clips or 49152
         clips = (torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1) * 0.05
         # every fourth clip carries a call-like burst pattern that has midpoints and fires the rule (tests/signals.py
         # scrub_a, label 1 in the reference): clips without midpoints leave the tail kernel early, so an all-noise batch
@@ -164,7 +164,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         units, unit, bytes_per = n, "clips/s", 64_000 + 4
         what = (f"{n} x 1 s 16 kHz fp32 clips (25 % with a call-like burst pattern, label 1) through classify() "
                 "(2 x IIR, 2 x spectrogram, rule), bit-exact with the reference")
-        kernel = "iir2_split_kernel + spectrogram_kernel x2 + classify_tail_kernel"
+        kernel = "iir2_split_kernel + spectrogram_kernel x2 + classify_midpoints_kernel + classify_bands_kernel"
     for _ in range(max(1, args.warmup // 4)):
         step()
     torch.cuda.synchronize()

@@ -467,7 +467,7 @@ struct ClassifyCtx {
     // workspace for one sub-batch
     float *d_x = nullptr, *d_bp = nullptr, *d_mp = nullptr, *d_sbp = nullptr, *d_smp = nullptr;
     float *d_mean_bp = nullptr, *d_mean_mp = nullptr;      // spectrogram segment means, written by the IIR kernel
-    int *d_labels = nullptr;
+    int *d_labels = nullptr, *d_hits = nullptr;            // d_hits: work list of clips with midpoints
     dsp::ClassifyTrace *d_trace = nullptr;
     long cap_clips = 0;
     int cap_n = 0;
@@ -500,10 +500,10 @@ int cls_reserve(long clips, int n)
 {
     if (clips <= g_cls.cap_clips && n <= g_cls.cap_n) return DSP_OK;
     for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_bp, (void *)g_cls.d_mp, (void *)g_cls.d_sbp, (void *)g_cls.d_smp,
-                    (void *)g_cls.d_mean_bp, (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_trace})
+                    (void *)g_cls.d_mean_bp, (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_hits, (void *)g_cls.d_trace})
         if (p) hipFree(p);
     g_cls.d_x = g_cls.d_bp = g_cls.d_mp = g_cls.d_sbp = g_cls.d_smp = g_cls.d_mean_bp = g_cls.d_mean_mp = nullptr;
-    g_cls.d_labels = nullptr; g_cls.d_trace = nullptr;
+    g_cls.d_labels = g_cls.d_hits = nullptr; g_cls.d_trace = nullptr;
     g_cls.cap_clips = 0; g_cls.cap_n = 0;
     const size_t sig = (size_t)clips * n * sizeof(float);
     const size_t spec = (size_t)clips * dsp::kSpecBins * std::max(1, spec_bins(n)) * sizeof(float);
@@ -515,6 +515,7 @@ int cls_reserve(long clips, int n)
     DSP_HIP(hipMalloc(&g_cls.d_mean_bp, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_mean_mp, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_labels, (size_t)clips * sizeof(int)));
+    DSP_HIP(hipMalloc(&g_cls.d_hits, (size_t)(clips + 1) * sizeof(int)));
     DSP_HIP(hipMalloc(&g_cls.d_trace, (size_t)clips * sizeof(dsp::ClassifyTrace)));
     g_cls.cap_clips = clips; g_cls.cap_n = n;
     return DSP_OK;
@@ -535,14 +536,16 @@ int cls_run(const float *d_x, long clips, int n, long stride, hipStream_t st)
     const dsp::IirCoef bp = coef_f32(3000, 7500), mp = coef_f32(1000, 3000);   // classifier.cpp:14-19, 438-442
     DSP_HIP(dsp::launch_iir_f32(d_x, clips, n, stride, bp, g_cls.d_bp, mp, g_cls.d_mp, st, g_cls.d_mean_bp, g_cls.d_mean_mp));
     // the IIR kernel writes with the input's row stride; the workspace rows are n long
-    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_bp, clips, n, stride, g_cls.d_tab, g_cls.d_sbp, st, g_cls.d_mean_bp));
+    // midpoints first (1000-3000 Hz map); the 3000-7500 Hz spectrogram and its band sums only for clips that have midpoints
     DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_mp, clips, n, stride, g_cls.d_tab, g_cls.d_smp, st, g_cls.d_mean_mp));
-    DSP_HIP(dsp::launch_classify_tail(g_cls.d_sbp, g_cls.d_smp, clips, n, 16000, g_cls.d_tab, g_cls.d_labels, g_cls.d_trace, st));
+    DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_smp, clips, n, 16000, g_cls.d_tab, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st));
+    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_bp, clips, n, stride, g_cls.d_tab, g_cls.d_sbp, st, g_cls.d_mean_bp, g_cls.d_trace));
+    DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st));
     return DSP_OK;
 }
 
 // clips per pass through the workspace (270 KB per 1 s clip): large enough that lane-per-clip IIR waves fill the chip
-constexpr long kClsSubBatch = 32768;
+constexpr long kClsSubBatch = 49152;
 
 }  // namespace
 

@@ -187,7 +187,6 @@ __global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict
 {
     __shared__ float tin[2][64 * IIR_LD];
     __shared__ float vbuf[2][2][64 * IIR_LD];          // [filter][tile parity]
-    __shared__ float ytile[2][64 * IIR_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f = wv & 1;                               // filter
@@ -272,8 +271,10 @@ __global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict
             }
         } else if (s >= 1) {
             const int t0 = (s - 1) * IIR_TS, cols = tile_cols(s - 1);
-            const float *vin = vbuf[f][(s - 1) & 1];
-            float *yo = ytile[f];
+            // y replaces v in place (each lane rewrites the row it has just read), so the taps wave needs no tile of its own:
+            // 6 tiles = 50 KB per block, three blocks per CU
+            float *yo = vbuf[f][(s - 1) & 1];
+            const float *vin = yo;
             auto taps = [&](float v, int sidx) {                     // classifier.cpp:207-216, then the segment sums
                 float o = c.b[0] * v;
 #pragma unroll
@@ -402,9 +403,11 @@ __device__ __forceinline__ void butterfly(cpx &a, cpx &b, const cpx u)
     a.y = a.y + t2;
 }
 
+// gate (optional): per-clip records whose n_midpoints == 0 mark clips whose spectrogram will never be read
+// (classify() sums this map only around midpoints): their frames are skipped.
 __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restrict__ y, long n_clips, int n, long stride,
                                                           const SpecTables *__restrict__ tab, float *__restrict__ sxx, int T,
-                                                          const float *__restrict__ means)
+                                                          const float *__restrict__ means, const ClassifyTrace *__restrict__ gate)
 {
     __shared__ float2 lds[4][kSpecSeg];
     // PSD columns of 16 consecutive frames are collected here and stored as 64-byte row segments: the output is
@@ -463,7 +466,28 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
     const int n_here = (int)(total - gid0 < 64 ? total - gid0 : 64);
     long clip = gid0 / T;
     int t = (int)(gid0 - clip * T);
+    unsigned done = 0;                                     // columns of the current 16-frame PSD tile that were computed
     for (int f = 0; f < n_here; ++f) {
+        if (gate && gate[clip].n_midpoints == 0) {         // wave-uniform: nothing downstream reads this clip's map
+            if ((f & 15) == 15 || f == n_here - 1) {
+                if (done) {
+                    const int col = lane & 15, ff = (f & ~15) + col;
+                    if ((done >> col) & 1) {
+                        const long g = gid0 + ff;
+                        const long cl = g / T;
+                        const int tt = (int)(g - cl * T);
+                        float *out = sxx + cl * (long)kSpecBins * T + tt;
+                        for (int row = lane >> 4; row < kSpecBins; row += 4) out[(long)row * T] = tile[row * 17 + col];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                done = 0;
+            }
+            if (++t == T) { t = 0; ++clip; }
+            continue;
+        }
         const float mean_f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), f));
         const float *seg = y + clip * stride + (long)t * kSpecHop;
         cpx v[4];
@@ -501,10 +525,11 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        done |= 1u << (f & 15);
         if ((f & 15) == 15 || f == n_here - 1) {
             // flush frames [f & ~15, f]: lane -> column lane % 16 (one frame, one division), rows lane / 16 + 4 k
             const int col = lane & 15, ff = (f & ~15) + col;
-            if (ff <= f) {
+            if ((done >> col) & 1) {
                 const long g = gid0 + ff;
                 const long cl = g / T;
                 const int tt = (int)(g - cl * T);
@@ -514,18 +539,19 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            done = 0;
         }
         if (++t == T) { t = 0; ++clip; }
     }
 }
 
 hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
-                                  float *sxx, hipStream_t stream, const float *means)
+                                  float *sxx, hipStream_t stream, const float *means, const ClassifyTrace *gate)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0 || T <= 0) return hipSuccess;
     const long total = n_clips * T;
-    hipLaunchKernelGGL(spectrogram_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means);
+    hipLaunchKernelGGL(spectrogram_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, gate);
     return hipGetLastError();
 }
 
@@ -582,27 +608,64 @@ __device__ float sum_intense_dev(float lower, float upper, float half_range, int
 // sum_intense for a whole wavefront: the cells are fetched 64 at a time in the reference's (row, column) order, then
 // added ONE BY ONE in that order (v_readlane + add: the float sum's order is part of the result).  NaN cells add 0.0f,
 // which leaves a float sum unchanged bit for bit, exactly like the reference's skip.  Returns the same value in every lane.
-__device__ float sum_intense_wave(float lower, float upper, float half_range, int fs, int T, const float *db, float midpoint)
+// The reference's index searches ("while (i < n && key(i) < lo) ++i" and its mirror image) for a whole wavefront: 64
+// candidates per step, the exit index is the first (last) lane whose test fails -- the same comparisons on the same
+// floats, without a float division per loop trip on a single lane.  All 64 lanes must be active.
+template <class Pred>
+__device__ __forceinline__ int wave_first_false(int count, Pred pred)
+{
+    const int lane = threadIdx.x & 63;
+    for (int b = 0; b < count; b += 64) {
+        const int i = b + lane;
+        const unsigned long long m = __ballot(i < count && !pred(i));
+        if (m) return b + __ffsll((long long)m) - 1;
+    }
+    return count;
+}
+template <class Pred>
+__device__ __forceinline__ int wave_last_false(int count, Pred pred)
+{
+    const int lane = threadIdx.x & 63;
+    for (int b = ((count - 1) / 64) * 64; b >= 0; b -= 64) {
+        const int i = b + lane;
+        const unsigned long long m = __ballot(i < count && !pred(i));
+        if (m) return b + 63 - __clzll((long long)m);
+    }
+    return -1;
+}
+
+__device__ float sum_intense_wave(float lower, float upper, float half_range, int fs, int T, const float *db, float midpoint,
+                                  float *scratch /* LDS, 128 floats of this wavefront */)
 {
     auto freq = [&](int k) { return (float)k * (float)fs / (float)kSpecSeg; };
     auto time = [&](int t) { return ((float)(t * kSpecHop + kSpecSeg / 2)) / (float)fs; };
-    int f0 = 0;
-    while (f0 < kSpecBins && freq(f0) < lower) ++f0;
-    int f1 = kSpecBins - 1;
-    while (f1 >= 0 && freq(f1) > upper) --f1;
+    const float t_lo = midpoint - half_range, t_hi = midpoint + half_range;
+    int f0 = wave_first_false(kSpecBins, [&](int k) { return freq(k) < lower; });
+    int f1 = wave_last_false(kSpecBins, [&](int k) { return freq(k) > upper; });
     if (f0 >= kSpecBins) f0 = kSpecBins - 1;
     if (f1 < 0) f1 = 0;
     if (f0 > f1) { int x = f0; f0 = f1; f1 = x; }
-    int t0 = 0;
-    while (t0 < T && time(t0) < midpoint - half_range) ++t0;
-    int t1 = T - 1;
-    while (t1 >= 0 && time(t1) > midpoint + half_range) --t1;
+    int t0 = wave_first_false(T, [&](int t) { return time(t) < t_lo; });
+    int t1 = wave_last_false(T, [&](int t) { return time(t) > t_hi; });
     if (t0 >= T) t0 = T - 1;
     if (t1 < 0) t1 = 0;
     if (t0 > t1) { int x = t0; t0 = t1; t1 = x; }
     const int lane = threadIdx.x & 63;
     const int W = t1 - t0 + 1, N = (f1 - f0 + 1) * W;
     float total = 0.0f;
+    auto chain = [&](float a) {                              // 64 adds in lane order
+#pragma unroll
+        for (int l = 0; l < 64; ++l) total = total + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), l));
+    };
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // Only 7-18 % of the cells of a map are kept; the others are NaN and the reference skips them.  The kept cells are
+    // packed, still in (row, column) order, into the wavefront's scratch (ballot + mbcnt ranks) and the add chain runs
+    // once per 64 KEPT cells instead of once per 64 cells.  Padding lanes hold 0.0f, and x + 0.0f == x bit for bit.
+    int pend = 0;                                            // wave-uniform: cells waiting in scratch
     for (int e0 = 0; e0 < N; e0 += 64) {
         const int e = e0 + lane;
         float v = 0.0f;
@@ -611,9 +674,25 @@ __device__ float sum_intense_wave(float lower, float upper, float half_range, in
             v = db[(long)(f0 + r) * T + t0 + cidx];
             if (isnan(v)) v = 0.0f;
         }
-        // lanes past the end hold 0.0f: adding them changes nothing, so every chunk is a straight line of 64 adds
-#pragma unroll
-        for (int l = 0; l < 64; ++l) total = total + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+        const bool kept = v != 0.0f;                         // kept cells lie in (0.65, 0.80)
+        const unsigned long long m = __ballot(kept);
+        if (m == 0) continue;
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (kept) scratch[pend + rank] = v;
+        pend += __popcll(m);
+        if (pend >= 64) {
+            wave_sync();
+            const float a = scratch[lane];
+            const float rest = lane < pend - 64 ? scratch[64 + lane] : 0.0f;
+            wave_sync();
+            scratch[lane] = rest;
+            chain(a);
+            pend -= 64;
+        }
+    }
+    if (pend > 0) {
+        wave_sync();
+        chain(lane < pend ? scratch[lane] : 0.0f);
     }
     return total;
 }
@@ -642,46 +721,57 @@ hipError_t launch_spec_threshold(SpecTables *tables, hipStream_t stream)
     return hipGetLastError();
 }
 
-// USE_LDS: the map fits the LDS budget (129 x T <= kTailLdsCells): the PSD cells of the clip are read ONCE into
-// registers (kTailPerThread per thread) and the map is written to LDS; otherwise the map is rebuilt in place in HBM.
-constexpr int kTailPerThread = (kTailLdsCells + 255) / 256;
-
-template <bool USE_LDS>
-__global__ __launch_bounds__(256) void classify_tail_kernel(float *__restrict__ sxx_bp, const float *__restrict__ sxx_mp,
-                                                            long n_clips, int T, int fs, const SpecTables *__restrict__ tab,
-                                                            int *__restrict__ labels, ClassifyTrace *__restrict__ trace)
+// classify() after the spectrograms, as two kernels so that the band-pass spectrogram can be skipped for clips
+// without midpoints:
+//   classify_midpoints_kernel  (midpoint spectrogram only)  time bins above 70 dB -> blob times -> greedy clusters ->
+//                              midpoints, written to the clip's ClassifyTrace record; label 0 when there are none
+//   classify_bands_kernel      (band-pass spectrogram, clips with midpoints only)  dB map, normalisation, the three
+//                              band sums per midpoint in the reference's order, the rule
+__global__ __launch_bounds__(256) void classify_midpoints_kernel(const float *__restrict__ sxx_mp, long n_clips, int T, int fs,
+                                                                 const SpecTables *__restrict__ tab, int *__restrict__ labels,
+                                                                 ClassifyTrace *__restrict__ trace, int *__restrict__ hits)
 {
-    extern __shared__ float map_lds[];
     __shared__ float blob[1024];
     __shared__ int col_any[1024];
-    __shared__ float red_mn[4], red_mx[4];
     const long clip = blockIdx.x;
     if (clip >= n_clips) return;
     const int tid = threadIdx.x;
     const int cells = kSpecBins * T;
-    float *bp_g = sxx_bp + clip * (long)cells;
     const float *mp = sxx_mp + clip * (long)cells;
-    __shared__ float mids[kMaxMidpoints];
-    __shared__ int n_mids;
     for (int j = tid; j < T; j += 256) col_any[j] = 0;
+    // a whole record per clip: band sums the rule never reaches (no midpoints, or after the first hit) read as 0
+    if (tid < kMaxMidpoints * 3) (&trace[clip].sums[0][0])[tid] = 0.0f;
+    else trace[clip].midpoints[tid - kMaxMidpoints * 3] = 0.0f;          // 256 threads = 3 x 64 sums + 64 midpoints
     __syncthreads();
-
-    // ---- midpoint map first: keep > 70 dB, time bins with any cell   classifier.cpp:457-518
+    // keep > 70 dB, time bins with any cell   classifier.cpp:457-518.  Eight loads in flight per thread.
     {
         const float keep_min = tab->mp_keep_min;
-        int col = tid % T;
-        const int step = 256 % T;
-        for (int i = tid; i < cells; i += 256) {
-            if (mp[i] >= keep_min) col_any[col] = 1;        // same value from every writer
-            col += step;
-            if (col >= T) col -= T;
+        constexpr int B = 8;
+        for (int i0 = tid; i0 < cells; i0 += 256 * B) {
+            float v[B];
+#pragma unroll
+            for (int u = 0; u < B; ++u) v[u] = i0 + 256 * u < cells ? __builtin_nontemporal_load(mp + i0 + 256 * u) : 0.0f;
+#pragma unroll
+            for (int u = 0; u < B; ++u)
+                if (v[u] >= keep_min) col_any[(i0 + 256 * u) % T] = 1;    // same value from every writer
         }
     }
     __syncthreads();
+    if (tid >= 64) return;
+    // blob times of the flagged bins, in order (ballot ranks), then the greedy clustering on one lane
+    int nb = 0;
+    for (int j0 = 0; j0 < T; j0 += 64) {
+        const int j = j0 + tid;
+        const bool flag = j < T && col_any[j] != 0;
+        const unsigned long long m = __ballot(flag);
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (flag) blob[nb + rank] = ((float)(j * kSpecHop + kSpecSeg / 2)) / (float)fs;
+        nb += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (tid == 0) {
-        int nb = 0;
-        for (int j = 0; j < T && nb < 1024; ++j)
-            if (col_any[j]) blob[nb++] = ((float)(j * kSpecHop + kSpecSeg / 2)) / (float)fs;
         // greedy clustering, classifier.cpp:522-574
         const float tol = 0.05f, min_dur = 0.15f;
         int count = 0, i0 = 0;
@@ -692,20 +782,36 @@ __global__ __launch_bounds__(256) void classify_tail_kernel(float *__restrict__ 
             if (dur >= min_dur) {
                 float sm = 0.0f;
                 for (int k = i0; k <= i1; ++k) sm = sm + blob[k];
-                if (count < kMaxMidpoints) mids[count] = sm / (float)(i1 - i0 + 1);
+                if (count < kMaxMidpoints) trace[clip].midpoints[count] = sm / (float)(i1 - i0 + 1);
                 ++count;
             }
             i0 = i1 + 1;
         }
         if (count > kMaxMidpoints) count = kMaxMidpoints;
-        n_mids = count;
-        if (trace) trace[clip].n_midpoints = count;
+        trace[clip].n_midpoints = count;
         if (count == 0) labels[clip] = 0;                   // classifier.cpp:93-114: no midpoint can fire the rule
+        else hits[1 + atomicAdd(hits, 1)] = (int)clip;      // work list of the band kernels, any order
     }
-    __syncthreads();
-    // no midpoints: the band-pass dB map would never be read (the reference builds it anyway; the label and the trace
-    // are the same), so the block stops here -- the whole map pass below is paid only by clips that have midpoints
-    if (n_mids == 0) return;
+}
+
+// USE_LDS: the map fits the LDS budget (129 x T <= kTailLdsCells): the PSD cells of the clip are read ONCE into
+// registers (kTailPerThread per thread) and the map is written to LDS; otherwise the map is rebuilt in place in HBM.
+constexpr int kTailPerThread = (kTailLdsCells + 255) / 256;
+
+template <bool USE_LDS>
+__device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, long clip, int T, int fs, int *__restrict__ labels,
+                                                    ClassifyTrace *__restrict__ trace, float *map_lds)
+{
+    __shared__ float red_mn[4], red_mx[4];
+    __shared__ float mids[kMaxMidpoints];
+#ifndef DSP_BANDS_DIAG
+#define DSP_BANDS_DIAG 0
+#endif
+    int n_mids = trace[clip].n_midpoints;
+    const int tid = threadIdx.x;
+    const int cells = kSpecBins * T;
+    float *bp_g = sxx_bp + clip * (long)cells;
+    if (tid < n_mids) mids[tid] = trace[clip].midpoints[tid];
 
     // ---- band-pass map: dB, clip min/max, normalise, keep (0.65, 0.80)  classifier.cpp:35-80
     // to_db is monotone in the PSD value s, so the clip's dB minimum / maximum are to_db of the smallest / largest
@@ -741,15 +847,44 @@ __global__ __launch_bounds__(256) void classify_tail_kernel(float *__restrict__ 
     auto keep = [&](float sv) {
         float v = NAN;
         if (sv >= s_lo && sv <= s_hi) {                 // (false for s <= 0 and NaN)
+            if (DSP_BANDS_DIAG & 2) return sv;
             v = (to_db(sv) - mn) / (mx - mn);
             v = (v > lo_thr && v < hi_thr) ? v : NAN;
         }
         return v;
     };
+    __shared__ float2 pend_buf[4][64];                       // per wavefront: (cell index, s) waiting for its log10
     if (USE_LDS) {
+        // Cells outside the widened band are NaN at once.  The others (7-18 % of a map) are queued per wavefront and
+        // evaluated up to 64 at a time, so a float64 log10 is paid per ~64 candidates and not per 64 cells.
+        float2 *pb = pend_buf[tid >> 6];
+        const int lane = tid & 63;
+        auto wave_sync = [] {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        auto drain = [&](int count) {
+            wave_sync();
+            if (lane < count) { const float2 e = pb[lane]; map_lds[__float_as_int(e.x)] = keep(e.y); }
+            wave_sync();
+        };
+        int pend = 0;                                        // wave-uniform
 #pragma unroll
-        for (int k = 0; k < kTailPerThread; ++k)
-            if (tid + 256 * k < cells) map_lds[tid + 256 * k] = keep(cell[k]);
+        for (int k = 0; k < kTailPerThread; ++k) {
+            const int idx = tid + 256 * k;
+            const float sv = cell[k];
+            const bool cand = idx < cells && sv >= s_lo && sv <= s_hi;
+            if (idx < cells && !cand) map_lds[idx] = NAN;
+            const unsigned long long m = __ballot(cand);
+            if (m == 0) continue;
+            const int add = __popcll(m);
+            if (pend + add > 64) { drain(pend); pend = 0; }
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (cand) pb[pend + rank] = make_float2(__int_as_float(idx), sv);
+            pend += add;
+        }
+        drain(pend);
     } else {
         for (int i = tid; i < cells; i += 256) bp_g[i] = keep(bp_g[i]);
     }
@@ -758,19 +893,18 @@ __global__ __launch_bounds__(256) void classify_tail_kernel(float *__restrict__ 
     // classifier.cpp:93-114: per midpoint the three band sums, one wavefront each (the fourth idles), then the rule
     __shared__ float band[3];
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int count = n_mids;
+    float *scratch = reinterpret_cast<float *>(pend_buf[wv]);       // free again after the barrier above
     int hit = 0;
-    for (int k = 0; k < count; ++k) {
+    if (DSP_BANDS_DIAG & 1) n_mids = 0;
+    if (DSP_BANDS_DIAG & 4) { if (tid == 0) labels[clip] = bp[5] > 0; return; }
+    for (int k = 0; k < n_mids; ++k) {
         const float mid = mids[k];
-        if (wv == 0) { const float v = sum_intense_wave(5000, 7000, 0.18f, fs, T, bp, mid); if ((tid & 63) == 0) band[0] = v; }
-        if (wv == 1) { const float v = sum_intense_wave(2500, 5000, 0.05f, fs, T, bp, mid); if ((tid & 63) == 0) band[1] = v; }
-        if (wv == 2) { const float v = sum_intense_wave(500, 2500, 0.18f, fs, T, bp, mid); if ((tid & 63) == 0) band[2] = v; }
+        if (wv == 0) { const float v = sum_intense_wave(5000, 7000, 0.18f, fs, T, bp, mid, scratch); if ((tid & 63) == 0) band[0] = v; }
+        if (wv == 1) { const float v = sum_intense_wave(2500, 5000, 0.05f, fs, T, bp, mid, scratch); if ((tid & 63) == 0) band[1] = v; }
+        if (wv == 2) { const float v = sum_intense_wave(500, 2500, 0.18f, fs, T, bp, mid, scratch); if ((tid & 63) == 0) band[2] = v; }
         __syncthreads();
         const float above = band[0], middle = band[1], below = band[2];
-        if (tid == 0 && trace) {
-            trace[clip].midpoints[k] = mid;
-            trace[clip].sums[k][0] = above; trace[clip].sums[k][1] = middle; trace[clip].sums[k][2] = below;
-        }
+        if (tid == 0) { trace[clip].sums[k][0] = above; trace[clip].sums[k][1] = middle; trace[clip].sums[k][2] = below; }
         hit = (middle < 100 && above > 200 && below > 80) ? 1 : 0;
         __syncthreads();
         if (hit) break;                                      // uniform: every thread read the same three sums
@@ -778,18 +912,46 @@ __global__ __launch_bounds__(256) void classify_tail_kernel(float *__restrict__ 
     if (tid == 0) labels[clip] = hit;
 }
 
-hipError_t launch_classify_tail(float *sxx_bp, float *sxx_mp, long n_clips, int n, int fs, const SpecTables *tables, int *labels,
-                                ClassifyTrace *trace, hipStream_t stream)
+// Clips with midpoints come from the work list the midpoints kernel filled (hits[0] = count, then clip numbers): the
+// blocks of a fixed grid walk it, so the load is even over the XCDs whatever the positions of those clips in the batch
+// (workgroups go round-robin to the XCDs by block number: "one block per clip" left 6 of 8 XCDs idle for a batch with
+// every fourth clip positive).
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void classify_bands_kernel(float *__restrict__ sxx_bp, int T, int fs, int *__restrict__ labels,
+                                                             ClassifyTrace *__restrict__ trace, const int *__restrict__ hits)
+{
+    extern __shared__ float map_lds[];
+    const int count = hits[0];
+    for (int it = blockIdx.x; it < count; it += gridDim.x) {
+        classify_bands_clip<USE_LDS>(sxx_bp, hits[1 + it], T, fs, labels, trace, map_lds);
+        __syncthreads();                                     // the block's LDS is reused by the next clip
+    }
+}
+
+hipError_t launch_classify_midpoints(const float *sxx_mp, long n_clips, int n, int fs, const SpecTables *tables, int *labels,
+                                     ClassifyTrace *trace, int *hits, hipStream_t stream)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0) return hipSuccess;
-    if (T <= 0 || T > 1024) return hipErrorInvalidValue;
+    if (T <= 0 || T > 1024 || !trace || !hits) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(hits, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(classify_midpoints_kernel, dim3((unsigned)n_clips), dim3(256), 0, stream, sxx_mp, n_clips, T, fs, tables, labels, trace, hits);
+    return hipGetLastError();
+}
+
+hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, const int *hits,
+                                 hipStream_t stream)
+{
+    const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
+    if (n_clips <= 0) return hipSuccess;
+    if (T <= 0 || T > 1024 || !trace || !hits) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)(n_clips < 2048 ? n_clips : 2048);      // 256 CUs x 4 resident blocks x 2
     if (kSpecBins * T <= kTailLdsCells)
-        hipLaunchKernelGGL(classify_tail_kernel<true>, dim3((unsigned)n_clips), dim3(256), (size_t)kSpecBins * T * sizeof(float), stream, sxx_bp,
-                           sxx_mp, n_clips, T, fs, tables, labels, trace);
+        hipLaunchKernelGGL(classify_bands_kernel<true>, dim3(blocks), dim3(256), (size_t)kSpecBins * T * sizeof(float), stream, sxx_bp, T, fs,
+                           labels, trace, hits);
     else
-        hipLaunchKernelGGL(classify_tail_kernel<false>, dim3((unsigned)n_clips), dim3(256), 0, stream, sxx_bp, sxx_mp, n_clips, T, fs, tables,
-                           labels, trace);
+        hipLaunchKernelGGL(classify_bands_kernel<false>, dim3(blocks), dim3(256), 0, stream, sxx_bp, T, fs, labels, trace, hits);
     return hipGetLastError();
 }
 

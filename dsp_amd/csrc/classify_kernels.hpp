@@ -38,20 +38,26 @@ hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long strid
                                  hipStream_t stream);
 
 // sxx[c][129][T] (T = (n-256)/224+1) of clip rows y[c][0..n)
-// means (optional): segment means [c][T] already computed by launch_iir_f32
-hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
-                                  float *sxx, hipStream_t stream, const float *means = nullptr);
-
 struct ClassifyTrace {           // per clip, for parity tests
     int n_midpoints;
     float midpoints[kMaxMidpoints];
     float sums[kMaxMidpoints][3];
 };
 
-// labels[c] from the two spectrograms (band-pass 3000-7500 and 1000-3000), classifier.cpp:35-135.
-// Both sxx buffers are overwritten with their dB maps.  trace may be nullptr.
-hipError_t launch_classify_tail(float *sxx_bp, float *sxx_mp, long n_clips, int n, int fs, const SpecTables *tables, int *labels,
-                                ClassifyTrace *trace, hipStream_t stream);
+// means (optional): segment means [c][T] already computed by launch_iir_f32.  gate (optional): clips whose record has
+// n_midpoints == 0 are skipped (their map would never be read by the classify tail).
+hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
+                                  float *sxx, hipStream_t stream, const float *means = nullptr, const ClassifyTrace *gate = nullptr);
+
+
+// classify() after the spectrograms (classifier.cpp:35-135), two kernels: midpoints from the 1000-3000 Hz map (records in
+// `trace`, label 0 when there are none), then the band sums + rule from the 3000-7500 Hz map for the clips that have
+// midpoints (sxx_bp is overwritten with its dB map when it does not fit LDS).  `trace` is required (it carries the midpoints);
+// `hits` (1 + n_clips ints) is the work list between the two: hits[0] = clips with midpoints, then their numbers.
+hipError_t launch_classify_midpoints(const float *sxx_mp, long n_clips, int n, int fs, const SpecTables *tables, int *labels,
+                                     ClassifyTrace *trace, int *hits, hipStream_t stream);
+hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, const int *hits,
+                                 hipStream_t stream);
 // fills tables->mp_keep_min (once per context)
 hipError_t launch_spec_threshold(SpecTables *tables, hipStream_t stream);
 

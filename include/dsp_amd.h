@@ -161,7 +161,8 @@ int dsp_compute_spectrogram_f32(const float *signal, int signal_length, int fs,
 typedef struct dsp_classify_trace {
     int n_midpoints;
     float midpoints[64];
-    float sums[64][3];   /* above (5-7 kHz), middle (2.5-5 kHz), below (0.5-2.5 kHz) */
+    float sums[64][3];   /* above (5-7 kHz), middle (2.5-5 kHz), below (0.5-2.5 kHz); rows after the
+                          * first midpoint that fires the rule are 0 (the reference stops there)  */
 } dsp_classify_trace;
 
 /* classify() over n_clips clips of n samples (row stride in floats).  labels[n_clips];

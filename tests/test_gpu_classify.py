@@ -54,6 +54,20 @@ def test_batch_labels_midpoints_and_band_sums(dsp, golden):
         assert np.array_equal(sums[:k], osums[:k])                   # sum_intense x3, bit exact
 
 
+def test_band_pass_gating_is_invisible_in_a_shuffled_batch(dsp, golden):
+    """The 3000-7500 Hz spectrogram is skipped for clips without midpoints, frame by frame inside wavefronts that
+    straddle clips: every clip of a shuffled positive / negative mix must get the record it gets on its own."""
+    g = golden("classifier_ref.npz")
+    base = np.stack([g[f"{n}__input"] for n in CASES])
+    _, alone = dsp.classify_batch(base, with_trace=True)
+    want = [int(g[f"{n}__label"]) for n in CASES]
+    order = np.random.default_rng(11).integers(0, len(CASES), 300)
+    labels, trace = dsp.classify_batch(base[order], with_trace=True)
+    assert list(labels) == [want[i] for i in order]
+    for i, (mids, sums) in zip(order, trace):
+        assert np.array_equal(mids, alone[i][0]) and np.array_equal(sums, alone[i][1])
+
+
 def test_device_batch_and_ragged_batches(dsp, golden):
     import torch
     g = golden("classifier_ref.npz")
