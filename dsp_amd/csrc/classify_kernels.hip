@@ -403,11 +403,12 @@ __device__ __forceinline__ void butterfly(cpx &a, cpx &b, const cpx u)
     a.y = a.y + t2;
 }
 
-// gate (optional): per-clip records whose n_midpoints == 0 mark clips whose spectrogram will never be read
-// (classify() sums this map only around midpoints): their frames are skipped.
+// hits (optional): work list of the clips whose map is wanted (hits[0] = count, then clip numbers, as written by
+// classify_midpoints_kernel): frame slot s of the launch is time bin s % T of clip hits[1 + s / T], so the wanted clips
+// are packed into the first wavefronts whatever their position in the batch, and the others exit at once.
 __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restrict__ y, long n_clips, int n, long stride,
                                                           const SpecTables *__restrict__ tab, float *__restrict__ sxx, int T,
-                                                          const float *__restrict__ means, const ClassifyTrace *__restrict__ gate)
+                                                          const float *__restrict__ means, const int *__restrict__ hits)
 {
     __shared__ float2 lds[4][kSpecSeg];
     // PSD columns of 16 consecutive frames are collected here and stored as 64-byte row segments: the output is
@@ -417,23 +418,27 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float2 *buf = lds[wib];
     float *tile = psd_tile[wib];
-    const long total = n_clips * T;
+    const long total = (hits ? (long)hits[0] : n_clips) * T;
     const long gid0 = ((long)blockIdx.x * 4 + wib) * 64;
     if (gid0 >= total) return;
+    auto clip_of = [&](long slot) { return hits ? (long)hits[1 + slot] : slot; };
 
     // ---- phase 1: sequential mean of this lane's frame
     float mean = 0.0f;
-    if (means) {                      // already summed, in the same order, by the IIR kernel's lanes
-        if (gid0 + lane < total) mean = means[gid0 + lane];
-    } else {
+    {
         const long gid = gid0 + lane;
         if (gid < total) {
-            const long clip = gid / T;
-            const int t = (int)(gid - clip * T);
-            const float *seg = y + clip * stride + (long)t * kSpecHop;
-            float sum = 0.0f;
-            for (int i = 0; i < kSpecSeg; ++i) sum = sum + seg[i];
-            mean = sum / (float)kSpecSeg;
+            const long slot = gid / T;
+            const int t = (int)(gid - slot * T);
+            const long clip = clip_of(slot);
+            if (means) {              // already summed, in the same order, by the IIR kernel's lanes
+                mean = means[clip * T + t];
+            } else {
+                const float *seg = y + clip * stride + (long)t * kSpecHop;
+                float sum = 0.0f;
+                for (int i = 0; i < kSpecSeg; ++i) sum = sum + seg[i];
+                mean = sum / (float)kSpecSeg;
+            }
         }
     }
 
@@ -464,30 +469,10 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
 
     // ---- phase 2
     const int n_here = (int)(total - gid0 < 64 ? total - gid0 : 64);
-    long clip = gid0 / T;
-    int t = (int)(gid0 - clip * T);
-    unsigned done = 0;                                     // columns of the current 16-frame PSD tile that were computed
+    long slot = gid0 / T;
+    int t = (int)(gid0 - slot * T);
+    long clip = clip_of(slot);
     for (int f = 0; f < n_here; ++f) {
-        if (gate && gate[clip].n_midpoints == 0) {         // wave-uniform: nothing downstream reads this clip's map
-            if ((f & 15) == 15 || f == n_here - 1) {
-                if (done) {
-                    const int col = lane & 15, ff = (f & ~15) + col;
-                    if ((done >> col) & 1) {
-                        const long g = gid0 + ff;
-                        const long cl = g / T;
-                        const int tt = (int)(g - cl * T);
-                        float *out = sxx + cl * (long)kSpecBins * T + tt;
-                        for (int row = lane >> 4; row < kSpecBins; row += 4) out[(long)row * T] = tile[row * 17 + col];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-                done = 0;
-            }
-            if (++t == T) { t = 0; ++clip; }
-            continue;
-        }
         const float mean_f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), f));
         const float *seg = y + clip * stride + (long)t * kSpecHop;
         cpx v[4];
@@ -525,33 +510,31 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        done |= 1u << (f & 15);
         if ((f & 15) == 15 || f == n_here - 1) {
             // flush frames [f & ~15, f]: lane -> column lane % 16 (one frame, one division), rows lane / 16 + 4 k
             const int col = lane & 15, ff = (f & ~15) + col;
-            if ((done >> col) & 1) {
+            if (ff <= f) {
                 const long g = gid0 + ff;
-                const long cl = g / T;
-                const int tt = (int)(g - cl * T);
-                float *out = sxx + cl * (long)kSpecBins * T + tt;
+                const long sl = g / T;
+                const int tt = (int)(g - sl * T);
+                float *out = sxx + clip_of(sl) * (long)kSpecBins * T + tt;
                 for (int row = lane >> 4; row < kSpecBins; row += 4) out[(long)row * T] = tile[row * 17 + col];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            done = 0;
         }
-        if (++t == T) { t = 0; ++clip; }
+        if (++t == T) { t = 0; ++slot; if (f + 1 < n_here) clip = clip_of(slot); }
     }
 }
 
 hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
-                                  float *sxx, hipStream_t stream, const float *means, const ClassifyTrace *gate)
+                                  float *sxx, hipStream_t stream, const float *means, const int *hits)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0 || T <= 0) return hipSuccess;
     const long total = n_clips * T;
-    hipLaunchKernelGGL(spectrogram_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, gate);
+    hipLaunchKernelGGL(spectrogram_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits);
     return hipGetLastError();
 }
 

@@ -44,10 +44,10 @@ struct ClassifyTrace {           // per clip, for parity tests
     float sums[kMaxMidpoints][3];
 };
 
-// means (optional): segment means [c][T] already computed by launch_iir_f32.  gate (optional): clips whose record has
-// n_midpoints == 0 are skipped (their map would never be read by the classify tail).
+// means (optional): segment means [c][T] already computed by launch_iir_f32.  hits (optional, device): work list
+// (hits[0] = count, then clip numbers) of the clips whose map is wanted; the maps of the other clips are not written.
 hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
-                                  float *sxx, hipStream_t stream, const float *means = nullptr, const ClassifyTrace *gate = nullptr);
+                                  float *sxx, hipStream_t stream, const float *means = nullptr, const int *hits = nullptr);
 
 
 // classify() after the spectrograms (classifier.cpp:35-135), two kernels: midpoints from the 1000-3000 Hz map (records in
