@@ -537,9 +537,9 @@ int cls_run(const float *d_x, long clips, int n, long stride, hipStream_t st)
     DSP_HIP(dsp::launch_iir_f32(d_x, clips, n, stride, bp, g_cls.d_bp, mp, g_cls.d_mp, st, g_cls.d_mean_bp, g_cls.d_mean_mp));
     // the IIR kernel writes with the input's row stride; the workspace rows are n long
     // midpoints first (1000-3000 Hz map); the 3000-7500 Hz spectrogram and its band sums only for clips that have midpoints
-    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_mp, clips, n, stride, g_cls.d_tab, g_cls.d_smp, st, g_cls.d_mean_mp));
+    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_mp, clips, n, stride, g_cls.d_tab, g_cls.d_smp, st, g_cls.d_mean_mp, nullptr, true));
     DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_smp, clips, n, 16000, g_cls.d_tab, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st));
-    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_bp, clips, n, stride, g_cls.d_tab, g_cls.d_sbp, st, g_cls.d_mean_bp, g_cls.d_hits));
+    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_bp, clips, n, stride, g_cls.d_tab, g_cls.d_sbp, st, g_cls.d_mean_bp, g_cls.d_hits, true));
     DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st));
     return DSP_OK;
 }

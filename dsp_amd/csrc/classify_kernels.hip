@@ -378,6 +378,11 @@ hipError_t launch_iir_f64(const double *x, long n_clips, int n, long stride, con
 //            butterflies of one level are independent, so the results are bit-identical to the
 //            serial loop whatever the lane split.
 // ---------------------------------------------------------------------------------
+#ifndef DSP_SPEC_TILE
+#define DSP_SPEC_TILE 16
+#endif
+// frames whose PSD columns are collected in LDS before they are stored as row segments (SPEC_TILE floats each)
+constexpr int SPEC_TILE = DSP_SPEC_TILE;
 __device__ __forceinline__ unsigned bitrev6(unsigned v) { return __brev(v) >> 26; }
 
 struct cpx { float x, y; };
@@ -406,18 +411,21 @@ __device__ __forceinline__ void butterfly(cpx &a, cpx &b, const cpx u)
 // hits (optional): work list of the clips whose map is wanted (hits[0] = count, then clip numbers, as written by
 // classify_midpoints_kernel): frame slot s of the launch is time bin s % T of clip hits[1 + s / T], so the wanted clips
 // are packed into the first wavefronts whatever their position in the batch, and the others exit at once.
+// FRAME_MAJOR: the map is written [time][bin] (one frame = 129 consecutive floats, stored straight from the registers)
+// instead of the reference's [bin][time]; classify()'s own kernels read that layout, the spectrogram entry point does not.
+template <bool FRAME_MAJOR>
 __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restrict__ y, long n_clips, int n, long stride,
                                                           const SpecTables *__restrict__ tab, float *__restrict__ sxx, int T,
                                                           const float *__restrict__ means, const int *__restrict__ hits)
 {
     __shared__ float2 lds[4][kSpecSeg];
-    // PSD columns of 16 consecutive frames are collected here and stored as 64-byte row segments: the output is
+    // PSD columns of SPEC_TILE consecutive frames are collected here and stored as row segments: the output is
     // [bin][time], one frame is a COLUMN of it (129 scattered dwords if stored directly)
-    __shared__ float psd_tile[4][kSpecBins * 17];
+    __shared__ float psd_tile[FRAME_MAJOR ? 1 : 4][FRAME_MAJOR ? 1 : kSpecBins * (SPEC_TILE + 1)];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float2 *buf = lds[wib];
-    float *tile = psd_tile[wib];
+    float *tile = psd_tile[FRAME_MAJOR ? 0 : wib];
     const long total = (hits ? (long)hits[0] : n_clips) * T;
     const long gid0 = ((long)blockIdx.x * 4 + wib) * 64;
     if (gid0 >= total) return;
@@ -466,28 +474,58 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
         win[j] = tab->window[src[j]];
     }
     const float U = tab->U;
+    const bool trivial01 = tab->trivial_first_levels != 0;
 
     // ---- phase 2
     const int n_here = (int)(total - gid0 < 64 ? total - gid0 : 64);
     long slot = gid0 / T;
     int t = (int)(gid0 - slot * T);
     long clip = clip_of(slot);
+    // the four samples of the NEXT frame are requested before the current one is transformed: a frame is ~0.4 us of
+    // arithmetic behind ~1.5 us of load latency otherwise (three wavefronts per SIMD do not cover that)
+    float raw[4];
+    {
+        const float *seg = y + clip * stride + (long)t * kSpecHop;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) raw[j] = seg[src[j]];
+    }
     for (int f = 0; f < n_here; ++f) {
         const float mean_f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), f));
-        const float *seg = y + clip * stride + (long)t * kSpecHop;
+        float cur[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = raw[j];
+        if (f + 1 < n_here) {
+            const bool wrap = t + 1 == T;
+            const long nclip = wrap ? clip_of(slot + 1) : clip;
+            const float *seg = y + nclip * stride + (long)(wrap ? 0 : t + 1) * kSpecHop;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw[j] = seg[src[j]];
+        }
         cpx v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = {(seg[src[j]] - mean_f) * win[j], 0.0f};     // classifier.cpp:336-346
+        for (int j = 0; j < 4; ++j) v[j] = {(cur[j] - mean_f) * win[j], 0.0f};          // classifier.cpp:336-346
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if (p > 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { const float2 q = buf[pos[p][j]]; v[j] = {q.x, q.y}; }
             }
-            butterfly(v[0], v[1], ua[p]);
-            butterfly(v[2], v[3], ua[p]);
-            butterfly(v[0], v[2], ub0[p]);
-            butterfly(v[1], v[3], ub1[p]);
+            if (p == 0 && trivial01) {
+                // Levels 0 and 1 on real input with twiddles (1,0), (1,0), (0,-1): t = u * b is (b.x, 0) resp. (0, -b.x),
+                // so the reference's ten operations per butterfly leave these sums and differences and zeros.  Every
+                // non-zero value is the reference's bit for bit (finite input); a zero may differ in sign, which
+                // re^2 + im^2 cannot see.
+                const float a0 = v[0].x + v[1].x, a1 = v[0].x - v[1].x, a2 = v[2].x + v[3].x, a3 = v[2].x - v[3].x;
+                v[0] = {a0 + a2, 0.0f};
+                v[2] = {a0 - a2, 0.0f};
+                v[1] = {a1, -a3};
+                v[3] = {a1, a3};
+            } else {
+                butterfly(v[0], v[1], ua[p]);
+                butterfly(v[2], v[3], ua[p]);
+                butterfly(v[0], v[2], ub0[p]);
+                butterfly(v[1], v[3], ub1[p]);
+            }
             if (p < 3) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) buf[pos[p][j]] = make_float2(v[j].x, v[j].y);
@@ -497,44 +535,52 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
             }
         }
         // lane g now holds X[g], X[g + 64], X[g + 128], X[g + 192]; classifier.cpp:350-365
-        {
-            const int col = f & 15;
-            float p0 = (v[0].x * v[0].x + v[0].y * v[0].y) / U;
-            if (lane >= 1) p0 = p0 * 2.0f;
-            tile[lane * 17 + col] = p0;
-            float p1 = (v[1].x * v[1].x + v[1].y * v[1].y) / U;
-            p1 = p1 * 2.0f;
-            tile[(lane + 64) * 17 + col] = p1;
-            if (lane == 0) tile[128 * 17 + col] = (v[2].x * v[2].x + v[2].y * v[2].y) / U;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if ((f & 15) == 15 || f == n_here - 1) {
-            // flush frames [f & ~15, f]: lane -> column lane % 16 (one frame, one division), rows lane / 16 + 4 k
-            const int col = lane & 15, ff = (f & ~15) + col;
-            if (ff <= f) {
-                const long g = gid0 + ff;
-                const long sl = g / T;
-                const int tt = (int)(g - sl * T);
-                float *out = sxx + clip_of(sl) * (long)kSpecBins * T + tt;
-                for (int row = lane >> 4; row < kSpecBins; row += 4) out[(long)row * T] = tile[row * 17 + col];
-            }
+        float p0 = (v[0].x * v[0].x + v[0].y * v[0].y) / U;
+        if (lane >= 1) p0 = p0 * 2.0f;
+        float p1 = (v[1].x * v[1].x + v[1].y * v[1].y) / U;
+        p1 = p1 * 2.0f;
+        const float p2 = (v[2].x * v[2].x + v[2].y * v[2].y) / U;      // bin 128, lane 0 only
+        if (FRAME_MAJOR) {
+            float *out = sxx + (clip * T + t) * (long)kSpecBins;
+            out[lane] = p0;
+            out[lane + 64] = p1;
+            if (lane == 0) out[128] = p2;
+        } else {
+            const int col = f & (SPEC_TILE - 1);
+            tile[lane * (SPEC_TILE + 1) + col] = p0;
+            tile[(lane + 64) * (SPEC_TILE + 1) + col] = p1;
+            if (lane == 0) tile[128 * (SPEC_TILE + 1) + col] = p2;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if ((f & (SPEC_TILE - 1)) == SPEC_TILE - 1 || f == n_here - 1) {
+                // flush frames [f & ~(SPEC_TILE - 1), f]: lane -> column lane % SPEC_TILE (one frame, one division), rows lane / SPEC_TILE + k 64 / SPEC_TILE
+                const int col2 = lane & (SPEC_TILE - 1), ff = (f & ~(SPEC_TILE - 1)) + col2;
+                if (ff <= f) {
+                    const long g = gid0 + ff;
+                    const long sl = g / T;
+                    const int tt = (int)(g - sl * T);
+                    float *out = sxx + clip_of(sl) * (long)kSpecBins * T + tt;
+                    for (int row = lane / SPEC_TILE; row < kSpecBins; row += 64 / SPEC_TILE) out[(long)row * T] = tile[row * (SPEC_TILE + 1) + col2];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
         if (++t == T) { t = 0; ++slot; if (f + 1 < n_here) clip = clip_of(slot); }
     }
 }
 
 hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
-                                  float *sxx, hipStream_t stream, const float *means, const int *hits)
+                                  float *sxx, hipStream_t stream, const float *means, const int *hits, bool frame_major)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0 || T <= 0) return hipSuccess;
     const long total = n_clips * T;
-    hipLaunchKernelGGL(spectrogram_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (frame_major) hipLaunchKernelGGL(spectrogram_kernel<true>, grid, dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits);
+    else hipLaunchKernelGGL(spectrogram_kernel<false>, grid, dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits);
     return hipGetLastError();
 }
 
@@ -558,34 +604,6 @@ __device__ __forceinline__ float wave_maxf(float v)
 {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
-}
-
-__device__ float sum_intense_dev(float lower, float upper, float half_range, int fs, int T, const float *db, float midpoint)
-{
-    // classifier.cpp:370-431 with freqs[k] = k*fs/256 and times[t] = (224 t + 128)/fs recomputed in place
-    auto freq = [&](int k) { return (float)k * (float)fs / (float)kSpecSeg; };
-    auto time = [&](int t) { return ((float)(t * kSpecHop + kSpecSeg / 2)) / (float)fs; };
-    int f0 = 0;
-    while (f0 < kSpecBins && freq(f0) < lower) ++f0;
-    int f1 = kSpecBins - 1;
-    while (f1 >= 0 && freq(f1) > upper) --f1;
-    if (f0 >= kSpecBins) f0 = kSpecBins - 1;
-    if (f1 < 0) f1 = 0;
-    if (f0 > f1) { int x = f0; f0 = f1; f1 = x; }
-    int t0 = 0;
-    while (t0 < T && time(t0) < midpoint - half_range) ++t0;
-    int t1 = T - 1;
-    while (t1 >= 0 && time(t1) > midpoint + half_range) --t1;
-    if (t0 >= T) t0 = T - 1;
-    if (t1 < 0) t1 = 0;
-    if (t0 > t1) { int x = t0; t0 = t1; t1 = x; }
-    float total = 0.0f;
-    for (int i = f0; i <= f1; ++i)
-        for (int j = t0; j <= t1; ++j) {
-            const float v = db[(long)i * T + j];
-            if (!isnan(v)) total = total + v;
-        }
-    return total;
 }
 
 // sum_intense for a whole wavefront: the cells are fetched 64 at a time in the reference's (row, column) order, then
@@ -654,7 +672,7 @@ __device__ float sum_intense_wave(float lower, float upper, float half_range, in
         float v = 0.0f;
         if (e < N) {
             const int r = e / W, cidx = e - r * W;
-            v = db[(long)(f0 + r) * T + t0 + cidx];
+            v = db[(long)(t0 + cidx) * kSpecBins + f0 + r];       // the map is [time][bin]
             if (isnan(v)) v = 0.0f;
         }
         const bool kept = v != 0.0f;                         // kept cells lie in (0.65, 0.80)
@@ -736,7 +754,7 @@ __global__ __launch_bounds__(256) void classify_midpoints_kernel(const float *__
             for (int u = 0; u < B; ++u) v[u] = i0 + 256 * u < cells ? __builtin_nontemporal_load(mp + i0 + 256 * u) : 0.0f;
 #pragma unroll
             for (int u = 0; u < B; ++u)
-                if (v[u] >= keep_min) col_any[(i0 + 256 * u) % T] = 1;    // same value from every writer
+                if (v[u] >= keep_min) col_any[(i0 + 256 * u) / kSpecBins] = 1;    // [time][bin] map; same value from every writer
         }
     }
     __syncthreads();
@@ -976,6 +994,9 @@ void build_spec_tables(int fs, SpecTables &t)
         c1 = (float)std::sqrt((1.0 + (double)c1) / 2.0);
         l1 <<= 1;
     }
+    // the spectrogram kernel's short form of levels 0 and 1 (real input) is valid for exactly these twiddles
+    t.trivial_first_levels = t.tw_re[0] == 1.0f && t.tw_im[0] == 0.0f && t.tw_re[1] == 1.0f && t.tw_im[1] == 0.0f &&
+                             t.tw_re[2] == 0.0f && t.tw_im[2] == -1.0f;
 }
 
 }  // namespace dsp

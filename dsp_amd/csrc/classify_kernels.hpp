@@ -19,6 +19,7 @@ struct SpecTables {
     // reference's own recurrence (PlainFFT.cpp:52-84) so every butterfly sees the same bits
     float tw_re[255], tw_im[255];   // level l starts at (1<<l) - 1
     float mp_keep_min;              // smallest float s with (float)(10 log10(s / 1e-12)) > 70 (filled on the device)
+    int trivial_first_levels;       // 1 when the twiddles of FFT levels 0 and 1 are exactly (1,0), (1,0), (0,-1) (they are)
 };
 
 struct IirCoef { float b[9], a[9]; };
@@ -46,11 +47,13 @@ struct ClassifyTrace {           // per clip, for parity tests
 
 // means (optional): segment means [c][T] already computed by launch_iir_f32.  hits (optional, device): work list
 // (hits[0] = count, then clip numbers) of the clips whose map is wanted; the maps of the other clips are not written.
+// frame_major: sxx[c][T][129] instead of the reference's [c][129][T] -- the layout launch_classify_midpoints / _bands read.
 hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
-                                  float *sxx, hipStream_t stream, const float *means = nullptr, const int *hits = nullptr);
+                                  float *sxx, hipStream_t stream, const float *means = nullptr, const int *hits = nullptr,
+                                  bool frame_major = false);
 
 
-// classify() after the spectrograms (classifier.cpp:35-135), two kernels: midpoints from the 1000-3000 Hz map (records in
+// classify() after the spectrograms (classifier.cpp:35-135; maps in the frame_major layout), two kernels: midpoints from the 1000-3000 Hz map (records in
 // `trace`, label 0 when there are none), then the band sums + rule from the 3000-7500 Hz map for the clips that have
 // midpoints (sxx_bp is overwritten with its dB map when it does not fit LDS).  `trace` is required (it carries the midpoints);
 // `hits` (1 + n_clips ints) is the work list between the two: hits[0] = clips with midpoints, then their numbers.
