@@ -154,8 +154,8 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         n = args.clips or 49152
         clips = (torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1) * 0.05
         # every fourth clip carries a call-like burst pattern that has midpoints and fires the rule (tests/signals.py
-        # scrub_a, label 1 in the reference): clips without midpoints leave the tail kernel early, so an all-noise batch
-        # would flatter it
+        # scrub_a, label 1 in the reference): the band-pass spectrogram and the band sums run only for clips with
+        # midpoints, so an all-noise batch would flatter it
         from tests import signals as S
         call = torch.from_numpy(S.classify_cases()["scrub_a"]).to(dev)
         clips[::4] = call + clips[::4] * 0.01
@@ -164,7 +164,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         units, unit, bytes_per = n, "clips/s", 64_000 + 4
         what = (f"{n} x 1 s 16 kHz fp32 clips (25 % with a call-like burst pattern, label 1) through classify() "
                 "(2 x IIR, 2 x spectrogram, rule), bit-exact with the reference")
-        kernel = "iir2_split_kernel + spectrogram_kernel x2 + classify_midpoints_kernel + classify_bands_kernel"
+        kernel = "iir2_split_kernel + spectrogram_kernel<flags> + classify_midpoints_kernel + spectrogram_kernel<frame-major> + classify_bands_kernel"
     for _ in range(max(1, args.warmup // 4)):
         step()
     torch.cuda.synchronize()

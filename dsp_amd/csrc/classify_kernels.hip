@@ -275,24 +275,24 @@ __global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict
             // 6 tiles = 50 KB per block, three blocks per CU
             float *yo = vbuf[f][(s - 1) & 1];
             const float *vin = yo;
-            auto taps = [&](float v, int sidx) {                     // classifier.cpp:207-216, then the segment sums
+            auto taps = [&](float v) {                               // classifier.cpp:207-216
                 float o = c.b[0] * v;
 #pragma unroll
                 for (int j = 1; j <= 8; ++j) o = o + c.b[j] * d[j - 1];
 #pragma unroll
                 for (int j = 7; j > 0; --j) d[j] = d[j - 1];
                 d[0] = v;
-                if (means) {
-                    const int k = sidx / kSpecHop, pos = sidx - k * kSpecHop;
-                    if (pos == 0) { prev = cur; cur = 0.0f; }
-                    cur = cur + o;
-                    if (pos < kSpecSeg - kSpecHop && k >= 1) {
-                        prev = prev + o;
-                        if (pos == kSpecSeg - kSpecHop - 1 && k - 1 < n_seg) means[(clip0 + lane) * n_seg + k - 1] = prev / (float)kSpecSeg;
-                    }
-                }
                 return o;
             };
+            // The spectrogram's segments (256 samples every 224) start on tile boundaries and overlap by exactly one
+            // tile: tile 7k is the first tile of segment k and the last one of segment k-1.  Their sequential sums
+            // (classifier.cpp:329-333) are carried per tile: one add per sample, two in the shared tile.
+            static_assert(kSpecHop % IIR_TS == 0 && kSpecSeg - kSpecHop == IIR_TS, "segment sums are kept per IIR tile");
+            constexpr int kTilesPerHop = kSpecHop / IIR_TS;
+            const int ti = s - 1, seg_k = ti / kTilesPerHop;
+            const bool seg_start = means != nullptr && ti % kTilesPerHop == 0;
+            const bool seg_both = seg_start && seg_k >= 1;           // the tile also closes segment seg_k - 1
+            if (seg_start) { prev = cur; cur = 0.0f; }
             if (lane < rows && cols == IIR_TS) {
 #pragma unroll
                 for (int h = 0; h < IIR_TS; h += IIR_BURST) {
@@ -300,12 +300,21 @@ __global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict
 #pragma unroll
                     for (int i = 0; i < IIR_BURST; ++i) vr[i] = vin[lane * IIR_LD + h + i];
 #pragma unroll
-                    for (int i = 0; i < IIR_BURST; ++i) orr[i] = taps(vr[i], t0 + h + i);
+                    for (int i = 0; i < IIR_BURST; ++i) orr[i] = taps(vr[i]);
+                    if (seg_both) {
+#pragma unroll
+                        for (int i = 0; i < IIR_BURST; ++i) { cur = cur + orr[i]; prev = prev + orr[i]; }
+                    } else if (means) {
+#pragma unroll
+                        for (int i = 0; i < IIR_BURST; ++i) cur = cur + orr[i];
+                    }
 #pragma unroll
                     for (int i = 0; i < IIR_BURST; ++i) yo[lane * IIR_LD + h + i] = orr[i];
                 }
+                if (seg_both && seg_k - 1 < n_seg) means[(clip0 + lane) * n_seg + seg_k - 1] = prev / (float)kSpecSeg;
             } else if (lane < rows) {
-                for (int i = 0; i < cols; ++i) yo[lane * IIR_LD + i] = taps(vin[lane * IIR_LD + i], t0 + i);
+                // a short last tile lies past every whole segment: no sums to keep
+                for (int i = 0; i < cols; ++i) yo[lane * IIR_LD + i] = taps(vin[lane * IIR_LD + i]);
             }
             // this wave's own tile: wave-level ordering is enough before the coalesced store
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -411,9 +420,15 @@ __device__ __forceinline__ void butterfly(cpx &a, cpx &b, const cpx u)
 // hits (optional): work list of the clips whose map is wanted (hits[0] = count, then clip numbers, as written by
 // classify_midpoints_kernel): frame slot s of the launch is time bin s % T of clip hits[1 + s / T], so the wanted clips
 // are packed into the first wavefronts whatever their position in the batch, and the others exit at once.
-// FRAME_MAJOR: the map is written [time][bin] (one frame = 129 consecutive floats, stored straight from the registers)
-// instead of the reference's [bin][time]; classify()'s own kernels read that layout, the spectrogram entry point does not.
-template <bool FRAME_MAJOR>
+// OUT selects what leaves the kernel:
+//   SPEC_BIN_MAJOR    the reference's [bin][time] map (the spectrogram entry point)
+//   SPEC_FRAME_MAJOR  [time][bin]: one frame = 129 consecutive floats, stored straight from the registers (the band-pass
+//                     map inside classify(); classify_bands_kernel reads that layout)
+//   SPEC_FLAGS        no map at all: one int per frame, 1 when any of its 129 cells is >= SpecTables::mp_keep_min.  That
+//                     is all find_midpoints takes from the 1000-3000 Hz map (classifier.cpp:457-518), so classify() never
+//                     writes that map to HBM (36 KB per clip written and read back otherwise)
+enum { SPEC_BIN_MAJOR = 0, SPEC_FRAME_MAJOR = 1, SPEC_FLAGS = 2 };
+template <int OUT>
 __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restrict__ y, long n_clips, int n, long stride,
                                                           const SpecTables *__restrict__ tab, float *__restrict__ sxx, int T,
                                                           const float *__restrict__ means, const int *__restrict__ hits)
@@ -421,11 +436,12 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
     __shared__ float2 lds[4][kSpecSeg];
     // PSD columns of SPEC_TILE consecutive frames are collected here and stored as row segments: the output is
     // [bin][time], one frame is a COLUMN of it (129 scattered dwords if stored directly)
-    __shared__ float psd_tile[FRAME_MAJOR ? 1 : 4][FRAME_MAJOR ? 1 : kSpecBins * (SPEC_TILE + 1)];
+    constexpr bool TILED = OUT == SPEC_BIN_MAJOR;
+    __shared__ float psd_tile[TILED ? 4 : 1][TILED ? kSpecBins * (SPEC_TILE + 1) : 1];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float2 *buf = lds[wib];
-    float *tile = psd_tile[FRAME_MAJOR ? 0 : wib];
+    float *tile = psd_tile[TILED ? wib : 0];
     const long total = (hits ? (long)hits[0] : n_clips) * T;
     const long gid0 = ((long)blockIdx.x * 4 + wib) * 64;
     if (gid0 >= total) return;
@@ -475,6 +491,8 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
     }
     const float U = tab->U;
     const bool trivial01 = tab->trivial_first_levels != 0;
+    const float keep_min = tab->mp_keep_min;
+    int flag = 0;
 
     // ---- phase 2
     const int n_here = (int)(total - gid0 < 64 ? total - gid0 : 64);
@@ -540,7 +558,10 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
         float p1 = (v[1].x * v[1].x + v[1].y * v[1].y) / U;
         p1 = p1 * 2.0f;
         const float p2 = (v[2].x * v[2].x + v[2].y * v[2].y) / U;      // bin 128, lane 0 only
-        if (FRAME_MAJOR) {
+        if (OUT == SPEC_FLAGS) {
+            const bool loud = p0 >= keep_min || p1 >= keep_min || (lane == 0 && p2 >= keep_min);
+            if (__ballot(loud) != 0 && lane == f) flag = 1;             // lane f keeps the flag of frame f
+        } else if (OUT == SPEC_FRAME_MAJOR) {
             float *out = sxx + (clip * T + t) * (long)kSpecBins;
             out[lane] = p0;
             out[lane + 64] = p1;
@@ -570,6 +591,7 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
         }
         if (++t == T) { t = 0; ++slot; if (f + 1 < n_here) clip = clip_of(slot); }
     }
+    if (OUT == SPEC_FLAGS && lane < n_here) reinterpret_cast<int *>(sxx)[gid0 + lane] = flag;      // [clip][T] (no work list here)
 }
 
 hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
@@ -579,8 +601,21 @@ hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stri
     if (n_clips <= 0 || T <= 0) return hipSuccess;
     const long total = n_clips * T;
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (frame_major) hipLaunchKernelGGL(spectrogram_kernel<true>, grid, dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits);
-    else hipLaunchKernelGGL(spectrogram_kernel<false>, grid, dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits);
+    if (frame_major)
+        hipLaunchKernelGGL(spectrogram_kernel<SPEC_FRAME_MAJOR>, grid, dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits);
+    else
+        hipLaunchKernelGGL(spectrogram_kernel<SPEC_BIN_MAJOR>, grid, dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits);
+    return hipGetLastError();
+}
+
+hipError_t launch_spectrogram_flags(const float *y, long n_clips, int n, long stride, const SpecTables *tables, int *flags,
+                                    hipStream_t stream, const float *means)
+{
+    const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
+    if (n_clips <= 0 || T <= 0) return hipSuccess;
+    const long total = n_clips * T;
+    hipLaunchKernelGGL(spectrogram_kernel<SPEC_FLAGS>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y, n_clips, n, stride, tables,
+                       reinterpret_cast<float *>(flags), T, means, (const int *)nullptr);
     return hipGetLastError();
 }
 
@@ -728,42 +763,22 @@ hipError_t launch_spec_threshold(SpecTables *tables, hipStream_t stream)
 //                              midpoints, written to the clip's ClassifyTrace record; label 0 when there are none
 //   classify_bands_kernel      (band-pass spectrogram, clips with midpoints only)  dB map, normalisation, the three
 //                              band sums per midpoint in the reference's order, the rule
-__global__ __launch_bounds__(256) void classify_midpoints_kernel(const float *__restrict__ sxx_mp, long n_clips, int T, int fs,
-                                                                 const SpecTables *__restrict__ tab, int *__restrict__ labels,
-                                                                 ClassifyTrace *__restrict__ trace, int *__restrict__ hits)
+__global__ __launch_bounds__(256) void classify_midpoints_kernel(const int *__restrict__ loud, long n_clips, int T, int fs,
+                                                                 int *__restrict__ labels, ClassifyTrace *__restrict__ trace,
+                                                                 int *__restrict__ hits)
 {
-    __shared__ float blob[1024];
-    __shared__ int col_any[1024];
-    const long clip = blockIdx.x;
+    // a wavefront per clip; loud[clip][T] are the time bins with a cell above 70 dB (spectrogram_kernel<SPEC_FLAGS>)
+    __shared__ float blob_all[4][1024];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long clip = (long)blockIdx.x * 4 + wib;
     if (clip >= n_clips) return;
-    const int tid = threadIdx.x;
-    const int cells = kSpecBins * T;
-    const float *mp = sxx_mp + clip * (long)cells;
-    for (int j = tid; j < T; j += 256) col_any[j] = 0;
-    // a whole record per clip: band sums the rule never reaches (no midpoints, or after the first hit) read as 0
-    if (tid < kMaxMidpoints * 3) (&trace[clip].sums[0][0])[tid] = 0.0f;
-    else trace[clip].midpoints[tid - kMaxMidpoints * 3] = 0.0f;          // 256 threads = 3 x 64 sums + 64 midpoints
-    __syncthreads();
-    // keep > 70 dB, time bins with any cell   classifier.cpp:457-518.  Eight loads in flight per thread.
-    {
-        const float keep_min = tab->mp_keep_min;
-        constexpr int B = 8;
-        for (int i0 = tid; i0 < cells; i0 += 256 * B) {
-            float v[B];
-#pragma unroll
-            for (int u = 0; u < B; ++u) v[u] = i0 + 256 * u < cells ? __builtin_nontemporal_load(mp + i0 + 256 * u) : 0.0f;
-#pragma unroll
-            for (int u = 0; u < B; ++u)
-                if (v[u] >= keep_min) col_any[(i0 + 256 * u) / kSpecBins] = 1;    // [time][bin] map; same value from every writer
-        }
-    }
-    __syncthreads();
-    if (tid >= 64) return;
+    float *blob = blob_all[wib];
     // blob times of the flagged bins, in order (ballot ranks), then the greedy clustering on one lane
     int nb = 0;
     for (int j0 = 0; j0 < T; j0 += 64) {
-        const int j = j0 + tid;
-        const bool flag = j < T && col_any[j] != 0;
+        const int j = j0 + lane;
+        const bool flag = j < T && loud[clip * T + j] != 0;
         const unsigned long long m = __ballot(flag);
         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
         if (flag) blob[nb + rank] = ((float)(j * kSpecHop + kSpecSeg / 2)) / (float)fs;
@@ -772,10 +787,11 @@ __global__ __launch_bounds__(256) void classify_midpoints_kernel(const float *__
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (tid == 0) {
+    int count = 0;
+    if (lane == 0) {
         // greedy clustering, classifier.cpp:522-574
         const float tol = 0.05f, min_dur = 0.15f;
-        int count = 0, i0 = 0;
+        int i0 = 0;
         while (i0 < nb) {
             int i1 = i0;
             while (i1 + 1 < nb && (blob[i1 + 1] - blob[i1]) <= tol) ++i1;
@@ -793,6 +809,13 @@ __global__ __launch_bounds__(256) void classify_midpoints_kernel(const float *__
         if (count == 0) labels[clip] = 0;                   // classifier.cpp:93-114: no midpoint can fire the rule
         else hits[1 + atomicAdd(hits, 1)] = (int)clip;      // work list of the band kernels, any order
     }
+    count = __builtin_amdgcn_readfirstlane(count);
+    // a whole record per clip: unused midpoints and the band sums the rule never reaches (no midpoints, or after the
+    // first hit) read as 0.  midpoints[64] and sums[64][3] are 256 consecutive floats.
+    static_assert(kMaxMidpoints == 64 && sizeof(ClassifyTrace) == 4 + 4 * 256, "record layout");
+    float *rec = trace[clip].midpoints;
+    for (int i = lane; i < 4 * kMaxMidpoints; i += 64)
+        if (i >= count) rec[i] = 0.0f;
 }
 
 // USE_LDS: the map fits the LDS budget (129 x T <= kTailLdsCells): the PSD cells of the clip are read ONCE into
@@ -805,10 +828,7 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
 {
     __shared__ float red_mn[4], red_mx[4];
     __shared__ float mids[kMaxMidpoints];
-#ifndef DSP_BANDS_DIAG
-#define DSP_BANDS_DIAG 0
-#endif
-    int n_mids = trace[clip].n_midpoints;
+    const int n_mids = trace[clip].n_midpoints;
     const int tid = threadIdx.x;
     const int cells = kSpecBins * T;
     float *bp_g = sxx_bp + clip * (long)cells;
@@ -848,7 +868,6 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
     auto keep = [&](float sv) {
         float v = NAN;
         if (sv >= s_lo && sv <= s_hi) {                 // (false for s <= 0 and NaN)
-            if (DSP_BANDS_DIAG & 2) return sv;
             v = (to_db(sv) - mn) / (mx - mn);
             v = (v > lo_thr && v < hi_thr) ? v : NAN;
         }
@@ -896,8 +915,6 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *scratch = reinterpret_cast<float *>(pend_buf[wv]);       // free again after the barrier above
     int hit = 0;
-    if (DSP_BANDS_DIAG & 1) n_mids = 0;
-    if (DSP_BANDS_DIAG & 4) { if (tid == 0) labels[clip] = bp[5] > 0; return; }
     for (int k = 0; k < n_mids; ++k) {
         const float mid = mids[k];
         if (wv == 0) { const float v = sum_intense_wave(5000, 7000, 0.18f, fs, T, bp, mid, scratch); if ((tid & 63) == 0) band[0] = v; }
@@ -929,15 +946,15 @@ __global__ __launch_bounds__(256) void classify_bands_kernel(float *__restrict__
     }
 }
 
-hipError_t launch_classify_midpoints(const float *sxx_mp, long n_clips, int n, int fs, const SpecTables *tables, int *labels,
-                                     ClassifyTrace *trace, int *hits, hipStream_t stream)
+hipError_t launch_classify_midpoints(const int *loud, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, int *hits,
+                                     hipStream_t stream)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0) return hipSuccess;
     if (T <= 0 || T > 1024 || !trace || !hits) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(hits, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(classify_midpoints_kernel, dim3((unsigned)n_clips), dim3(256), 0, stream, sxx_mp, n_clips, T, fs, tables, labels, trace, hits);
+    hipLaunchKernelGGL(classify_midpoints_kernel, dim3((unsigned)((n_clips + 3) / 4)), dim3(256), 0, stream, loud, n_clips, T, fs, labels, trace, hits);
     return hipGetLastError();
 }
 

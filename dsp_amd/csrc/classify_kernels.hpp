@@ -53,12 +53,17 @@ hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stri
                                   bool frame_major = false);
 
 
-// classify() after the spectrograms (classifier.cpp:35-135; maps in the frame_major layout), two kernels: midpoints from the 1000-3000 Hz map (records in
-// `trace`, label 0 when there are none), then the band sums + rule from the 3000-7500 Hz map for the clips that have
-// midpoints (sxx_bp is overwritten with its dB map when it does not fit LDS).  `trace` is required (it carries the midpoints);
-// `hits` (1 + n_clips ints) is the work list between the two: hits[0] = clips with midpoints, then their numbers.
-hipError_t launch_classify_midpoints(const float *sxx_mp, long n_clips, int n, int fs, const SpecTables *tables, int *labels,
-                                     ClassifyTrace *trace, int *hits, hipStream_t stream);
+// The 1000-3000 Hz spectrogram reduced to what find_midpoints reads from it (classifier.cpp:457-518): loud[c][T] = 1 for
+// the time bins with a cell above 70 dB.  The map itself is not written.
+hipError_t launch_spectrogram_flags(const float *y, long n_clips, int n, long stride, const SpecTables *tables, int *loud,
+                                    hipStream_t stream, const float *means = nullptr);
+
+// classify() after the spectrograms (classifier.cpp:35-135), two kernels: midpoints from the loud time bins (records in
+// `trace`, label 0 when there are none), then the band sums + rule from the frame_major 3000-7500 Hz map for the clips that
+// have midpoints (sxx_bp is overwritten with its dB map when it does not fit LDS).  `trace` is required (it carries the
+// midpoints); `hits` (1 + n_clips ints) is the work list between the two: hits[0] = clips with midpoints, then their numbers.
+hipError_t launch_classify_midpoints(const int *loud, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, int *hits,
+                                     hipStream_t stream);
 hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, const int *hits,
                                  hipStream_t stream);
 // fills tables->mp_keep_min (once per context)
