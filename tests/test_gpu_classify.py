@@ -96,6 +96,31 @@ def test_other_lengths_vs_oracle(dsp):
             assert np.array_equal(t, to) and np.array_equal(sxx, so)
 
 
+def test_long_and_short_clips_with_midpoints_vs_oracle(dsp):
+    """Clips with midpoints at lengths other than 1 s: 1.5 s / 2.2 s (the dB map no longer fits LDS and is rebuilt in HBM),
+    0.6 s, and a mixed batch of the long ones -- labels, midpoints and band sums against the oracle, bit exact."""
+    from oracle import oracle as O
+    c = S.classify_cases()
+    a, b, j = c["scrub_a"], c["scrub_b"], c["jay_like"]
+    long_clips = [np.concatenate([a, a[:8000]]), np.concatenate([b, j[:8000]]), np.concatenate([j, b[:8000]]),
+                  (S.uniform_pm1(24000, 9) * np.float32(0.05)).astype(np.float32)]
+    seen_mids = 0
+    for x in long_clips + [np.concatenate([a, b, a[:3200]]), a[:9600].copy(), b[3000:13000].copy()]:
+        labels, trace = dsp.classify_batch(x[None, :], with_trace=True)
+        lab, _, osums = O.classify(x)                                 # band sums: zero rows after the first hit
+        omids = O.find_midpoints(x)
+        assert labels[0] == lab
+        assert np.array_equal(trace[0][0], omids)
+        assert np.array_equal(trace[0][1], osums)
+        seen_mids += len(omids)
+    assert seen_mids >= 4
+    batch = np.stack(long_clips)[[0, 3, 1, 3, 2, 0]]
+    labels, trace = dsp.classify_batch(batch, with_trace=True)
+    for x, lab, (mids, sums) in zip(batch, labels, trace):
+        olab, _, osums = O.classify(x)
+        assert lab == olab and np.array_equal(mids, O.find_midpoints(x)) and np.array_equal(sums, osums)
+
+
 def test_fp64_filter_matches_postbutter_dump(dsp, golden):
     """donut-classifier/_postbutter.txt (fp64 DF-II, classifier.c:420-446) and the oracle, bit exact."""
     from oracle import oracle as O
