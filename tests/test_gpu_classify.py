@@ -77,6 +77,9 @@ def test_device_batch_and_ragged_batches(dsp, golden):
         clips = np.tile(base, (reps, 1))
         got = dsp.classify_device(torch.from_numpy(clips).cuda()).cpu().numpy()
         assert np.array_equal(got, np.tile(want, reps))
+    big = torch.from_numpy(base).cuda().repeat(7100, 1)                # 49 700 clips: two passes through the 49 152-clip workspace
+    assert np.array_equal(dsp.classify_device(big).cpu().numpy(), np.tile(want, 7100))
+    del big
     wide = torch.zeros((7, 16000 + 40), device="cuda")                # strided rows
     wide[:, :16000] = torch.from_numpy(base).cuda()
     assert np.array_equal(dsp.classify_device(wide[:, :16000]).cpu().numpy(), want)
