@@ -165,6 +165,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         what = (f"{n} x 1 s 16 kHz fp32 clips (25 % with a call-like burst pattern, label 1) through classify() "
                 "(2 x IIR, 2 x spectrogram, rule), bit-exact with the reference")
         kernel = "iir2_split_kernel + spectrogram_kernel<flags> + classify_midpoints_kernel + spectrogram_kernel<frame-major> + classify_bands_kernel"
+    settle(step, torch, args.settle)
     for _ in range(max(1, args.warmup // 4)):
         step()
     torch.cuda.synchronize()
@@ -187,11 +188,21 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         print(json.dumps({
             "metric": f"{args.workload}: {unit}", "value": world * units * steps / elapsed, "unit": unit, "n_gpus": world,
             "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": what},
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": what, "clock_settle_s": args.settle},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes_per_launch": bytes_per * n}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def settle(step, torch, seconds):
+    """Untimed: keep the GPU busy with the workload's own step until its clocks have ramped (see --settle)."""
+    t_end = time.perf_counter() + max(0.0, seconds)
+    while time.perf_counter() < t_end:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
 
 
 def main():
@@ -199,6 +210,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=float, default=0.5,
+                    help="seconds of untimed back-to-back steps before the W warmup steps: a step is 0.45 ms, so W = 10..20 "
+                         "steps end before the GPU's clocks have ramped (first launches after idle run 0.6 ms); reported in config")
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="all-gather the per-rank features every step (RCCL)")
     ap.add_argument("--workload", choices=["frames", "clips", "classify", "config3", "config5", "pcm16"], default="frames",
@@ -254,6 +268,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    settle(lambda: plan.frames(frames, out), torch, args.settle)      # compute only: ranks may do different counts
     for _ in range(args.warmup):
         step()
     sync()
@@ -293,7 +308,8 @@ def main():
                                    "Hann(512) -> 512-pt FFT -> 40 HTK mel -> per-frame dB -> 13 DCT-II coeffs, "
                                    "inputs resident in HBM",
                        "frames_per_gpu": n, "frame_length": FRAME, "n_fft": 512, "n_mels": 40, "n_mfcc": N_MFCC,
-                       "gather": do_gather, "parallelism": f"frames sharded over {world} rank(s)"},
+                       "gather": do_gather, "parallelism": f"frames sharded over {world} rank(s)",
+                       "clock_settle_s": args.settle},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "mfcc512_wave_kernel", "kernel_ms": kernel_ms,
