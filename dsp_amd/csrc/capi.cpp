@@ -469,6 +469,7 @@ struct ClassifyCtx {
     float *d_mean_bp = nullptr, *d_mean_mp = nullptr;      // spectrogram segment means, written by the IIR kernel
     int *d_labels = nullptr, *d_hits = nullptr;            // d_hits: work list of clips with midpoints
     int *d_loud = nullptr;                                 // [clip][T]: time bins of the 1000-3000 Hz map above 70 dB
+    int *d_gate = nullptr;                                 // [clip][T]: 0 = the segment's energy rules a loud cell out (IIR kernel)
     dsp::ClassifyTrace *d_trace = nullptr;
     long cap_clips = 0;
     int cap_n = 0;
@@ -500,11 +501,11 @@ int spec_bins(int n) { return n < dsp::kSpecSeg ? 0 : (n - dsp::kSpecSeg) / dsp:
 int cls_reserve(long clips, int n)
 {
     if (clips <= g_cls.cap_clips && n <= g_cls.cap_n) return DSP_OK;
-    for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_bp, (void *)g_cls.d_mp, (void *)g_cls.d_sbp, (void *)g_cls.d_loud,
+    for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_bp, (void *)g_cls.d_mp, (void *)g_cls.d_sbp, (void *)g_cls.d_loud, (void *)g_cls.d_gate,
                     (void *)g_cls.d_mean_bp, (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_hits, (void *)g_cls.d_trace})
         if (p) hipFree(p);
     g_cls.d_x = g_cls.d_bp = g_cls.d_mp = g_cls.d_sbp = g_cls.d_mean_bp = g_cls.d_mean_mp = nullptr;
-    g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = nullptr; g_cls.d_trace = nullptr;
+    g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = g_cls.d_gate = nullptr; g_cls.d_trace = nullptr;
     g_cls.cap_clips = 0; g_cls.cap_n = 0;
     const size_t sig = (size_t)clips * n * sizeof(float);
     const size_t spec = (size_t)clips * dsp::kSpecBins * std::max(1, spec_bins(n)) * sizeof(float);
@@ -513,6 +514,7 @@ int cls_reserve(long clips, int n)
     DSP_HIP(hipMalloc(&g_cls.d_mp, sig));
     DSP_HIP(hipMalloc(&g_cls.d_sbp, spec));
     DSP_HIP(hipMalloc(&g_cls.d_loud, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(int)));
+    DSP_HIP(hipMalloc(&g_cls.d_gate, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(int)));
     DSP_HIP(hipMalloc(&g_cls.d_mean_bp, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_mean_mp, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_labels, (size_t)clips * sizeof(int)));
@@ -535,10 +537,10 @@ dsp::IirCoef coef_f32(double lo, double hi)
 int cls_run(const float *d_x, long clips, int n, long stride, hipStream_t st)
 {
     const dsp::IirCoef bp = coef_f32(3000, 7500), mp = coef_f32(1000, 3000);   // classifier.cpp:14-19, 438-442
-    DSP_HIP(dsp::launch_iir_f32(d_x, clips, n, stride, bp, g_cls.d_bp, mp, g_cls.d_mp, st, g_cls.d_mean_bp, g_cls.d_mean_mp));
+    DSP_HIP(dsp::launch_iir_f32(d_x, clips, n, stride, bp, g_cls.d_bp, mp, g_cls.d_mp, st, g_cls.d_mean_bp, g_cls.d_mean_mp, g_cls.d_tab, g_cls.d_gate));
     // the IIR kernel writes with the input's row stride; the workspace rows are n long
     // midpoints first (1000-3000 Hz map); the 3000-7500 Hz spectrogram and its band sums only for clips that have midpoints
-    DSP_HIP(dsp::launch_spectrogram_flags(g_cls.d_mp, clips, n, stride, g_cls.d_tab, g_cls.d_loud, st, g_cls.d_mean_mp));
+    DSP_HIP(dsp::launch_spectrogram_flags(g_cls.d_mp, clips, n, stride, g_cls.d_tab, g_cls.d_loud, st, g_cls.d_mean_mp, g_cls.d_gate));
     DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_loud, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st));
     DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_bp, clips, n, stride, g_cls.d_tab, g_cls.d_sbp, st, g_cls.d_mean_bp, g_cls.d_hits, true));
     DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st));

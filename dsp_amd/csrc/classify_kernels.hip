@@ -183,7 +183,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restri
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict__ x, long n_clips, int n, long stride,
                                                          const IirCoef c1, float *__restrict__ y1, const IirCoef c2, float *__restrict__ y2,
-                                                         float *__restrict__ means1, float *__restrict__ means2)
+                                                         float *__restrict__ means1, float *__restrict__ means2,
+                                                         const SpecTables *__restrict__ tab, int *__restrict__ gate2)
 {
     __shared__ float tin[2][64 * IIR_LD];
     __shared__ float vbuf[2][2][64 * IIR_LD];          // [filter][tile parity]
@@ -202,6 +203,12 @@ __global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict
 #pragma unroll
     for (int j = 0; j < 8; ++j) d[j] = 0.0f;
     float cur = 0.0f, prev = 0.0f;                      // taps waves: running sums of the current / previous segment
+    // gate2 (filter 2, needs means2 and tab): an upper bound of each segment's windowed, mean-removed energy
+    // E = sum w^2 (y - m)^2 = A - 2 m B + m^2 C <= A + 2 |m| |B| + m^2 C with A = sum w^2 y^2, B = sum w^2 y, C = sum w^2.
+    // gate2[clip][k] = 0 when 512 E / U (Parseval bound of every PSD cell, 1 % margin for the float sums) stays below
+    // the 70 dB threshold: spectrogram_kernel<SPEC_FLAGS> then never reads that frame.
+    const bool gating = gate2 != nullptr && f == 1 && means != nullptr && tab != nullptr && tab->gate_ok != 0;
+    float ea_cur = 0.0f, eb_cur = 0.0f, ea_prev = 0.0f, eb_prev = 0.0f;
 
     // x tiles: the 128 recurrence threads load them (4 float4 each per full tile), one tile ahead in registers
     constexpr int CH = IIR_TS / 4, NV = 64 * CH / 128;
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict
             const int ti = s - 1, seg_k = ti / kTilesPerHop;
             const bool seg_start = means != nullptr && ti % kTilesPerHop == 0;
             const bool seg_both = seg_start && seg_k >= 1;           // the tile also closes segment seg_k - 1
-            if (seg_start) { prev = cur; cur = 0.0f; }
+            if (seg_start) { prev = cur; cur = 0.0f; ea_prev = ea_cur; eb_prev = eb_cur; ea_cur = eb_cur = 0.0f; }
             if (lane < rows && cols == IIR_TS) {
 #pragma unroll
                 for (int h = 0; h < IIR_TS; h += IIR_BURST) {
@@ -308,10 +315,30 @@ __global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict
 #pragma unroll
                         for (int i = 0; i < IIR_BURST; ++i) cur = cur + orr[i];
                     }
+                    if (gating) {
+                        if (seg_start) {                             // tapered tile: in for the new segment, out for the old one
+#pragma unroll
+                            for (int i = 0; i < IIR_BURST; ++i) {
+                                const float wi = tab->win2_in[h + i] * orr[i], wo = tab->win2_out[h + i] * orr[i];
+                                ea_cur = fmaf(wi, orr[i], ea_cur); eb_cur = eb_cur + wi;
+                                ea_prev = fmaf(wo, orr[i], ea_prev); eb_prev = eb_prev + wo;
+                            }
+                        } else {                                     // the window is 1 here
+#pragma unroll
+                            for (int i = 0; i < IIR_BURST; ++i) { ea_cur = fmaf(orr[i], orr[i], ea_cur); eb_cur = eb_cur + orr[i]; }
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < IIR_BURST; ++i) yo[lane * IIR_LD + h + i] = orr[i];
                 }
-                if (seg_both && seg_k - 1 < n_seg) means[(clip0 + lane) * n_seg + seg_k - 1] = prev / (float)kSpecSeg;
+                if (seg_both && seg_k - 1 < n_seg) {
+                    const float m = prev / (float)kSpecSeg;
+                    means[(clip0 + lane) * n_seg + seg_k - 1] = m;
+                    if (gating) {
+                        const float e = ea_prev + 2.0f * fabsf(m) * fabsf(eb_prev) + m * m * tab->win2_sum;
+                        gate2[(clip0 + lane) * n_seg + seg_k - 1] = e * tab->gate_scale >= tab->mp_keep_min ? 1 : 0;
+                    }
+                }
             } else if (lane < rows) {
                 // a short last tile lies past every whole segment: no sums to keep
                 for (int i = 0; i < cols; ++i) yo[lane * IIR_LD + i] = taps(vin[lane * IIR_LD + i]);
@@ -342,14 +369,20 @@ __global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict
 }
 
 hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, const IirCoef &c1, float *y1,
-                          const IirCoef &c2, float *y2, hipStream_t stream, float *means1, float *means2)
+                          const IirCoef &c2, float *y2, hipStream_t stream, float *means1, float *means2,
+                          const SpecTables *tables, int *gate2)
 {
     if (n_clips <= 0 || n <= 0) return hipSuccess;
     const int blocks = (int)((n_clips + 63) / 64);
     const bool aligned = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y1) % 16 == 0 &&
                          reinterpret_cast<uintptr_t>(y2) % 16 == 0;
+    if (gate2 && !(y2 && aligned)) {      // only the split kernel computes the gate: every frame is "maybe" (non-zero ints)
+        const int n_seg = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
+        hipError_t e = hipMemsetAsync(gate2, 1, (size_t)n_clips * n_seg * sizeof(int), stream);
+        if (e != hipSuccess) return e;
+    }
     if (y2 && aligned)       // classify(): recurrence / taps split over four wavefronts (means1 / means2 may be nullptr)
-        hipLaunchKernelGGL(iir2_split_kernel, dim3(blocks), dim3(256), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2, means1, means2);
+        hipLaunchKernelGGL(iir2_split_kernel, dim3(blocks), dim3(256), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2, means1, means2, tables, gate2);
     else if (y2 && means1 && means2)
         hipLaunchKernelGGL((iir_kernel<float, IirCoef, true, float, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2,
                            means1, means2);
@@ -431,7 +464,8 @@ enum { SPEC_BIN_MAJOR = 0, SPEC_FRAME_MAJOR = 1, SPEC_FLAGS = 2 };
 template <int OUT>
 __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restrict__ y, long n_clips, int n, long stride,
                                                           const SpecTables *__restrict__ tab, float *__restrict__ sxx, int T,
-                                                          const float *__restrict__ means, const int *__restrict__ hits)
+                                                          const float *__restrict__ means, const int *__restrict__ hits,
+                                                          const int *__restrict__ gate)
 {
     __shared__ float2 lds[4][kSpecSeg];
     // PSD columns of SPEC_TILE consecutive frames are collected here and stored as row segments: the output is
@@ -446,6 +480,17 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
     const long gid0 = ((long)blockIdx.x * 4 + wib) * 64;
     if (gid0 >= total) return;
     auto clip_of = [&](long slot) { return hits ? (long)hits[1 + slot] : slot; };
+    // SPEC_FLAGS with a gate (written by the IIR kernel, [clip][T]): 0 = the frame's energy proves that no cell can reach
+    // the threshold (max_k PSD[k] <= 2 |X[k]|^2 / U <= 512 sum v_n^2 / U, Parseval), so its flag is 0 without a transform
+    unsigned long long todo = ~0ull;
+    if (OUT == SPEC_FLAGS && gate) {
+        const bool maybe = gid0 + lane < total && gate[gid0 + lane] != 0;
+        todo = __ballot(maybe);
+        if (todo == 0) {
+            if (gid0 + lane < total) reinterpret_cast<int *>(sxx)[gid0 + lane] = 0;
+            return;
+        }
+    }
 
     // ---- phase 1: sequential mean of this lane's frame
     float mean = 0.0f;
@@ -501,18 +546,25 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
     long clip = clip_of(slot);
     // the four samples of the NEXT frame are requested before the current one is transformed: a frame is ~0.4 us of
     // arithmetic behind ~1.5 us of load latency otherwise (three wavefronts per SIMD do not cover that)
-    float raw[4];
-    {
-        const float *seg = y + clip * stride + (long)t * kSpecHop;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) raw[j] = seg[src[j]];
-    }
+    float raw[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    bool have_raw = false;                                  // raw holds the samples of the frame about to be transformed
     for (int f = 0; f < n_here; ++f) {
+        if (OUT == SPEC_FLAGS && !((todo >> f) & 1)) {      // gated out: flag 0
+            have_raw = false;
+            if (++t == T) { t = 0; ++slot; if (f + 1 < n_here) clip = clip_of(slot); }
+            continue;
+        }
         const float mean_f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mean), f));
+        if (!have_raw) {
+            const float *seg = y + clip * stride + (long)t * kSpecHop;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw[j] = seg[src[j]];
+        }
         float cur[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) cur[j] = raw[j];
-        if (f + 1 < n_here) {
+        have_raw = f + 1 < n_here && ((todo >> (f + 1)) & 1);
+        if (have_raw) {
             const bool wrap = t + 1 == T;
             const long nclip = wrap ? clip_of(slot + 1) : clip;
             const float *seg = y + nclip * stride + (long)(wrap ? 0 : t + 1) * kSpecHop;
@@ -602,20 +654,20 @@ hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stri
     const long total = n_clips * T;
     const dim3 grid((unsigned)((total + 255) / 256));
     if (frame_major)
-        hipLaunchKernelGGL(spectrogram_kernel<SPEC_FRAME_MAJOR>, grid, dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits);
+        hipLaunchKernelGGL(spectrogram_kernel<SPEC_FRAME_MAJOR>, grid, dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits, (const int *)nullptr);
     else
-        hipLaunchKernelGGL(spectrogram_kernel<SPEC_BIN_MAJOR>, grid, dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits);
+        hipLaunchKernelGGL(spectrogram_kernel<SPEC_BIN_MAJOR>, grid, dim3(256), 0, stream, y, n_clips, n, stride, tables, sxx, T, means, hits, (const int *)nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_spectrogram_flags(const float *y, long n_clips, int n, long stride, const SpecTables *tables, int *flags,
-                                    hipStream_t stream, const float *means)
+                                    hipStream_t stream, const float *means, const int *gate)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0 || T <= 0) return hipSuccess;
     const long total = n_clips * T;
     hipLaunchKernelGGL(spectrogram_kernel<SPEC_FLAGS>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, y, n_clips, n, stride, tables,
-                       reinterpret_cast<float *>(flags), T, means, (const int *)nullptr);
+                       reinterpret_cast<float *>(flags), T, means, (const int *)nullptr, gate);
     return hipGetLastError();
 }
 
@@ -1011,6 +1063,17 @@ void build_spec_tables(int fs, SpecTables &t)
         c1 = (float)std::sqrt((1.0 + (double)c1) / 2.0);
         l1 <<= 1;
     }
+    // energy gate of the IIR kernel: the taper covers exactly the first and the last 32 samples of a segment
+    t.gate_ok = 1;
+    for (int i = kSpecSeg - kSpecHop; i < kSpecHop; ++i) t.gate_ok &= t.window[i] == 1.0f;
+    float c = 0.0f;
+    for (int i = 0; i < kSpecSeg; ++i) c += t.window[i] * t.window[i];
+    for (int i = 0; i < kSpecSeg - kSpecHop; ++i) {
+        t.win2_in[i] = t.window[i] * t.window[i];
+        t.win2_out[i] = t.window[kSpecHop + i] * t.window[kSpecHop + i];
+    }
+    t.win2_sum = c * 1.0001f;
+    t.gate_scale = 2.0f * (float)kSpecSeg / t.U * 1.01f;
     // the spectrogram kernel's short form of levels 0 and 1 (real input) is valid for exactly these twiddles
     t.trivial_first_levels = t.tw_re[0] == 1.0f && t.tw_im[0] == 0.0f && t.tw_re[1] == 1.0f && t.tw_im[1] == 0.0f &&
                              t.tw_re[2] == 0.0f && t.tw_im[2] == -1.0f;

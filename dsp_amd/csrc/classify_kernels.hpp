@@ -20,6 +20,11 @@ struct SpecTables {
     float tw_re[255], tw_im[255];   // level l starts at (1<<l) - 1
     float mp_keep_min;              // smallest float s with (float)(10 log10(s / 1e-12)) > 70 (filled on the device)
     int trivial_first_levels;       // 1 when the twiddles of FFT levels 0 and 1 are exactly (1,0), (1,0), (0,-1) (they are)
+    // energy gate (iir2_split_kernel -> spectrogram_kernel<SPEC_FLAGS>): squared taper of the first / last 32 samples of
+    // a segment, sum of the squared window, 2 N / U with 1 % margin, 1 when the window is exactly 1 in between
+    float win2_in[kSpecSeg - kSpecHop], win2_out[kSpecSeg - kSpecHop];
+    float win2_sum, gate_scale;
+    int gate_ok;
 };
 
 struct IirCoef { float b[9], a[9]; };
@@ -31,7 +36,8 @@ struct IirCoefD { double b[9], a[9]; };
 // their own outputs (classifier.cpp:329-333: 256 samples from 224 t, added in order) and store the segment
 // means means[c][t], so the spectrogram kernel need not walk the samples serially again.
 hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, const IirCoef &c1, float *y1,
-                          const IirCoef &c2, float *y2, hipStream_t stream, float *means1 = nullptr, float *means2 = nullptr);
+                          const IirCoef &c2, float *y2, hipStream_t stream, float *means1 = nullptr, float *means2 = nullptr,
+                          const SpecTables *tables = nullptr, int *gate2 = nullptr);
 hipError_t launch_iir_f64(const double *x, long n_clips, int n, long stride, const IirCoefD &c, double *y,
                           hipStream_t stream);
 // float rows, recurrence in double, one rounding on store (per-frame prefilter of BASELINE config 3)
@@ -56,7 +62,7 @@ hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stri
 // The 1000-3000 Hz spectrogram reduced to what find_midpoints reads from it (classifier.cpp:457-518): loud[c][T] = 1 for
 // the time bins with a cell above 70 dB.  The map itself is not written.
 hipError_t launch_spectrogram_flags(const float *y, long n_clips, int n, long stride, const SpecTables *tables, int *loud,
-                                    hipStream_t stream, const float *means = nullptr);
+                                    hipStream_t stream, const float *means = nullptr, const int *gate = nullptr);
 
 // classify() after the spectrograms (classifier.cpp:35-135), two kernels: midpoints from the loud time bins (records in
 // `trace`, label 0 when there are none), then the band sums + rule from the frame_major 3000-7500 Hz map for the clips that

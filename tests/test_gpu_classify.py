@@ -124,6 +124,35 @@ def test_long_and_short_clips_with_midpoints_vs_oracle(dsp):
         assert lab == olab and np.array_equal(mids, O.find_midpoints(x)) and np.array_equal(sums, osums)
 
 
+def test_energy_gate_never_hides_a_loud_frame(dsp):
+    """The IIR kernel marks frames whose energy bounds every PSD cell below the 70 dB threshold, and the flag spectrogram
+    skips them.  Signals around that threshold (noise and 2 kHz bursts over four decades of amplitude, with and without
+    a DC offset) must give the oracle's midpoints and labels exactly."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(2024)
+    n_clips, n = 192, 16000
+    t = np.arange(n, dtype=np.float64) / 16000.0
+    clips = np.empty((n_clips, n), np.float32)
+    for i in range(n_clips):
+        amp = 10.0 ** rng.uniform(-3.5, 0.0)
+        x = rng.uniform(-1, 1, n) * amp * 10.0 ** rng.uniform(-2, 0)
+        for _ in range(rng.integers(0, 4)):                            # tone bursts inside the 1000-3000 Hz band
+            t0, dur = rng.uniform(0, 0.8), rng.uniform(0.02, 0.4)
+            env = ((t >= t0) & (t < t0 + dur)).astype(np.float64)
+            x = x + amp * env * np.sin(2 * np.pi * rng.uniform(1100, 2900) * t)
+        if i % 3 == 0:
+            x = x + rng.uniform(-0.5, 0.5)
+        clips[i] = x.astype(np.float32)
+    labels, trace = dsp.classify_batch(clips, with_trace=True)
+    with_mids = 0
+    for x, lab, (mids, sums) in zip(clips, labels, trace):
+        olab, _, osums = O.classify(x)
+        omids = O.find_midpoints(x)
+        assert lab == olab and np.array_equal(mids, omids) and np.array_equal(sums, osums)
+        with_mids += len(omids) > 0
+    assert 20 < with_mids < n_clips - 20                               # both sides of the gate are exercised
+
+
 def test_fp64_filter_matches_postbutter_dump(dsp, golden):
     """donut-classifier/_postbutter.txt (fp64 DF-II, classifier.c:420-446) and the oracle, bit exact."""
     from oracle import oracle as O
