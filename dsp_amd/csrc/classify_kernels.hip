@@ -672,9 +672,9 @@ hipError_t launch_spectrogram_flags(const float *y, long n_clips, int n, long st
 }
 
 // ---------------------------------------------------------------------------------
-// a11: dB maps, normalisation band, midpoints, three band sums, rule.  One wave per clip:
-// element-wise steps and min/max (order-independent, exact) run across lanes; the
-// order-dependent float sums (cluster means, sum_intense) run on lane 0 in the reference order.
+// a11: midpoints, dB map, normalisation band, three band sums, rule (classify_midpoints_kernel, classify_bands_kernel).
+// Element-wise steps and min/max (order-independent, exact) run across lanes; the order-dependent float sums keep the
+// reference's order: cluster means on one lane, sum_intense as a chain of v_readlane adds over the packed kept cells.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float to_db(float s)
 {
