@@ -35,12 +35,25 @@ def main():
     p3 = dsp_amd.MfccPlan(dsp_amd.default_config(n_fft=1024, frame_length=1024, hop_length=1024, n_mels=128, prefilter=2))
     cases.append(("config 3 (IIR + 1024)", lambda: p3.frames(x1024)))
     cl = (torch.rand((4096, 16000), device="cuda", generator=gen) * 2 - 1) * 0.05
+    # a third of the clips carry call-like patterns (midpoints; some fire the rule): the work list between the midpoints
+    # and the band kernels is filled with atomics in any order, the results must not depend on it
+    from tests import signals as S
+    sig = S.classify_cases()
+    for k, name in enumerate(("scrub_a", "jay_like", "scrub_b")):
+        cl[k::9] = torch.from_numpy(sig[name]).cuda() + cl[k::9] * 0.01
     lab = torch.empty(4096, dtype=torch.int32, device="cuda")
+    host = cl[:512].cpu().numpy()
+
+    def cls_trace():
+        labels, trace = dsp_amd.classify_batch(host, with_trace=True)
+        flat = [np.concatenate([[l], m, q.ravel()]) for l, (m, q) in zip(labels, trace)]
+        return torch.from_numpy(np.concatenate(flat).astype(np.float32))
 
     def cls():
         dsp_amd.classify_device(cl, lab)
         return lab.clone()
     cases.append(("classify", cls))
+    cases.append(("classify + trace (host)", cls_trace))
     bad = 0
     for name, fn in cases:
         ref = fn().clone()
