@@ -479,13 +479,22 @@ ClassifyCtx g_cls;
 
 static_assert(sizeof(dsp::ClassifyTrace) == sizeof(dsp_classify_trace), "trace layouts must match");
 
-int cls_init()
+void cls_release();
+
+// device < 0: DSP_AMD_DEVICE or 0 (host entry points); otherwise the GPU the caller's buffers live on.  The context
+// (tables + workspace) belongs to one GPU at a time and moves when a call names another one.
+int cls_init(int device = -1)
 {
-    if (g_cls.d_tab) return DSP_OK;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback");
-    const char *dev = std::getenv("DSP_AMD_DEVICE");
-    g_cls.device = dev ? std::atoi(dev) : 0;
+    if (device < 0) {
+        const char *dev = std::getenv("DSP_AMD_DEVICE");
+        device = g_cls.d_tab ? g_cls.device : (dev ? std::atoi(dev) : 0);
+    }
+    if (device >= n) return fail(DSP_EINVAL, "device index out of range");
+    if (g_cls.d_tab && g_cls.device == device) return DSP_OK;
+    if (g_cls.d_tab) cls_release();
+    g_cls.device = device;
     DSP_HIP(hipSetDevice(g_cls.device));
     dsp::SpecTables t;
     dsp::build_spec_tables(16000, t);
@@ -497,6 +506,19 @@ int cls_init()
 }
 
 int spec_bins(int n) { return n < dsp::kSpecSeg ? 0 : (n - dsp::kSpecSeg) / dsp::kSpecHop + 1; }
+
+void cls_release()
+{
+    hipSetDevice(g_cls.device);
+    hipDeviceSynchronize();
+    for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_bp, (void *)g_cls.d_mp, (void *)g_cls.d_sbp, (void *)g_cls.d_loud, (void *)g_cls.d_gate,
+                    (void *)g_cls.d_mean_bp, (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_hits, (void *)g_cls.d_trace,
+                    (void *)g_cls.d_tab})
+        if (p) hipFree(p);
+    g_cls.d_x = g_cls.d_bp = g_cls.d_mp = g_cls.d_sbp = g_cls.d_mean_bp = g_cls.d_mean_mp = nullptr;
+    g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = g_cls.d_gate = nullptr; g_cls.d_trace = nullptr; g_cls.d_tab = nullptr;
+    g_cls.cap_clips = 0; g_cls.cap_n = 0;
+}
 
 int cls_reserve(long clips, int n)
 {
@@ -659,7 +681,12 @@ int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long s
     if (spec_bins(n) > 1024) return fail(DSP_EINVAL, "clip too long (more than 1024 spectrogram columns)");
     if (n_clips == 0) return DSP_OK;
     std::lock_guard<std::mutex> lock(g_cls.mu);
-    int rc = cls_init();
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, d_signal) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(DSP_EINVAL, "signal is not a device pointer");
+    }
+    int rc = cls_init(attr.device);
     if (rc < 0) return rc;
     DSP_HIP(hipSetDevice(g_cls.device));
     hipStream_t st = (hipStream_t)stream;
