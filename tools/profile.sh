@@ -15,6 +15,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "GRBM_GUI_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_TRANS"; do
     name=$(echo $grp | tr ' ' '_' | cut -c1-40)
-    timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -- $BENCH --steps 4 --warmup 2 > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || echo "pmc pass $name failed" >> "$OUT/errors.txt"
+    timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -- $BENCH --steps 4 --warmup 2 --settle 0 > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.err" || echo "pmc pass $name failed" >> "$OUT/errors.txt"
 done
 find "$OUT" -name "*.csv" | head -50
