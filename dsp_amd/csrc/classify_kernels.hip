@@ -892,13 +892,16 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
     // widened by a safety margin can survive the reference's test: those get the exact dB value and the reference's
     // own float comparison, all others are NaN in the reference as well.
     float smn = INFINITY, smx = -INFINITY;
-    float cell[USE_LDS ? kTailPerThread : 1];
     if (USE_LDS) {
+        // all loads of the thread in flight together, then the raw PSD values wait in the LDS map for their second pass
+        float cell[kTailPerThread];
 #pragma unroll
         for (int k = 0; k < kTailPerThread; ++k) cell[k] = tid + 256 * k < cells ? bp_g[tid + 256 * k] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < kTailPerThread; ++k)
+        for (int k = 0; k < kTailPerThread; ++k) {
             if (cell[k] > 0) { smn = fminf(smn, cell[k]); smx = fmaxf(smx, cell[k]); }
+            if (tid + 256 * k < cells) map_lds[tid + 256 * k] = cell[k];
+        }
     } else {
         for (int i = tid; i < cells; i += 256) {
             const float sv = bp_g[i];
@@ -942,10 +945,12 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
             wave_sync();
         };
         int pend = 0;                                        // wave-uniform
-#pragma unroll
+        // a rolled loop: the float64 log10 of keep() is inlined once, not once per cell of the thread (the unrolled form
+        // was 9 000 instructions, more than the instruction cache holds)
+#pragma unroll 1
         for (int k = 0; k < kTailPerThread; ++k) {
             const int idx = tid + 256 * k;
-            const float sv = cell[k];
+            const float sv = idx < cells ? map_lds[idx] : 0.0f;       // this thread's own store above
             const bool cand = idx < cells && sv >= s_lo && sv <= s_hi;
             if (idx < cells && !cand) map_lds[idx] = NAN;
             const unsigned long long m = __ballot(cand);
