@@ -9,5 +9,5 @@ LOG=$(mktemp)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -Wno-unused-value \
     -Rpass-analysis=kernel-resource-usage "$@" -o "$ROOT/variants/$NAME.so" capi.cpp capi_consumers.cpp tables.cpp mfcc_kernels.hip mfcc_row_kernel.hip mfcc1024_kernel.hip mfcc1024_wave_kernel.hip classify_kernels.hip svm_kernels.hip consumer_kernels.hip > "$LOG" 2>&1 || { grep -E "error" "$LOG" | head; rm -f "$LOG"; exit 1; }
 # resource usage of the default instantiation (reference shape, float input, tile epilogue)
-grep -A12 "Function Name: _ZN3dsp19mfcc512_wave_kernelILi4ELi10ELi3ELb1ELi1ELi0ELi1EE" "$LOG" | grep -E "VGPRs:|Occupancy \[|ScratchSize" | head -3
+grep -A12 "Function Name: _ZN3dsp19mfcc512_wave_kernelILi4ELi10ELi3ELi512ELi0ELi1ELb0ELb0EE" "$LOG" | grep -E "VGPRs:|Occupancy \[|ScratchSize" | head -3
 rm -f "$LOG"
