@@ -569,7 +569,7 @@ int cls_run(const float *d_x, long clips, int n, long stride, hipStream_t st)
     return DSP_OK;
 }
 
-// clips per pass through the workspace (270 KB per 1 s clip): large enough that lane-per-clip IIR waves fill the chip
+// clips per pass through the workspace (170 KB per 1 s clip): 768 blocks of 64 lanes = three resident IIR blocks per CU
 constexpr long kClsSubBatch = 49152;
 
 }  // namespace
