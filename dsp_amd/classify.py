@@ -72,6 +72,14 @@ def classify_batch(clips: np.ndarray, with_trace: bool = False):
     return labels, out
 
 
+def find_midpoints(data: np.ndarray, fs: int = 16000) -> np.ndarray:
+    """sync/lib/classifier.h:18: midpoints (seconds) of the loud 1000-3000 Hz stretches of one clip."""
+    data = np.ascontiguousarray(data, np.float32).reshape(-1)
+    out = np.zeros(64, np.float32)
+    n = _lib.check(_lib.load().dsp_find_midpoints(data.ctypes.data, data.size, int(fs), out.ctypes.data, out.size), "dsp_find_midpoints")
+    return out[:n].copy()
+
+
 def classify_device(clips, labels=None):
     """clips: cuda float32 [n_clips][n] -> cuda int32 labels; runs on torch's current stream."""
     import torch

@@ -702,6 +702,19 @@ int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long s
     return DSP_OK;
 }
 
+// sync/lib/classifier.h:18 (find_midpoints): the midpoints are a by-product of the classify pipeline (its trace record)
+int dsp_find_midpoints(const float *data, int num_frames, int fs, float *midpoints, int max_midpoints)
+{
+    if (!data || num_frames <= 0 || max_midpoints < 0 || (max_midpoints > 0 && !midpoints)) return fail(DSP_EINVAL, "bad argument");
+    if (fs != 16000) return fail(DSP_EINVAL, "find_midpoints: only 16000 Hz has filter coefficients (classifier.cpp:138-191)");
+    int label = 0;
+    dsp_classify_trace tr;
+    const int rc = dsp_classify_batch_host(data, 1, num_frames, num_frames, &label, &tr);
+    if (rc < 0) return rc;
+    for (int i = 0; i < tr.n_midpoints && i < max_midpoints; ++i) midpoints[i] = tr.midpoints[i];
+    return tr.n_midpoints;
+}
+
 // sync/lib/classifier.h:19.  Same contract: 0/1, 0 also on failure (reason in dsp_last_error()).
 int dsp_classify(float *data, int data_size)
 {

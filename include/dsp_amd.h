@@ -173,6 +173,14 @@ int dsp_classify_batch_host(const float *signal, long n_clips, int n, long strid
 int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long stride, int *d_labels,
                               void *stream);
 
+/* find_midpoints (sync/lib/classifier.h:18, classifier.cpp:433-598): the 1000-3000 Hz filter, its spectrogram,
+ * time bins above 70 dB, greedy clusters of at least 0.15 s -> their mean times, in seconds.  Host pointers.
+ * Returns the number of midpoints (at most 64 are found; the first max_midpoints are written) or a negative
+ * error; fs must be 16000 (the only rate butter_bandpass has coefficients for).  The reference's sum_intense
+ * (classifier.h:17) has no entry point of its own: it runs inside classify, its values are the `sums` of
+ * dsp_classify_trace.                                                              */
+int dsp_find_midpoints(const float *data, int num_frames, int fs, float *midpoints, int max_midpoints);
+
 /* --- pooling + SVM (cepstrum/scrubjay_infer.c:36-66, 105-141; scrubjay_svm.onnx) ------ */
 
 /* mfcc_stats pooling: feat[c][2*n_coef] = per-coefficient mean | population std over the T

@@ -39,6 +39,17 @@ def test_classify_entry_point_label(dsp, golden, name):
     assert dsp.classify(g[f"{name}__input"]) == int(g[f"{name}__label"])
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_find_midpoints_entry_point(dsp, golden, name):
+    g = golden("classifier_ref.npz")
+    assert np.array_equal(dsp.find_midpoints(g[f"{name}__input"]), g[f"{name}__midpoints"])
+
+
+def test_find_midpoints_rejects_other_rates(dsp):
+    with pytest.raises(dsp.DspError):
+        dsp.find_midpoints(np.zeros(16000, np.float32), fs=96000)
+
+
 def test_batch_labels_midpoints_and_band_sums(dsp, golden):
     from oracle import oracle as O
     g = golden("classifier_ref.npz")
