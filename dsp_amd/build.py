@@ -8,10 +8,22 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.environ.get("DSP_AMD_LIB") or os.path.join(PKG, "libdsp_amd.so")
-SOURCES = ["capi.cpp", "capi_consumers.cpp", "tables.cpp", "mfcc_kernels.hip", "mfcc_row_kernel.hip", "mfcc1024_kernel.hip", "mfcc1024_wave_kernel.hip", "classify_kernels.hip",
+SOURCES = ["capi.cpp", "capi_consumers.cpp", "capi_classifier_cxx.cpp", "tables.cpp", "mfcc_kernels.hip", "mfcc_row_kernel.hip", "mfcc1024_kernel.hip", "mfcc1024_wave_kernel.hip", "classify_kernels.hip",
            "svm_kernels.hip", "consumer_kernels.hip"]
-HEADERS = ["tables.hpp", "mfcc_kernels.hpp", "mfcc_device.hpp", "classify_kernels.hpp", "svm_kernels.hpp", "consumer_kernels.hpp", "capi_util.hpp",
-           os.path.join("..", "..", "include", "dsp_amd.h")]
+HEADERS = ["exports.map", "tables.hpp", "mfcc_kernels.hpp", "mfcc_device.hpp", "classify_kernels.hpp", "svm_kernels.hpp", "consumer_kernels.hpp", "capi_util.hpp",
+           os.path.join("..", "..", "include", "dsp_amd.h"), os.path.join("..", "..", "include", "dsp_amd_classifier.h")]
+
+
+def source_hash() -> str:
+    """sha256 over every source and header of the library, compiled into it (dsp_version()) so that a loaded
+    binary can be checked against the tree it claims to come from."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        h.update(name.encode())
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def _hipcc() -> str:
@@ -52,8 +64,11 @@ def _build_locked(verbose: bool) -> str:
     # -fno-slp-vectorize: packed fp32 VALU (v_pk_fma_f32 ...) issues at half rate on
     # gfx950, so SLP packing only adds register shuffles (measured: 292 -> 222
     # issue slots per frame, 126 -> 108 VGPRs).
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-slp-vectorize", "-Wno-unused-value", "-o", tmp]
+    # -fvisibility=hidden: only what include/dsp_amd.h and include/dsp_amd_classifier.h declare is exported
+    # (#pragma GCC visibility push(default) in those headers); tests/test_capi_cpu.py asserts the export list.
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-fno-slp-vectorize", "-Wno-unused-value", f'-DDSP_AMD_SRC_HASH="{source_hash()}"',
+           "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", tmp]
     cmd += os.environ.get("DSP_AMD_EXTRA_FLAGS", "").split()
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

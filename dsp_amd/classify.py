@@ -54,14 +54,30 @@ def classify(data: np.ndarray) -> int:
     return int(_lib.load().dsp_classify(data.ctypes.data, data.size))
 
 
-def classify_batch(clips: np.ndarray, with_trace: bool = False):
-    """clips [n_clips][n] float32 (host) -> labels int32 [n_clips] (+ per-clip midpoints / band sums)."""
+# thresholds of the reference's variants: (keep_lo, keep_hi, midpoint_db, middle_max, above_min, below_min)
+CLASSIFY_SYNC_LIB = (0.65, 0.80, 70.0, 100.0, 200.0, 80.0)        # sync/lib/classifier.cpp:67-68, :436, :109 (default)
+CLASSIFY_MICROPHONE = (0.70, 0.85, 45.0, 100.0, 200.0, 150.0)     # microphone/src/classifier.cpp:79-80, :448, :123
+
+
+def classify_config(values=None) -> "_lib.ClassifyConfig":
+    """dsp_classify_config: the library's defaults (sync/lib thresholds) or a 6-tuple like CLASSIFY_MICROPHONE."""
+    c = _lib.ClassifyConfig()
+    _lib.load().dsp_classify_default_config(C.byref(c))
+    if values is not None:
+        c.keep_lo, c.keep_hi, c.midpoint_db, c.middle_max, c.above_min, c.below_min = (float(v) for v in values)
+    return c
+
+
+def classify_batch(clips: np.ndarray, with_trace: bool = False, config=None):
+    """clips [n_clips][n] float32 (host) -> labels int32 [n_clips] (+ per-clip midpoints / band sums).
+    config: None (sync/lib thresholds) or a 6-tuple / ClassifyConfig (dsp_classify_batch_host_cfg)."""
     clips = np.ascontiguousarray(np.atleast_2d(clips), np.float32)
     n_clips, n = clips.shape
     labels = np.zeros(n_clips, np.int32)
     tr = (_lib.ClassifyTrace * n_clips)() if with_trace else None
-    _lib.check(_lib.load().dsp_classify_batch_host(clips.ctypes.data, n_clips, n, n, labels.ctypes.data,
-                                                    C.byref(tr) if with_trace else None), "dsp_classify_batch_host")
+    cfg = None if config is None else (config if isinstance(config, _lib.ClassifyConfig) else classify_config(config))
+    _lib.check(_lib.load().dsp_classify_batch_host_cfg(C.byref(cfg) if cfg is not None else None, clips.ctypes.data, n_clips, n, n,
+                                                        labels.ctypes.data, C.byref(tr) if with_trace else None), "dsp_classify_batch_host_cfg")
     if not with_trace:
         return labels
     out = []
@@ -80,7 +96,7 @@ def find_midpoints(data: np.ndarray, fs: int = 16000) -> np.ndarray:
     return out[:n].copy()
 
 
-def classify_device(clips, labels=None):
+def classify_device(clips, labels=None, config=None):
     """clips: cuda float32 [n_clips][n] -> cuda int32 labels; runs on torch's current stream."""
     import torch
     if not (clips.is_cuda and clips.dtype == torch.float32 and clips.dim() == 2 and clips.stride(1) == 1):
@@ -89,6 +105,7 @@ def classify_device(clips, labels=None):
     if labels is None:
         labels = torch.empty(n_clips, dtype=torch.int32, device=clips.device)
     st = C.c_void_p(torch.cuda.current_stream(clips.device).cuda_stream)
-    _lib.check(_lib.load().dsp_classify_batch_device(clips.data_ptr(), n_clips, n, clips.stride(0), labels.data_ptr(), st),
-               "dsp_classify_batch_device")
+    cfg = None if config is None else (config if isinstance(config, _lib.ClassifyConfig) else classify_config(config))
+    _lib.check(_lib.load().dsp_classify_batch_device_cfg(C.byref(cfg) if cfg is not None else None, clips.data_ptr(), n_clips, n,
+                                                          clips.stride(0), labels.data_ptr(), st), "dsp_classify_batch_device_cfg")
     return labels

@@ -87,13 +87,20 @@ struct dsp_mfcc_plan {
     // staging for the host-pointer entry points
     float *d_in = nullptr, *d_out = nullptr;
     size_t in_cap = 0, out_cap = 0;
-    std::mutex mu;
+    // Guards the plan's workspaces (d_filtered, d_frame_max / d_clip_floor, d_in / d_out) while a call reserves them and
+    // enqueues the kernels that use them.  The kernels themselves run after the lock is released: a plan whose path uses
+    // a workspace (prefilter, DSP_LOG_GLOBAL_REF1 over clips, the *_host entry points) serves ONE stream at a time;
+    // the workspace-free paths (frames / clips / pcm16 / fused, per-frame log mode) may be driven from several streams.
+    std::recursive_mutex mu;
 };
 
 extern "C" {
 
 const char *dsp_last_error(void) { return g_err.c_str(); }
-const char *dsp_version(void) { return "dsp_amd 0.1 (gfx950)"; }
+#ifndef DSP_AMD_SRC_HASH
+#define DSP_AMD_SRC_HASH "unknown"
+#endif
+const char *dsp_version(void) { return "dsp_amd 0.2 (gfx950) src:" DSP_AMD_SRC_HASH; }
 
 int dsp_device_count(void)
 {
@@ -288,6 +295,7 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
                long clip_stride, void *stream, int in_kind = 0)
 {
     if (n_frames == 0) return DSP_OK;
+    DSP_HIP(hipSetDevice(p->device));       // the caller's current device may be another GPU: tables and workspaces live on the plan's
     const bool single_clip = frames_per_clip > 0 && n_frames == frames_per_clip;   // stride unused
     if ((reinterpret_cast<uintptr_t>(d_in) & (in_kind == 1 ? 3 : 7)) || (!single_clip && (clip_stride & 1)))
         return fail(DSP_EINVAL, "input must be 8-byte aligned (4 for mono int16) with an even clip stride");
@@ -334,6 +342,7 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
         // floor per clip, pass 2 is the normal kernel clipping at that floor
         const long n_clips = n_frames / frames_per_clip;
         int rc;
+        std::lock_guard<std::recursive_mutex> lock(p->mu);
         if ((rc = reserve(&p->d_frame_max, &p->frame_max_cap, (size_t)n_frames * sizeof(float))) < 0) return rc;
         if ((rc = reserve(&p->d_clip_floor, &p->clip_floor_cap, (size_t)n_clips * sizeof(float))) < 0) return rc;
         a.frame_max = p->d_frame_max;
@@ -367,7 +376,7 @@ int dsp_mfcc_frames_device(dsp_mfcc_plan *p, const float *d_frames, long n_frame
     // BASELINE config 3: 8th-order Butterworth (donut-classifier/classifier.c:420-446, float64) over each
     // frame from zero state, rounded to float, then the MFCC chain.  Filtered frames go through a
     // bounded workspace (sub-batches of <= 1 Mi frames) instead of a second full-size buffer.
-    std::lock_guard<std::mutex> lock(p->mu);
+    std::lock_guard<std::recursive_mutex> lock(p->mu);
     DSP_HIP(hipSetDevice(p->device));
     const int fl = p->cfg.frame_length;
     const long sub = std::min<long>(n_frames, 1L << 20);
@@ -417,7 +426,7 @@ int dsp_mfcc_frames_host(dsp_mfcc_plan *p, const float *frames, long n_frames, f
 {
     if (!p || n_frames < 0 || (n_frames > 0 && (!frames || !out))) return fail(DSP_EINVAL, "bad argument");
     if (n_frames == 0) return DSP_OK;
-    std::lock_guard<std::mutex> lock(p->mu);
+    std::lock_guard<std::recursive_mutex> lock(p->mu);
     DSP_HIP(hipSetDevice(p->device));
     const size_t in_b = (size_t)n_frames * p->cfg.frame_length * sizeof(float);
     const size_t out_b = (size_t)n_frames * p->cfg.n_mfcc * sizeof(float);
@@ -440,7 +449,7 @@ int dsp_mfcc_clips_host(dsp_mfcc_plan *p, const float *signal, long n_clips, int
     if (t == 0 || n_clips == 0) return 0;
     if (!signal || !out) return fail(DSP_EINVAL, "NULL buffer");
     if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
-    std::lock_guard<std::mutex> lock(p->mu);
+    std::lock_guard<std::recursive_mutex> lock(p->mu);
     DSP_HIP(hipSetDevice(p->device));
     // device copy is packed with an even stride so every frame start stays 8-byte aligned
     const long dstride = samples_per_clip + (samples_per_clip & 1);
@@ -456,6 +465,8 @@ int dsp_mfcc_clips_host(dsp_mfcc_plan *p, const float *signal, long n_clips, int
     DSP_HIP(hipStreamSynchronize(nullptr));
     return t;
 }
+
+}  // extern "C"
 
 // ---- donut classifier path ------------------------------------------------------------
 
@@ -473,9 +484,28 @@ struct ClassifyCtx {
     dsp::ClassifyTrace *d_trace = nullptr;
     long cap_clips = 0;
     int cap_n = 0;
+    float keep_min_db = 70.0f;                             // the midpoint threshold d_tab->mp_keep_min was computed for
+    bool gate_ok = false;                                  // SpecTables::gate_ok of d_tab
     std::mutex mu;
 };
 ClassifyCtx g_cls;
+
+// 957 columns = 13.4 s: a midpoint needs a cluster of >= 12 columns (0.15 s at 14 ms per column) followed by a gap of >= 4
+// (0.05 s), so 64 * 15 - 3 columns cannot hold more than the kMaxMidpoints = 64 a trace record has room for
+constexpr int kMaxSpecColumns = 957;
+
+bool valid_classify_cfg(const dsp_classify_config &c)
+{
+    auto fin = [](float v) { return v == v && v - v == 0.0f; };
+    return fin(c.keep_lo) && fin(c.keep_hi) && fin(c.midpoint_db) && fin(c.middle_max) && fin(c.above_min) && fin(c.below_min) &&
+           c.keep_lo < c.keep_hi;
+}
+
+dsp_classify_config default_classify_cfg()
+{
+    // sync/lib/classifier.cpp:67-68 (0.65 / 0.80), :436 (70 dB), :109 (100 / 200 / 80)
+    return dsp_classify_config{0.65f, 0.80f, 70.0f, 100.0f, 200.0f, 80.0f};
+}
 
 static_assert(sizeof(dsp::ClassifyTrace) == sizeof(dsp_classify_trace), "trace layouts must match");
 
@@ -500,12 +530,15 @@ int cls_init(int device = -1)
     dsp::build_spec_tables(16000, t);
     DSP_HIP(hipMalloc(&g_cls.d_tab, sizeof(t)));
     DSP_HIP(hipMemcpy(g_cls.d_tab, &t, sizeof(t), hipMemcpyHostToDevice));
-    DSP_HIP(dsp::launch_spec_threshold(g_cls.d_tab, nullptr));
+    g_cls.gate_ok = t.gate_ok != 0;
+    g_cls.keep_min_db = 70.0f;
+    DSP_HIP(dsp::launch_spec_threshold(g_cls.d_tab, g_cls.keep_min_db, nullptr));
     DSP_HIP(hipStreamSynchronize(nullptr));
     return DSP_OK;
 }
 
 int spec_bins(int n) { return n < dsp::kSpecSeg ? 0 : (n - dsp::kSpecSeg) / dsp::kSpecHop + 1; }
+long cls_row(int n) { return ((long)n + 3) & ~3L; }      // workspace row: n floats rounded up to 16 bytes
 
 void cls_release()
 {
@@ -529,7 +562,7 @@ int cls_reserve(long clips, int n)
     g_cls.d_x = g_cls.d_bp = g_cls.d_mp = g_cls.d_sbp = g_cls.d_mean_bp = g_cls.d_mean_mp = nullptr;
     g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = g_cls.d_gate = nullptr; g_cls.d_trace = nullptr;
     g_cls.cap_clips = 0; g_cls.cap_n = 0;
-    const size_t sig = (size_t)clips * n * sizeof(float);
+    const size_t sig = (size_t)clips * cls_row(n) * sizeof(float);
     const size_t spec = (size_t)clips * dsp::kSpecBins * std::max(1, spec_bins(n)) * sizeof(float);
     DSP_HIP(hipMalloc(&g_cls.d_x, sig));
     DSP_HIP(hipMalloc(&g_cls.d_bp, sig));
@@ -556,16 +589,24 @@ dsp::IirCoef coef_f32(double lo, double hi)
 }
 
 // one sub-batch already resident at d_x (row stride n): labels (+ trace) into the workspace
-int cls_run(const float *d_x, long clips, int n, long stride, hipStream_t st)
+int cls_run(const dsp_classify_config &cfg, const float *d_x, long clips, int n, long stride, hipStream_t st)
 {
     const dsp::IirCoef bp = coef_f32(3000, 7500), mp = coef_f32(1000, 3000);   // classifier.cpp:14-19, 438-442
-    DSP_HIP(dsp::launch_iir_f32(d_x, clips, n, stride, bp, g_cls.d_bp, mp, g_cls.d_mp, st, g_cls.d_mean_bp, g_cls.d_mean_mp, g_cls.d_tab, g_cls.d_gate));
-    // the IIR kernel writes with the input's row stride; the workspace rows are n long
+    if (cfg.midpoint_db != g_cls.keep_min_db) {      // the table's threshold PSD value follows the configured dB threshold
+        DSP_HIP(hipDeviceSynchronize());             // earlier calls (other streams) may still read the old value
+        DSP_HIP(dsp::launch_spec_threshold(g_cls.d_tab, cfg.midpoint_db, st));
+        g_cls.keep_min_db = cfg.midpoint_db;
+    }
+    const dsp::ClassifyRule rule{cfg.keep_lo, cfg.keep_hi, cfg.middle_max, cfg.above_min, cfg.below_min};
+    // the filtered copies are packed (rows of n rounded up to 16 bytes) whatever the input's stride
+    const long ys = cls_row(n);
+    DSP_HIP(dsp::launch_iir_f32(d_x, clips, n, stride, bp, g_cls.d_bp, mp, g_cls.d_mp, st, g_cls.d_mean_bp, g_cls.d_mean_mp, g_cls.d_tab, g_cls.d_gate,
+                                ys, g_cls.gate_ok));
     // midpoints first (1000-3000 Hz map); the 3000-7500 Hz spectrogram and its band sums only for clips that have midpoints
-    DSP_HIP(dsp::launch_spectrogram_flags(g_cls.d_mp, clips, n, stride, g_cls.d_tab, g_cls.d_loud, st, g_cls.d_mean_mp, g_cls.d_gate));
+    DSP_HIP(dsp::launch_spectrogram_flags(g_cls.d_mp, clips, n, ys, g_cls.d_tab, g_cls.d_loud, st, g_cls.d_mean_mp, g_cls.d_gate));
     DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_loud, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st));
-    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_bp, clips, n, stride, g_cls.d_tab, g_cls.d_sbp, st, g_cls.d_mean_bp, g_cls.d_hits, true));
-    DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st));
+    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_bp, clips, n, ys, g_cls.d_tab, g_cls.d_sbp, st, g_cls.d_mean_bp, g_cls.d_hits, true));
+    DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, rule));
     return DSP_OK;
 }
 
@@ -624,8 +665,7 @@ int dsp_butter_bandpass_filter_f64(const double *data, long n_clips, int n, long
 
 int dsp_compute_spectrogram_f32(const float *signal, int n, int fs, float *frequencies, float *times, float *sxx)
 {
-    if (!signal || !sxx || n < 0) return fail(DSP_EINVAL, "bad argument");
-    if (fs != 16000) return fail(DSP_EINVAL, "only fs = 16000 (the reference's samplingFreq) is tabulated");
+    if (!signal || !sxx || n < 0 || fs <= 0) return fail(DSP_EINVAL, "bad argument");
     const int T = spec_bins(n);
     if (frequencies)
         for (int k = 0; k < dsp::kSpecBins; ++k) frequencies[k] = (float)k * (float)fs / (float)dsp::kSpecSeg;   // classifier.cpp:248-251
@@ -637,22 +677,59 @@ int dsp_compute_spectrogram_f32(const float *signal, int n, int fs, float *frequ
     if (rc < 0) return rc;
     DSP_HIP(hipSetDevice(g_cls.device));
     float *dx = nullptr, *ds = nullptr;
+    dsp::SpecTables *dt = nullptr;               // fs enters only through the PSD scale U = fs * sum w^2 (classifier.cpp:296-301)
     DSP_HIP(hipMalloc(&dx, (size_t)n * sizeof(float)));
     const size_t sb = (size_t)dsp::kSpecBins * T * sizeof(float);
     if (hipMalloc(&ds, sb) != hipSuccess) { hipFree(dx); return fail(DSP_ENOMEM, "hipMalloc"); }
-    hipError_t e = hipMemcpy(dx, signal, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = dsp::launch_spectrogram_f32(dx, 1, n, n, g_cls.d_tab, ds, nullptr);
+    hipError_t e = hipSuccess;
+    if (fs != 16000) {
+        dsp::SpecTables t;
+        dsp::build_spec_tables(fs, t);
+        e = hipMalloc(&dt, sizeof(t));
+        if (e == hipSuccess) e = hipMemcpy(dt, &t, sizeof(t), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipMemcpy(dx, signal, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dsp::launch_spectrogram_f32(dx, 1, n, n, dt ? dt : g_cls.d_tab, ds, nullptr);
     if (e == hipSuccess) e = hipMemcpy(sxx, ds, sb, hipMemcpyDeviceToHost);
     hipFree(dx); hipFree(ds);
+    if (dt) hipFree(dt);
     if (e != hipSuccess) return fail(DSP_EHIP, hipGetErrorString(e));
     return T;
 }
 
-int dsp_classify_batch_host(const float *signal, long n_clips, int n, long stride, int *labels,
-                            dsp_classify_trace *trace)
+int dsp_sum_intense_f32(float lower, float upper, float half_range, const float *frequencies, int freq_bins,
+                        const float *times, int time_bins, const float *db, float midpoint, float *out)
+{
+    if (!frequencies || !times || !db || !out || freq_bins <= 0 || time_bins <= 0) return fail(DSP_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    int rc = cls_init();
+    if (rc < 0) return rc;
+    DSP_HIP(hipSetDevice(g_cls.device));
+    const size_t nf = freq_bins, nt = time_bins, total = nf + nt + nf * nt + 1;
+    float *d = nullptr;
+    DSP_HIP(hipMalloc(&d, total * sizeof(float)));
+    hipError_t e = hipMemcpy(d, frequencies, nf * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + nf, times, nt * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + nf + nt, db, nf * nt * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dsp::launch_sum_intense(lower, upper, half_range, d, freq_bins, d + nf, time_bins, d + nf + nt, midpoint, d + nf + nt + nf * nt, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d + nf + nt + nf * nt, sizeof(float), hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return fail(DSP_EHIP, hipGetErrorString(e));
+    return DSP_OK;
+}
+
+void dsp_classify_default_config(dsp_classify_config *cfg)
+{
+    if (cfg) *cfg = default_classify_cfg();
+}
+
+int dsp_classify_batch_host_cfg(const dsp_classify_config *cfgp, const float *signal, long n_clips, int n, long stride, int *labels,
+                                dsp_classify_trace *trace)
 {
     if (!signal || !labels || n_clips < 0 || n < 0 || (n_clips > 1 && stride < n)) return fail(DSP_EINVAL, "bad argument");
-    if (spec_bins(n) > 1024) return fail(DSP_EINVAL, "clip too long (more than 1024 spectrogram columns)");
+    const dsp_classify_config cfg = cfgp ? *cfgp : default_classify_cfg();
+    if (!valid_classify_cfg(cfg)) return fail(DSP_EINVAL, "classify config: thresholds must be finite with keep_lo < keep_hi");
+    if (spec_bins(n) > kMaxSpecColumns) return fail(DSP_EINVAL, "clip too long (more than 957 spectrogram columns = 13.4 s at 16 kHz)");
     if (spec_bins(n) == 0) {      // clips shorter than one segment cannot fire the rule
         for (long c = 0; c < n_clips; ++c) labels[c] = 0;
         if (trace) std::memset(trace, 0, sizeof(*trace) * (size_t)n_clips);
@@ -665,9 +742,9 @@ int dsp_classify_batch_host(const float *signal, long n_clips, int n, long strid
     for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
         const long cnt = std::min(kClsSubBatch, n_clips - c0);
         if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n)) < 0) return rc;
-        DSP_HIP(hipMemcpy2DAsync(g_cls.d_x, (size_t)n * sizeof(float), signal + c0 * stride, (size_t)stride * sizeof(float),
+        DSP_HIP(hipMemcpy2DAsync(g_cls.d_x, (size_t)cls_row(n) * sizeof(float), signal + c0 * stride, (size_t)stride * sizeof(float),
                                  (size_t)n * sizeof(float), cnt, hipMemcpyHostToDevice, nullptr));
-        if ((rc = cls_run(g_cls.d_x, cnt, n, n, nullptr)) < 0) return rc;
+        if ((rc = cls_run(cfg, g_cls.d_x, cnt, n, cls_row(n), nullptr)) < 0) return rc;
         DSP_HIP(hipMemcpyAsync(labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, nullptr));
         if (trace) DSP_HIP(hipMemcpyAsync(trace + c0, g_cls.d_trace, (size_t)cnt * sizeof(dsp::ClassifyTrace), hipMemcpyDeviceToHost, nullptr));
         DSP_HIP(hipStreamSynchronize(nullptr));
@@ -675,10 +752,18 @@ int dsp_classify_batch_host(const float *signal, long n_clips, int n, long strid
     return DSP_OK;
 }
 
-int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long stride, int *d_labels, void *stream)
+int dsp_classify_batch_host(const float *signal, long n_clips, int n, long stride, int *labels, dsp_classify_trace *trace)
+{
+    return dsp_classify_batch_host_cfg(nullptr, signal, n_clips, n, stride, labels, trace);
+}
+
+int dsp_classify_batch_device_cfg(const dsp_classify_config *cfgp, const float *d_signal, long n_clips, int n, long stride,
+                                  int *d_labels, void *stream)
 {
     if (!d_signal || !d_labels || n_clips < 0 || n < 0 || (n_clips > 1 && stride < n)) return fail(DSP_EINVAL, "bad argument");
-    if (spec_bins(n) > 1024) return fail(DSP_EINVAL, "clip too long (more than 1024 spectrogram columns)");
+    const dsp_classify_config cfg = cfgp ? *cfgp : default_classify_cfg();
+    if (!valid_classify_cfg(cfg)) return fail(DSP_EINVAL, "classify config: thresholds must be finite with keep_lo < keep_hi");
+    if (spec_bins(n) > kMaxSpecColumns) return fail(DSP_EINVAL, "clip too long (more than 957 spectrogram columns = 13.4 s at 16 kHz)");
     if (n_clips == 0) return DSP_OK;
     std::lock_guard<std::mutex> lock(g_cls.mu);
     hipPointerAttribute_t attr;
@@ -693,13 +778,17 @@ int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long s
     if (spec_bins(n) == 0) { DSP_HIP(hipMemsetAsync(d_labels, 0, (size_t)n_clips * sizeof(int), st)); DSP_HIP(hipStreamSynchronize(st)); return DSP_OK; }
     for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
         const long cnt = std::min(kClsSubBatch, n_clips - c0);
-        // the kernels write filtered rows with the input's stride: size the workspace for it
-        if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), (int)std::max<long>(n, stride))) < 0) return rc;
-        if ((rc = cls_run(d_signal + c0 * stride, cnt, n, stride, st)) < 0) return rc;
+        if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n)) < 0) return rc;
+        if ((rc = cls_run(cfg, d_signal + c0 * stride, cnt, n, stride, st)) < 0) return rc;
         DSP_HIP(hipMemcpyAsync(d_labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, st));
     }
     DSP_HIP(hipStreamSynchronize(st));      // the workspace is shared: it must be idle before the lock is released
     return DSP_OK;
+}
+
+int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long stride, int *d_labels, void *stream)
+{
+    return dsp_classify_batch_device_cfg(nullptr, d_signal, n_clips, n, stride, d_labels, stream);
 }
 
 // sync/lib/classifier.h:18 (find_midpoints): the midpoints are a by-product of the classify pipeline (its trace record)
@@ -744,6 +833,14 @@ int dsp_mfcc_stats_device(const float *d_mfcc, long n_clips, int n_frames, int n
 {
     if (n_clips < 0 || n_frames <= 0 || n_coef <= 0 || n_coef > 64 || (n_clips > 0 && (!d_mfcc || !d_feat)))
         return fail(DSP_EINVAL, "bad argument");
+    if (n_clips > 0) {      // no handle here: launch on the GPU the caller's buffer lives on
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, d_mfcc) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+            (void)hipGetLastError();
+            return fail(DSP_EINVAL, "d_mfcc is not a device pointer");
+        }
+        DSP_HIP(hipSetDevice(attr.device));
+    }
     DSP_HIP(dsp::launch_mfcc_stats(d_mfcc, n_clips, n_frames, n_coef, d_feat, (hipStream_t)stream));
     return DSP_OK;
 }
@@ -796,6 +893,8 @@ int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signa
     if (!d_signal || !d_labels) return fail(DSP_EINVAL, "NULL buffer");
     if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
     if ((reinterpret_cast<uintptr_t>(d_signal) & 7) || (n_clips > 1 && (clip_stride & 1))) return fail(DSP_EINVAL, "input must be 8-byte aligned with an even clip stride");
+    if (s->device != p->device) return fail(DSP_EINVAL, "plan and SVM live on different devices");
+    DSP_HIP(hipSetDevice(p->device));
     dsp::Mfcc512Args a{};
     a.in = d_signal;
     a.in_kind = 0;
@@ -827,6 +926,7 @@ int dsp_svm_predict_device(dsp_svm *s, const float *d_feat, long n_clips, int *d
                            float *d_prob1, void *stream)
 {
     if (!s || n_clips < 0 || (n_clips > 0 && (!d_feat || !d_labels))) return fail(DSP_EINVAL, "bad argument");
+    DSP_HIP(hipSetDevice(s->device));
     DSP_HIP(dsp::launch_svm_predict(s->m, d_feat, n_clips, d_labels, d_decision, d_prob1, (hipStream_t)stream));
     return DSP_OK;
 }
@@ -841,7 +941,7 @@ static std::mutex g_default_mu;
 // 2fa/audio/word/c/mfcc.h:16-19.  Same contract as the reference: returns the
 // frame count, 0 for "clip too short / no room"; a GPU failure also returns 0
 // (no frames were produced) with the cause in dsp_last_error().
-int compute_mfcc(const float *signal, int num_samples, float *out_mfcc, int max_frames)
+extern "C" int compute_mfcc(const float *signal, int num_samples, float *out_mfcc, int max_frames)
 {
     dsp_mfcc_config cfg;
     dsp_mfcc_default_config(&cfg);
@@ -866,5 +966,3 @@ int compute_mfcc(const float *signal, int num_samples, float *out_mfcc, int max_
     }
     return t;
 }
-
-}  // extern "C"

@@ -54,7 +54,7 @@ __device__ __forceinline__ T iir_step(IirState<T> &s, const C &c, T x)
 // recurrences of the two filters run side by side instead of back to back in one lane.
 // MEANS (float): also emit the spectrogram's segment means of the outputs (see classify_kernels.hpp).
 template <typename T, typename C, bool TWO, typename TIO = T, bool MEANS = false>
-__global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restrict__ x, long n_clips, int n, long stride,
+__global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restrict__ x, long n_clips, int n, long stride, long ystride,
                                                              const C c1, TIO *__restrict__ y1, const C c2, TIO *__restrict__ y2,
                                                              float *__restrict__ means1 = nullptr, float *__restrict__ means2 = nullptr)
 {
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restri
 #pragma unroll
     for (int j = 0; j < 8; ++j) st.d[j] = T(0);
     // 16-byte vector path needs every row start and every tile start 16-byte aligned
-    const bool vec_ok = (stride * sizeof(TIO)) % 16 == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0 &&
+    const bool vec_ok = (stride * sizeof(TIO)) % 16 == 0 && (ystride * sizeof(TIO)) % 16 == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0 &&
                         (reinterpret_cast<uintptr_t>(y1) % 16) == 0 && (!TWO || (reinterpret_cast<uintptr_t>(y2) % 16) == 0);
     float cur = 0.0f, prev = 0.0f;                    // MEANS: running sums of the current and the previous segment
     const int n_seg = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
@@ -159,13 +159,13 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restri
 #pragma unroll
                     for (int i = 0; i < PER; ++i) tmp[i] = to[r * IIR_LD + cc + i];
                     __builtin_memcpy(&q, tmp, 16);
-                    *reinterpret_cast<f4nt *>(y + (clip0 + r) * stride + t0 + cc) = q;
+                    *reinterpret_cast<f4nt *>(y + (clip0 + r) * ystride + t0 + cc) = q;
                 }
             }
         } else
         for (int e = lane; e < 64 * IIR_TS; e += 64) {
             const int r = e / IIR_TS, cidx = e % IIR_TS;
-            if (r < rows && cidx < cols) y[(clip0 + r) * stride + t0 + cidx] = to[r * IIR_LD + cidx];
+            if (r < rows && cidx < cols) y[(clip0 + r) * ystride + t0 + cidx] = to[r * IIR_LD + cidx];
         }
         // no barrier here: the next iteration refills tin (read before the barrier above) and the barrier
         // after that refill orders this tile's reads of tout before the next tile's writes
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restri
 // run the taps one tile behind, keep the spectrogram's segment sums and store y.  Every sample
 // sees exactly the reference's operations in the reference's order (classifier.cpp:199-216).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict__ x, long n_clips, int n, long stride,
+__global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict__ x, long n_clips, int n, long stride, long ystride,
                                                          const IirCoef c1, float *__restrict__ y1, const IirCoef c2, float *__restrict__ y2,
                                                          float *__restrict__ means1, float *__restrict__ means2,
                                                          const SpecTables *__restrict__ tab, int *__restrict__ gate2)
@@ -353,13 +353,13 @@ __global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict
                     const int r = e / CH, cc = (e % CH) * 4;
                     if (r < rows) {                                  // streamed out: nothing in this kernel reads it back (-10 %)
                         const f4nt q = {yo[r * IIR_LD + cc], yo[r * IIR_LD + cc + 1], yo[r * IIR_LD + cc + 2], yo[r * IIR_LD + cc + 3]};
-                        __builtin_nontemporal_store(q, reinterpret_cast<f4nt *>(y + (clip0 + r) * stride + t0 + cc));
+                        __builtin_nontemporal_store(q, reinterpret_cast<f4nt *>(y + (clip0 + r) * ystride + t0 + cc));
                     }
                 }
             } else {
                 for (int e = lane; e < 64 * IIR_TS; e += 64) {
                     const int r = e / IIR_TS, ci = e % IIR_TS;
-                    if (r < rows && ci < cols) y[(clip0 + r) * stride + t0 + ci] = yo[r * IIR_LD + ci];
+                    if (r < rows && ci < cols) y[(clip0 + r) * ystride + t0 + ci] = yo[r * IIR_LD + ci];
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -372,24 +372,27 @@ __global__ __launch_bounds__(256) void iir2_split_kernel(const float *__restrict
 
 hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, const IirCoef &c1, float *y1,
                           const IirCoef &c2, float *y2, hipStream_t stream, float *means1, float *means2,
-                          const SpecTables *tables, int *gate2)
+                          const SpecTables *tables, int *gate2, long ystride, bool gate_tables_ok)
 {
     if (n_clips <= 0 || n <= 0) return hipSuccess;
+    if (ystride <= 0) ystride = stride;
     const int blocks = (int)((n_clips + 63) / 64);
-    const bool aligned = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y1) % 16 == 0 &&
-                         reinterpret_cast<uintptr_t>(y2) % 16 == 0;
-    if (gate2 && !(y2 && aligned)) {      // only the split kernel computes the gate: every frame is "maybe" (non-zero ints)
+    const bool aligned = stride % 4 == 0 && ystride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                         reinterpret_cast<uintptr_t>(y1) % 16 == 0 && reinterpret_cast<uintptr_t>(y2) % 16 == 0;
+    // only the split kernel computes the gate, and only when the window tables allow it (SpecTables::gate_ok): otherwise
+    // every frame is "maybe" (non-zero ints)
+    if (gate2 && !(y2 && aligned && means2 && tables && gate_tables_ok)) {
         const int n_seg = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
         hipError_t e = hipMemsetAsync(gate2, 1, (size_t)n_clips * n_seg * sizeof(int), stream);
         if (e != hipSuccess) return e;
     }
     if (y2 && aligned)       // classify(): recurrence / taps split over four wavefronts (means1 / means2 may be nullptr)
-        hipLaunchKernelGGL(iir2_split_kernel, dim3(blocks), dim3(256), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2, means1, means2, tables, gate2);
+        hipLaunchKernelGGL(iir2_split_kernel, dim3(blocks), dim3(256), 0, stream, x, n_clips, n, stride, ystride, c1, y1, c2, y2, means1, means2, tables, gate2);
     else if (y2 && means1 && means2)
-        hipLaunchKernelGGL((iir_kernel<float, IirCoef, true, float, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2,
+        hipLaunchKernelGGL((iir_kernel<float, IirCoef, true, float, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, ystride, c1, y1, c2, y2,
                            means1, means2);
-    else if (y2) hipLaunchKernelGGL((iir_kernel<float, IirCoef, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, c1, y1, c2, y2, nullptr, nullptr);
-    else hipLaunchKernelGGL((iir_kernel<float, IirCoef, false>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c1, y1, c1, y1, nullptr, nullptr);
+    else if (y2) hipLaunchKernelGGL((iir_kernel<float, IirCoef, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, ystride, c1, y1, c2, y2, nullptr, nullptr);
+    else hipLaunchKernelGGL((iir_kernel<float, IirCoef, false>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, ystride, c1, y1, c1, y1, nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -398,7 +401,7 @@ hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long strid
 {
     if (n_clips <= 0 || n <= 0) return hipSuccess;
     const int blocks = (int)((n_clips + 63) / 64);
-    hipLaunchKernelGGL((iir_kernel<double, IirCoefD, false, float>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c, y, c, y, nullptr, nullptr);
+    hipLaunchKernelGGL((iir_kernel<double, IirCoefD, false, float>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, stride, c, y, c, y, nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -407,7 +410,7 @@ hipError_t launch_iir_f64(const double *x, long n_clips, int n, long stride, con
 {
     if (n_clips <= 0 || n <= 0) return hipSuccess;
     const int blocks = (int)((n_clips + 63) / 64);
-    hipLaunchKernelGGL((iir_kernel<double, IirCoefD, false>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, c, y, c, y, nullptr, nullptr);
+    hipLaunchKernelGGL((iir_kernel<double, IirCoefD, false>), dim3(blocks), dim3(64), 0, stream, x, n_clips, n, stride, stride, c, y, c, y, nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -794,20 +797,22 @@ __device__ float sum_intense_wave(float lower, float upper, float half_range, in
 // flag per time bin -- half of the path's float64 log10 evaluations disappear.
 constexpr int kTailLdsCells = 129 * 72;
 
-__global__ void spec_threshold_kernel(SpecTables *tab)
+__global__ void spec_threshold_kernel(SpecTables *tab, float thr_db)
 {
-    // smallest positive float s with to_db(s) > 70: bisection on the bit pattern (positive floats order like ints)
-    unsigned lo = 0x00800000u, hi = 0x7F7FFFFFu;      // to_db(lo) <= 70 < to_db(hi)
+    // smallest positive float s with to_db(s) > thr_db: bisection on the bit pattern (positive floats order like ints;
+    // to_db is monotone).  Thresholds outside (to_db(FLT_MIN), to_db(FLT_MAX)) = (-259, 505) dB saturate.
+    unsigned lo = 0x00800000u, hi = 0x7F7FFFFFu;      // to_db(lo) <= thr < to_db(hi)
+    if (to_db(__uint_as_float(lo)) > thr_db) hi = lo;
     while (hi - lo > 1) {
         const unsigned mid = lo + (hi - lo) / 2;
-        if (to_db(__uint_as_float(mid)) > 70.0f) hi = mid; else lo = mid;
+        if (to_db(__uint_as_float(mid)) > thr_db) hi = mid; else lo = mid;
     }
-    tab->mp_keep_min = __uint_as_float(hi);
+    tab->mp_keep_min = to_db(__uint_as_float(hi)) > thr_db ? __uint_as_float(hi) : INFINITY;
 }
 
-hipError_t launch_spec_threshold(SpecTables *tables, hipStream_t stream)
+hipError_t launch_spec_threshold(SpecTables *tables, float threshold_db, hipStream_t stream)
 {
-    hipLaunchKernelGGL(spec_threshold_kernel, dim3(1), dim3(1), 0, stream, tables);
+    hipLaunchKernelGGL(spec_threshold_kernel, dim3(1), dim3(1), 0, stream, tables, threshold_db);
     return hipGetLastError();
 }
 
@@ -878,7 +883,7 @@ constexpr int kTailPerThread = (kTailLdsCells + 255) / 256;
 
 template <bool USE_LDS>
 __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, long clip, int T, int fs, int *__restrict__ labels,
-                                                    ClassifyTrace *__restrict__ trace, float *map_lds)
+                                                    ClassifyTrace *__restrict__ trace, float *map_lds, const ClassifyRule &rule)
 {
     __shared__ float red_mn[4], red_mx[4];
     __shared__ float mids[kMaxMidpoints];
@@ -918,10 +923,10 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
     smx = fmaxf(fmaxf(red_mx[0], red_mx[1]), fmaxf(red_mx[2], red_mx[3]));
     // the reference starts its running min / max from +-DBL_MAX stored in floats = +-inf
     const float mn = smn <= smx ? to_db(smn) : INFINITY, mx = smn <= smx ? to_db(smx) : -INFINITY;
-    const float lo_thr = 0.65f, hi_thr = 0.80f;
+    const float lo_thr = rule.keep_lo, hi_thr = rule.keep_hi;
     const double range = (double)mx - (double)mn, slack = 1e-4 * range + 1e-4;       // dB; float rounding of v is ~1e-6 range
-    const float s_lo = (float)(1e-12 * pow(10.0, ((double)mn + 0.65 * range - slack) / 10.0) * (1.0 - 1e-6));
-    const float s_hi = (float)(1e-12 * pow(10.0, ((double)mn + 0.80 * range + slack) / 10.0) * (1.0 + 1e-6));
+    const float s_lo = (float)(1e-12 * pow(10.0, ((double)mn + (double)lo_thr * range - slack) / 10.0) * (1.0 - 1e-6));
+    const float s_hi = (float)(1e-12 * pow(10.0, ((double)mn + (double)hi_thr * range + slack) / 10.0) * (1.0 + 1e-6));
     auto keep = [&](float sv) {
         float v = NAN;
         if (sv >= s_lo && sv <= s_hi) {                 // (false for s <= 0 and NaN)
@@ -982,7 +987,7 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
         __syncthreads();
         const float above = band[0], middle = band[1], below = band[2];
         if (tid == 0) { trace[clip].sums[k][0] = above; trace[clip].sums[k][1] = middle; trace[clip].sums[k][2] = below; }
-        hit = (middle < 100 && above > 200 && below > 80) ? 1 : 0;
+        hit = (middle < rule.middle_max && above > rule.above_min && below > rule.below_min) ? 1 : 0;
         __syncthreads();
         if (hit) break;                                      // uniform: every thread read the same three sums
     }
@@ -995,12 +1000,13 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
 // every fourth clip positive).
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void classify_bands_kernel(float *__restrict__ sxx_bp, int T, int fs, int *__restrict__ labels,
-                                                             ClassifyTrace *__restrict__ trace, const int *__restrict__ hits)
+                                                             ClassifyTrace *__restrict__ trace, const int *__restrict__ hits,
+                                                             const ClassifyRule rule)
 {
     extern __shared__ float map_lds[];
     const int count = hits[0];
     for (int it = blockIdx.x; it < count; it += gridDim.x) {
-        classify_bands_clip<USE_LDS>(sxx_bp, hits[1 + it], T, fs, labels, trace, map_lds);
+        classify_bands_clip<USE_LDS>(sxx_bp, hits[1 + it], T, fs, labels, trace, map_lds, rule);
         __syncthreads();                                     // the block's LDS is reused by the next clip
     }
 }
@@ -1018,7 +1024,7 @@ hipError_t launch_classify_midpoints(const int *loud, long n_clips, int n, int f
 }
 
 hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, const int *hits,
-                                 hipStream_t stream)
+                                 hipStream_t stream, const ClassifyRule &rule)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0) return hipSuccess;
@@ -1026,9 +1032,53 @@ hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int
     const unsigned blocks = (unsigned)(n_clips < 2048 ? n_clips : 2048);      // 256 CUs x 4 resident blocks x 2
     if (kSpecBins * T <= kTailLdsCells)
         hipLaunchKernelGGL(classify_bands_kernel<true>, dim3(blocks), dim3(256), (size_t)kSpecBins * T * sizeof(float), stream, sxx_bp, T, fs,
-                           labels, trace, hits);
+                           labels, trace, hits, rule);
     else
-        hipLaunchKernelGGL(classify_bands_kernel<false>, dim3(blocks), dim3(256), 0, stream, sxx_bp, T, fs, labels, trace, hits);
+        hipLaunchKernelGGL(classify_bands_kernel<false>, dim3(blocks), dim3(256), 0, stream, sxx_bp, T, fs, labels, trace, hits, rule);
+    return hipGetLastError();
+}
+
+// sum_intense as its own entry point (classifier.h:17): arbitrary frequency / time axes and a [bin][time] map, as the
+// reference's row pointers describe it.  One wavefront; cells are fetched 64 at a time in (row, column) order and added one by
+// one in that order.  A NaN cell adds +0.0f instead of being skipped: the running sum starts at +0 and can never become -0, so
+// x + 0.0f == x bit for bit.
+__global__ __launch_bounds__(64) void sum_intense_kernel(float lower, float upper, float half_range, const float *__restrict__ freqs, int nf,
+                                                         const float *__restrict__ times, int nt, const float *__restrict__ db,
+                                                         float midpoint, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const float t_lo = midpoint - half_range, t_hi = midpoint + half_range;
+    int f0 = wave_first_false(nf, [&](int k) { return freqs[k] < lower; });
+    int f1 = wave_last_false(nf, [&](int k) { return freqs[k] > upper; });
+    if (f0 >= nf) f0 = nf - 1;
+    if (f1 < 0) f1 = 0;
+    if (f0 > f1) { const int x = f0; f0 = f1; f1 = x; }
+    int t0 = wave_first_false(nt, [&](int t) { return times[t] < t_lo; });
+    int t1 = wave_last_false(nt, [&](int t) { return times[t] > t_hi; });
+    if (t0 >= nt) t0 = nt - 1;
+    if (t1 < 0) t1 = 0;
+    if (t0 > t1) { const int x = t0; t0 = t1; t1 = x; }
+    const long W = t1 - t0 + 1, N = (long)(f1 - f0 + 1) * W;
+    float total = 0.0f;
+    for (long e0 = 0; e0 < N; e0 += 64) {
+        const long e = e0 + lane;
+        float v = 0.0f;
+        if (e < N) {
+            const long r = e / W, c = e - r * W;
+            v = db[(f0 + r) * (long)nt + t0 + c];
+            if (isnan(v)) v = 0.0f;
+        }
+#pragma unroll
+        for (int l = 0; l < 64; ++l) total = total + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    }
+    if (lane == 0) *out = total;
+}
+
+hipError_t launch_sum_intense(float lower, float upper, float half_range, const float *freqs, int nf, const float *times, int nt,
+                              const float *db, float midpoint, float *out, hipStream_t stream)
+{
+    if (nf <= 0 || nt <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sum_intense_kernel, dim3(1), dim3(64), 0, stream, lower, upper, half_range, freqs, nf, times, nt, db, midpoint, out);
     return hipGetLastError();
 }
 

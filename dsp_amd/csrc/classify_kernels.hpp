@@ -35,9 +35,11 @@ struct IirCoefD { double b[9], a[9]; };
 // With y2 and means1 / means2 != nullptr the lanes also keep the spectrogram's per-segment sequential sums of
 // their own outputs (classifier.cpp:329-333: 256 samples from 224 t, added in order) and store the segment
 // means means[c][t], so the spectrogram kernel need not walk the samples serially again.
+// ystride: row stride of y1 / y2 (0 = the input's); gate_tables_ok: the host's SpecTables::gate_ok (when false, or when the
+// launch falls back to a kernel that does not compute the gate, gate2 is filled with "maybe").
 hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, const IirCoef &c1, float *y1,
                           const IirCoef &c2, float *y2, hipStream_t stream, float *means1 = nullptr, float *means2 = nullptr,
-                          const SpecTables *tables = nullptr, int *gate2 = nullptr);
+                          const SpecTables *tables = nullptr, int *gate2 = nullptr, long ystride = 0, bool gate_tables_ok = true);
 hipError_t launch_iir_f64(const double *x, long n_clips, int n, long stride, const IirCoefD &c, double *y,
                           hipStream_t stream);
 // float rows, recurrence in double, one rounding on store (per-frame prefilter of BASELINE config 3)
@@ -70,10 +72,18 @@ hipError_t launch_spectrogram_flags(const float *y, long n_clips, int n, long st
 // midpoints); `hits` (1 + n_clips ints) is the work list between the two: hits[0] = clips with midpoints, then their numbers.
 hipError_t launch_classify_midpoints(const int *loud, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, int *hits,
                                      hipStream_t stream);
+// the thresholds of classify() the reference's variants differ in (dsp_classify_config): keep band of the normalised dB
+// map (classifier.cpp:67-68) and the rule middle < . && above > . && below > . (classifier.cpp:109)
+struct ClassifyRule { float keep_lo, keep_hi, middle_max, above_min, below_min; };
 hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, const int *hits,
-                                 hipStream_t stream);
-// fills tables->mp_keep_min (once per context)
-hipError_t launch_spec_threshold(SpecTables *tables, hipStream_t stream);
+                                 hipStream_t stream, const ClassifyRule &rule);
+// fills tables->mp_keep_min for find_midpoints' lower_threshold_dB (classifier.cpp:436; once per context and threshold)
+hipError_t launch_spec_threshold(SpecTables *tables, float threshold_db, hipStream_t stream);
+
+// sum_intense (classifier.cpp:370-431) on a flat db[nf][nt] map in HBM: one wavefront, the reference's index searches and
+// its (row, column) order of additions; *out = the sum.
+hipError_t launch_sum_intense(float lower, float upper, float half_range, const float *freqs, int nf, const float *times, int nt,
+                              const float *db, float midpoint, float *out, hipStream_t stream);
 
 void build_spec_tables(int fs, SpecTables &t);
 

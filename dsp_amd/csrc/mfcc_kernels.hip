@@ -291,10 +291,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o);
         if (lane == 0) {
             const float score = term + m.rho;
-            const float fx = score * m.prob_a + m.prob_b;
-            const float p0 = fx >= 0.0f ? expf(-fx) / (1.0f + expf(-fx)) : 1.0f / (1.0f + expf(fx));
-            const float p1 = 1.0f - p0;
-            args.pool.labels[clip] = p1 > p0 ? 1 : 0;
+            int label;
+            float p1;
+            svm_binary_tail(score, m.prob_a, m.prob_b, label, p1);
+            args.pool.labels[clip] = label;
             if (args.pool.decision) args.pool.decision[clip] = score;
             if (args.pool.prob1) args.pool.prob1[clip] = p1;
         }

@@ -58,11 +58,11 @@ __global__ __launch_bounds__(64) void svm_kernel(const SvmModelDev m, const floa
     }
     for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o);
     if (lane == 0) {
-        const float score = term + m.rho;                    // ORT adds rho to the pairwise sum
-        const float f = score * m.prob_a + m.prob_b;         // Platt: P(class 0) = 1 / (1 + exp(f))
-        const float p0 = f >= 0.0f ? expf(-f) / (1.0f + expf(-f)) : 1.0f / (1.0f + expf(f));
-        const float p1 = 1.0f - p0;
-        labels[clip] = p1 > p0 ? 1 : 0;
+        const float score = term + m.rho;                    // ONNX "sum + rho" = libsvm's sum - model.rho (rho = intercept)
+        int label;
+        float p1;
+        svm_binary_tail(score, m.prob_a, m.prob_b, label, p1);
+        labels[clip] = label;
         if (decision) decision[clip] = score;
         if (prob1) prob1[clip] = p1;
     }

@@ -59,6 +59,13 @@ class ClassifyTrace(C.Structure):
     _fields_ = [("n_midpoints", C.c_int), ("midpoints", C.c_float * 64), ("sums", (C.c_float * 3) * 64)]
 
 
+class ClassifyConfig(C.Structure):
+    """dsp_classify_config (include/dsp_amd.h): the thresholds the reference's classify() variants differ in."""
+
+    _fields_ = [("keep_lo", C.c_float), ("keep_hi", C.c_float), ("midpoint_db", C.c_float),
+                ("middle_max", C.c_float), ("above_min", C.c_float), ("below_min", C.c_float)]
+
+
 WINDOW_HANN, WINDOW_HAMMING, WINDOW_RECT = 0, 1, 2
 MELNORM_NONE, MELNORM_SLANEY = 0, 1
 LOG_PER_FRAME_MAX, LOG_GLOBAL_REF1 = 0, 1
@@ -67,6 +74,7 @@ PREFILTER_NONE, PREFILTER_BUTTER_1000_3000, PREFILTER_BUTTER_3000_7500 = 0, 1, 2
 # every symbol include/dsp_amd.h declares (tests check the library exports them all)
 SYMBOLS = [
     "compute_mfcc", "dsp_classify",
+    "dsp_classify_default_config", "dsp_classify_batch_host_cfg", "dsp_classify_batch_device_cfg", "dsp_sum_intense_f32",
     "dsp_butter_bandpass_filter_f32", "dsp_butter_bandpass_filter_f64", "dsp_compute_spectrogram_f32",
     "dsp_classify_batch_host", "dsp_classify_batch_device", "dsp_find_midpoints",
     "dsp_mfcc_stats_device", "dsp_svm_create", "dsp_svm_destroy", "dsp_svm_predict_device",
@@ -79,6 +87,16 @@ SYMBOLS = [
     "dsp_last_error", "dsp_device_count", "dsp_version",
 ]
 
+# the reference's own C++-linkage names (sync/lib/classifier.h:14-19, include/dsp_amd_classifier.h), Itanium-mangled
+CXX_SYMBOLS = {
+    "butter_bandpass": "_Z15butter_bandpassffPfS_",
+    "butter_bandpass_filter": "_Z22butter_bandpass_filterPfiS_S_S_",
+    "compute_spectrogram": "_Z19compute_spectrogramPfiiPS_S0_PS0_PiS2_",
+    "sum_intense": "_Z11sum_intensefffPfiS_iPS_f",
+    "find_midpoints": "_Z14find_midpointsPfiiPi",
+    "classify": "_Z8classifyPfi",
+}
+
 _lib = None
 
 
@@ -88,12 +106,12 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if not os.environ.get("DSP_AMD_LIB") and _build.is_stale():   # an explicit DSP_AMD_LIB is loaded as is
+    explicit = bool(os.environ.get("DSP_AMD_LIB"))               # an explicit DSP_AMD_LIB is loaded as is
+    if not explicit and _build.is_stale():
         try:
             _build.build()
-        except Exception as e:  # noqa: BLE001
-            if not os.path.exists(path):
-                raise DspError(f"libdsp_amd.so is missing and could not be built: {e}") from e
+        except Exception as e:  # noqa: BLE001  (never fall back to an older binary: it would pass for the current source)
+            raise DspError(f"libdsp_amd.so is stale or missing and could not be rebuilt: {e}") from e
     # One HIP runtime per process: PyTorch-ROCm wheels bundle their own
     # libamdhip64.so (SONAME libamdhip64.so.7, the same as /opt/rocm's).  If torch is
     # going to share streams and HBM buffers with this library it must be loaded
@@ -152,6 +170,18 @@ def load() -> C.CDLL:
     L.dsp_last_error.argtypes = []; L.dsp_last_error.restype = C.c_char_p
     L.dsp_device_count.argtypes = []; L.dsp_device_count.restype = ip
     L.dsp_version.argtypes = []; L.dsp_version.restype = C.c_char_p
+    L.dsp_classify_default_config.argtypes = [C.POINTER(ClassifyConfig)]; L.dsp_classify_default_config.restype = None
+    L.dsp_classify_batch_host_cfg.argtypes = [C.POINTER(ClassifyConfig), vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_batch_host_cfg.restype = ip
+    L.dsp_classify_batch_device_cfg.argtypes = [C.POINTER(ClassifyConfig), vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_batch_device_cfg.restype = ip
+    L.dsp_sum_intense_f32.argtypes = [C.c_float, C.c_float, C.c_float, vp, ip, vp, ip, vp, C.c_float, C.POINTER(C.c_float)]
+    L.dsp_sum_intense_f32.restype = ip
+    if not explicit:
+        # the binary says which sources it was built from: a mismatch means the mtime check was fooled (copied tree,
+        # clock skew) and the library on disk is not the code in dsp_amd/csrc
+        built = L.dsp_version().decode().rsplit("src:", 1)[-1]
+        if built != _build.source_hash():
+            raise DspError(f"{path} was built from other sources (library {built}, tree {_build.source_hash()}): "
+                           "rebuild with `python -m dsp_amd.build`")
     _lib = L
     return L
 

@@ -25,6 +25,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: exactly the functions declared between this push and
+ * the matching pop (plus the C++-linkage reference names of dsp_amd_classifier.h) are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 /* ===================================================================== */
 /* 1. Reference entry points (drop-in)                                    */
 /* ===================================================================== */
@@ -39,9 +45,11 @@ int compute_mfcc(const float *signal, int num_samples, float *out_mfcc, int max_
 /* Replaces sync/lib/classifier.h:19 (definition classifier.cpp:9-136; fp32 firmware
  * twin of donut-classifier/classifier.c:30-212).  16 kHz mono clip -> 1 if the scrub-jay
  * rule fires, else 0 (also 0 on internal failure, classifier.cpp:87-91).  The reference
- * header is C++ without extern "C": this C symbol is `dsp_classify`; INTEGRATION.md
- * shows the one-line C++ shim that gives sync.cpp its `classify`.  Caller owns `data`
- * (host memory); unlike the reference nothing is printed.                          */
+ * header is C++ without extern "C": this is the C symbol; the C++-linkage `int classify(float*, int)`
+ * that sync.cpp links against is exported too and declared in dsp_amd_classifier.h, next to
+ * butter_bandpass, butter_bandpass_filter, compute_spectrogram, sum_intense and find_midpoints
+ * (classifier.h:14-18).  Caller owns `data` (host memory); nothing is printed unless the
+ * environment variable DSP_AMD_VERBOSE is set.                                      */
 int dsp_classify(float *data, int data_size);
 
 /* ===================================================================== */
@@ -65,7 +73,7 @@ enum { DSP_PREFILTER_NONE = 0, DSP_PREFILTER_BUTTER_1000_3000 = 1, DSP_PREFILTER
  * turned into a POD; dsp_mfcc_default_config() fills in the reference values. */
 typedef struct dsp_mfcc_config {
     int sample_rate;  /* 16000 */
-    int n_fft;        /* 512   (supported: 512, and 1024 through the general kernel) */
+    int n_fft;        /* 512   (supported: 512 and 1024, one wavefront per frame) */
     int frame_length; /* 400   (<= n_fft) */
     int hop_length;   /* 160 */
     int n_mels;       /* 40 */
@@ -173,12 +181,35 @@ int dsp_classify_batch_host(const float *signal, long n_clips, int n, long strid
 int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long stride, int *d_labels,
                               void *stream);
 
+/* The thresholds the reference's variants of classify() hard-code, as a POD (everything else in
+ * those files is identical, `diff sync/lib/classifier.cpp microphone/src/classifier.cpp`):
+ *                                   keep band      midpoint dB   rule  middle <  above >  below >
+ *   sync/lib/classifier.cpp         0.65 / 0.80    70            100 / 200 / 80    (:67-68, :436, :109)  default
+ *   microphone/src/classifier.cpp   0.70 / 0.85    45            100 / 200 / 150   (:79-80, :448, :123)
+ *   microphone/src/classifier.c     0.70 / -       45            50 / 200 / 200    (:120, :608, :164)
+ * The _cfg entry points take a NULL cfg for the default set.                          */
+typedef struct dsp_classify_config {
+    float keep_lo, keep_hi;        /* normalised-dB band kept in the 3000-7500 Hz map            */
+    float midpoint_db;             /* lower_threshold_dB of find_midpoints                        */
+    float middle_max, above_min, below_min;   /* sum_middle < . && sum_above > . && sum_below > . */
+} dsp_classify_config;
+void dsp_classify_default_config(dsp_classify_config *cfg);
+int dsp_classify_batch_host_cfg(const dsp_classify_config *cfg, const float *signal, long n_clips, int n, long stride,
+                                int *labels, dsp_classify_trace *trace);
+int dsp_classify_batch_device_cfg(const dsp_classify_config *cfg, const float *d_signal, long n_clips, int n, long stride,
+                                  int *d_labels, void *stream);
+
+/* sum_intense (sync/lib/classifier.h:17, classifier.cpp:370-431) on a flat matrix: db[freq_bins][time_bins] (NaN = dropped
+ * cell), the reference's index searches and its (row, column) summation order.  Host pointers; *out receives the sum.   */
+int dsp_sum_intense_f32(float lower, float upper, float half_range, const float *frequencies, int freq_bins,
+                        const float *times, int time_bins, const float *db, float midpoint, float *out);
+
 /* find_midpoints (sync/lib/classifier.h:18, classifier.cpp:433-598): the 1000-3000 Hz filter, its spectrogram,
  * time bins above 70 dB, greedy clusters of at least 0.15 s -> their mean times, in seconds.  Host pointers.
- * Returns the number of midpoints (at most 64 are found; the first max_midpoints are written) or a negative
- * error; fs must be 16000 (the only rate butter_bandpass has coefficients for).  The reference's sum_intense
- * (classifier.h:17) has no entry point of its own: it runs inside classify, its values are the `sums` of
- * dsp_classify_trace.                                                              */
+ * Returns the number of midpoints (the first max_midpoints are written) or a negative error; fs must be 16000
+ * (the only rate butter_bandpass has coefficients for).  Clips are limited to 957 spectrogram columns (13.4 s):
+ * a cluster needs 12 columns and a 4-column gap, so no such clip has more than the 64 midpoints a trace record
+ * holds; longer clips are rejected (DSP_EINVAL) rather than truncated.                 */
 int dsp_find_midpoints(const float *data, int num_frames, int fs, float *midpoints, int max_midpoints);
 
 /* --- pooling + SVM (cepstrum/scrubjay_infer.c:36-66, 105-141; scrubjay_svm.onnx) ------ */
@@ -277,6 +308,10 @@ int dsp_mfcc_lane_tables(const dsp_mfcc_config *cfg, void *out, int size);
 const char *dsp_last_error(void);   /* thread-local, "" when none */
 int dsp_device_count(void);
 const char *dsp_version(void);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

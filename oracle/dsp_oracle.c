@@ -732,7 +732,12 @@ float orc_sum_intense(float lower, float upper, float half_range,
 
 int orc_find_midpoints(const float *data, int n, int fs, float *midpoints, int cap)
 {
-    const float threshold_db = 70.0f;                /* classifier.cpp:436 */
+    return orc_find_midpoints_thr(data, n, fs, 70.0f, midpoints, cap);   /* classifier.cpp:436 */
+}
+
+/* lower_threshold_dB as a parameter: 70 in sync/lib/classifier.cpp:436, 45 in microphone/src/classifier.cpp:448 */
+int orc_find_midpoints_thr(const float *data, int n, int fs, float threshold_db, float *midpoints, int cap)
+{
     double bd[9], ad[9];
     float b[9], a[9];
     orc_butter_bandpass(1000, 3000, bd, ad);         /* classifier.cpp:438-442 */
@@ -784,6 +789,15 @@ int orc_find_midpoints(const float *data, int n, int fs, float *midpoints, int c
 
 int orc_classify(const float *data, int n, orc_classify_trace *trace)
 {
+    /* sync/lib/classifier.cpp:67-68, :436, :109 */
+    const orc_classify_cfg cfg = {0.65f, 0.80f, 70.0f, 100.0f, 200.0f, 80.0f};
+    return orc_classify_with(data, n, &cfg, trace);
+}
+
+/* The variants of classify() differ in these thresholds only (diff sync/lib/classifier.cpp
+ * microphone/src/classifier.cpp): keep band, midpoint dB threshold, rule.          */
+int orc_classify_with(const float *data, int n, const orc_classify_cfg *cfg, orc_classify_trace *trace)
+{
     const int fs = 16000;                            /* classifier.cpp:12 */
     double bd[9], ad[9];
     float b[9], a[9];
@@ -801,7 +815,7 @@ int orc_classify(const float *data, int n, orc_classify_trace *trace)
     orc_spectrogram_f32(filt, n, fs, freqs, times, sxx);
     float lo, hi;
     to_db_inplace(sxx, SPEC_BINS * T, &lo, &hi);     /* classifier.cpp:35-54 */
-    const float lo_thr = 0.65f, hi_thr = 0.80f;      /* classifier.cpp:67-68 */
+    const float lo_thr = cfg->keep_lo, hi_thr = cfg->keep_hi;      /* classifier.cpp:67-68 */
     for (int i = 0; i < SPEC_BINS * T; ++i) {
         if (!isnan(sxx[i])) {
             float v = (sxx[i] - lo) / (hi - lo);     /* classifier.cpp:57-65 */
@@ -810,7 +824,7 @@ int orc_classify(const float *data, int n, orc_classify_trace *trace)
     }
 
     float mids[64];
-    int n_mid = orc_find_midpoints(data, n, fs, mids, 64); /* classifier.cpp:84 */
+    int n_mid = orc_find_midpoints_thr(data, n, fs, cfg->midpoint_db, mids, 64); /* classifier.cpp:84 */
     int hit = 0;
     if (trace) trace->n_midpoints = n_mid;
     for (int k = 0; k < n_mid; ++k) {                /* classifier.cpp:93-114 */
@@ -821,7 +835,7 @@ int orc_classify(const float *data, int n, orc_classify_trace *trace)
             trace->midpoints[k] = mids[k];
             trace->sums[k][0] = above; trace->sums[k][1] = middle; trace->sums[k][2] = below;
         }
-        if (middle < 100 && above > 200 && below > 80) { hit = 1; break; }
+        if (middle < cfg->middle_max && above > cfg->above_min && below > cfg->below_min) { hit = 1; break; }
     }
     free(times); free(sxx); free(filt);
     return hit;
@@ -852,10 +866,15 @@ int orc_svm_predict(const orc_svm_model *m, const float *x, float *decision,
                     float *prob1)
 {
     /* ONNX Scaler: (x - offset) * scale; SVMClassifier RBF, two classes:
-     * score = sum_i coef_i * exp(-gamma * |z - sv_i|^2) + rho  (ONNX adds rho,
-     * skl2onnx stores rho = +intercept);  score > 0 votes for class 0.
-     * Platt: P(class0) = 1 / (1 + exp(prob_a * score + prob_b)); the label is
-     * the arg-max probability when calibration is present.                     */
+     * score = sum_i coef_i * exp(-gamma * |z - sv_i|^2) + rho.  This is libsvm's
+     * decision value sum - model.rho with model.rho = -intercept (sklearn
+     * libsvm_helper.c set_model), intercept = the ONNX rho; pinned against libsvm
+     * by tools/pin_svm_libsvm.py -> tests/golden/svm_libsvm_ref.npz.
+     * Label (svm.cpp svm_predict, sklearn .predict in cepstrum/run.py; ONNX
+     * Runtime's SVC mode counts the same votes): score > 0 votes class 0, else 1.
+     * Probability (svm.cpp svm_predict_probability): r01 = Platt sigmoid clamped to
+     * [1e-7, 1-1e-7], then multiclass_probability -- an iteration from (1/2, 1/2)
+     * with tolerance 0.005 / k, NOT the sigmoid itself.                          */
     float z[256];
     for (int j = 0; j < m->n_features; ++j)
         z[j] = (x[j] - m->offset[j]) * m->scale[j];
@@ -871,11 +890,41 @@ int orc_svm_predict(const orc_svm_model *m, const float *x, float *decision,
     }
     score += m->rho;
     float fApB = score * m->prob_a + m->prob_b;
-    float p0 = (fApB >= 0.0f) ? expf(-fApB) / (1.0f + expf(-fApB))
-                              : 1.0f / (1.0f + expf(fApB));
+    float r01f = (fApB >= 0.0f) ? expf(-fApB) / (1.0f + expf(-fApB))
+                                : 1.0f / (1.0f + expf(fApB));
+    if (r01f < 1e-7f) r01f = 1e-7f;
+    if (r01f > 1.0f - 1e-7f) r01f = 1.0f - 1e-7f;
+    /* multiclass_probability(k = 2), svm.cpp */
+    double r[2][2] = {{0.0, (double)r01f}, {1.0 - (double)r01f, 0.0}};
+    double Q[2][2], Qp[2], p[2] = {0.5, 0.5}, pQp;
+    const double eps = 0.005 / 2;
+    Q[0][0] = r[1][0] * r[1][0]; Q[0][1] = -r[1][0] * r[0][1];
+    Q[1][1] = r[0][1] * r[0][1]; Q[1][0] = Q[0][1];
+    for (int iter = 0; iter < 100; ++iter) {
+        pQp = 0;
+        for (int t = 0; t < 2; ++t) {
+            Qp[t] = Q[t][0] * p[0] + Q[t][1] * p[1];
+            pQp += p[t] * Qp[t];
+        }
+        double max_error = 0;
+        for (int t = 0; t < 2; ++t) {
+            double error = fabs(Qp[t] - pQp);
+            if (error > max_error) max_error = error;
+        }
+        if (max_error < eps) break;
+        for (int t = 0; t < 2; ++t) {
+            double diff = (-Qp[t] + pQp) / Q[t][t];
+            p[t] += diff;
+            pQp = (pQp + diff * (diff * Q[t][t] + 2 * Qp[t])) / (1 + diff) / (1 + diff);
+            for (int j = 0; j < 2; ++j) {
+                Qp[j] = (Qp[j] + diff * Q[t][j]) / (1 + diff);
+                p[j] /= (1 + diff);
+            }
+        }
+    }
     if (decision) *decision = score;
-    if (prob1) *prob1 = 1.0f - p0;
-    return (1.0f - p0) > p0 ? 1 : 0;
+    if (prob1) *prob1 = (float)p[1];
+    return score > 0.0f ? 0 : 1;
 }
 
 /* ---- classify_signal tail (stop_detector.c, audio_classifier_inference.c) ---------- */

@@ -150,6 +150,11 @@ typedef struct orc_classify_trace {
 
 /* classifier.cpp:9-136  returns 0/1; `trace` may be NULL.                     */
 int orc_classify(const float *data, int n, orc_classify_trace *trace);
+typedef struct orc_classify_cfg {
+    float keep_lo, keep_hi, midpoint_db, middle_max, above_min, below_min;
+} orc_classify_cfg;
+int orc_classify_with(const float *data, int n, const orc_classify_cfg *cfg, orc_classify_trace *trace);
+int orc_find_midpoints_thr(const float *data, int n, int fs, float threshold_db, float *midpoints, int cap);
 
 /* ---- pooling + SVM (cepstrum/scrubjay_infer.c, scrubjay_svm.onnx) ------- */
 

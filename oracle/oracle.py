@@ -244,10 +244,26 @@ def find_midpoints(data, fs=16000) -> np.ndarray:
     return out[:n]
 
 
-def classify(data):
+class ClassifyCfg(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("keep_lo", "keep_hi", "midpoint_db", "middle_max", "above_min", "below_min")]
+
+
+# thresholds of the reference's variants (keep band, midpoint dB, rule middle < / above > / below >)
+CLASSIFY_SYNC_LIB = (0.65, 0.80, 70.0, 100.0, 200.0, 80.0)        # sync/lib/classifier.cpp:67-68, :436, :109
+CLASSIFY_MICROPHONE = (0.70, 0.85, 45.0, 100.0, 200.0, 150.0)     # microphone/src/classifier.cpp:79-80, :448, :123
+
+
+def classify(data, cfg=None):
     data = np.ascontiguousarray(data, np.float32)
     tr = ClassifyTrace()
-    label = lib().orc_classify(data, data.size, C.byref(tr))
+    if cfg is None:
+        label = lib().orc_classify(data, data.size, C.byref(tr))
+    else:
+        L = lib()
+        L.orc_classify_with.argtypes = [_F, C.c_int, C.POINTER(ClassifyCfg), C.POINTER(ClassifyTrace)]
+        L.orc_classify_with.restype = C.c_int
+        c = ClassifyCfg(*[float(v) for v in cfg])
+        label = L.orc_classify_with(data, data.size, C.byref(c), C.byref(tr))
     mids = np.array(tr.midpoints[: tr.n_midpoints], np.float32)
     sums = np.array([[tr.sums[i][j] for j in range(3)] for i in range(tr.n_midpoints)], np.float32).reshape(-1, 3)
     return int(label), mids, sums

@@ -1,13 +1,21 @@
-"""GPU: pooling (scrubjay_infer.c:36-66) and the decoded ONNX SVM through the C ABI against
-the CPU oracle; floating point -> tolerance 2e-5 on decision / probability, labels equal
-away from p = 0.5.  The aubio front end is unpinned: the features here come
-from this library's own MFCC chain with n_mfcc = 20."""
+"""GPU: pooling (scrubjay_infer.c:36-66) and the decoded ONNX SVM through the C ABI against libsvm's own answers
+(tests/golden/svm_libsvm_ref.npz, tools/pin_svm_libsvm.py) and the CPU oracle; floating point -> tolerance 2e-5 on
+decision / probability, labels (the pairwise vote, decision > 0 -> class 0) equal away from decision = 0.  The
+probability is libsvm's multiclass_probability ITERATION, whose stopping test makes it jump by up to 0.005 / 2 when an
+input moves by an ulp across a stopping boundary: a comparison is "close" within 2e-5, or within that jump.
+The aubio front end is unpinned: the features here come from this library's own MFCC chain with n_mfcc = 20."""
 import numpy as np
 import pytest
 
 from tests import signals as S
 
 pytestmark = pytest.mark.gpu
+
+
+def _prob_close(p, q):
+    """-> (ok, on_a_boundary): 2e-5, or the iteration's own tolerance when the stopping test fell the other way."""
+    d = abs(float(p) - float(q))
+    return d <= 2.6e-3, d > 2e-5
 
 
 def _model(m):
@@ -37,15 +45,40 @@ def test_svm_vs_oracle(golden):
     svm = scrubjay.SvmModel({k: m[k] for k in m.files})
     x = np.stack([(m["offset"] + S.uniform_pm1(40, 900 + i) * (2.5 / m["scale"])).astype(np.float32) for i in range(300)])
     labels, dec, p1 = (a.cpu().numpy() for a in svm.predict(torch.from_numpy(x).cuda()))
-    seen = set()
+    seen, loose = set(), 0
     for i in range(x.shape[0]):
         lab, odec, op1 = O.svm_predict(_model(m), x[i])
         assert abs(dec[i] - odec) <= 2e-5 * max(1.0, abs(odec))
-        assert abs(p1[i] - op1) <= 2e-5
-        if abs(op1 - 0.5) > 1e-4:
+        ok, edge = _prob_close(p1[i], op1)
+        assert ok
+        loose += edge
+        if abs(odec) > 1e-5:
             assert labels[i] == lab
         seen.add(int(labels[i]))
-    assert seen == {0, 1}
+    assert seen == {0, 1} and loose <= 3
+
+
+def test_svm_vs_libsvm(golden):
+    """The HIP SVM against libsvm itself (sklearn.svm._libsvm fed the decoded ONNX attributes): decision values,
+    predict_proba and svm_predict's vote label on 320 vectors, 64 of them inside the zone where a sigmoid + arg-max reading
+    of the attributes would give the other label / another probability; plus the reference's 13 labelled WAVs (features
+    from a numpy restatement of train.py's librosa call), which libsvm -- and therefore this kernel -- labels 13 / 13."""
+    import torch
+    from dsp_amd import scrubjay
+    m = golden("scrubjay_svm.npz")
+    r = golden("svm_libsvm_ref.npz")
+    svm = scrubjay.SvmModel({k: m[k] for k in m.files})
+    labels, dec, p1 = (a.cpu().numpy() for a in svm.predict(torch.from_numpy(r["feat"]).cuda()))
+    assert np.abs(dec - r["decision"]).max() <= 2e-5
+    firm = np.abs(r["decision"]) > 1e-5
+    assert np.array_equal(labels[firm], r["label_vote"][firm]) and firm.sum() >= 300
+    sliver = (r["decision"] > 1e-5) & (r["decision"] < 0.0079)
+    assert sliver.sum() >= 16 and np.all(labels[sliver] == 0)            # sigmoid arg max says 1 here; libsvm (and ORT's votes) 0
+    d = np.abs(p1 - r["proba"][:, 1])
+    assert d.max() <= 2.6e-3 and (d > 2e-5).sum() <= 3
+    labels, dec, p1 = (a.cpu().numpy() for a in svm.predict(torch.from_numpy(r["labelled_feat"]).cuda()))
+    assert np.array_equal(labels, r["labelled_y"]) and np.array_equal(labels, r["labelled_vote"])      # polarity: 1 = scrub jay
+    assert np.abs(dec - r["labelled_decision"]).max() <= 2e-5 and np.abs(p1 - r["labelled_proba"][:, 1]).max() <= 2e-5
 
 
 def test_clip_to_label_pipeline(golden):
@@ -67,8 +100,8 @@ def test_clip_to_label_pipeline(golden):
         # pooled features inherit the MFCC gate (mean / std of values that each meet it)
         assert np.all(np.abs(feat[i] - ofeat) <= RTOL * np.abs(omfcc).max() + ATOL_DB)
         lab, odec, op1 = O.svm_predict(_model(m), feat[i])          # SVM checked on the SAME features
-        assert abs(dec[i].item() - odec) <= 2e-5 * max(1.0, abs(odec)) and abs(p1[i].item() - op1) <= 2e-5
-        if abs(op1 - 0.5) > 1e-4:
+        assert abs(dec[i].item() - odec) <= 2e-5 * max(1.0, abs(odec)) and _prob_close(p1[i].item(), op1)[0]
+        if abs(odec) > 1e-5:
             assert labels[i].item() == lab
 
 
@@ -101,8 +134,8 @@ def test_config5_at_scale(golden):
         of = O.mfcc_stats(O.compute_mfcc(clips[i].cpu().numpy(), 1 << 20, ocfg))
         lab, odec, op1 = O.svm_predict(_model(m), feat[i].cpu().numpy())                      # SVM on the GPU's own features
         assert np.abs(feat[i].cpu().numpy() - of).max() <= 1e-4 * np.abs(of).max() + 3e-4
-        assert abs(float(dec[i]) - odec) <= 2e-5 * max(1.0, abs(odec)) and abs(float(p1[i]) - op1) <= 2e-5
-        if abs(op1 - 0.5) > 1e-4:
+        assert abs(float(dec[i]) - odec) <= 2e-5 * max(1.0, abs(odec)) and _prob_close(float(p1[i]), op1)[0]
+        if abs(odec) > 1e-5:
             assert int(labels[i]) == lab
 
 

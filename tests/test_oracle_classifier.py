@@ -93,3 +93,13 @@ def test_mfcc_stats_population_std():
     out = O.mfcc_stats(m)
     assert np.allclose(out[:20], m.mean(0), rtol=1e-6, atol=1e-6)
     assert np.allclose(out[20:], m.std(0), rtol=1e-5, atol=1e-5)
+
+
+def test_sum_intense_vs_the_compiled_reference(golden):
+    """sum_intense of the reference's compiled classifier.cpp (tests/golden/make_golden_round2.py): real band-kept maps,
+    a random map, and the clamp / swap branches of the index searches (classifier.cpp:383-412)."""
+    s = golden("sum_intense_ref.npz")
+    for c in range(int(s["n_cases"])):
+        lo, hi, half, mid = (float(v) for v in s[f"c{c}_params"])
+        got = O.sum_intense(lo, hi, half, s[f"c{c}_freqs"], s[f"c{c}_times"], s[f"c{c}_db"], mid)
+        assert np.float32(got).tobytes() == s[f"c{c}_sum"].tobytes(), c
