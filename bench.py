@@ -2,14 +2,19 @@
 """bench.py -- MFCC frames/s on MI355X (BASELINE.json metric), one process per GPU.
 
     python bench.py                                   # 1 GPU, defaults finish in ~1-2 min
+    python bench.py --gpus N                          # starts N fresh rank processes itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path (window -> 512-pt FFT -> power -> 40 mel ->
 log -> 13-coef DCT-II) over one batch of synthetic frames already resident in HBM:
 BASELINE config 2, 1 M x 512 fp32 frames per GPU.  Frames shard embarrassingly
-over ranks (weak scaling, no data-path collective; --gather adds the RCCL
-all-gather of the per-rank feature blocks, BASELINE config 4's exchange step).
+over ranks (weak scaling, no data-path collective) -- that is `value`.  The path's one
+real exchange step, BASELINE config 4's gather of the per-clip MFCC matrices, is
+measured beside it in the same line (`config4`: 12 500 x 1 s clips per rank per step,
+[98][13] per clip, ONE RCCL all-gather per batch, double-buffered so that the gather of
+batch k overlaps the kernels of batch k + 1; dsp_amd/dist.py GatherPipeline).  --gather
+adds the same pipelined gather to the frames workload.
 
 Rank 0 prints ONE JSON line.  `value` = frames all ranks processed / max-over-
 ranks wall time of the K timed steps.  `roofline.achieved` = algorithmic bytes
@@ -48,18 +53,19 @@ def host_cpu_share() -> int:
     return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
 
 
-def pmc_traffic(frames_per_launch: int):
-    """HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in
-    separate runs, gfx950 x2 read correction), as condensed by tools/summarize_profile.py into profiles/."""
+def pmc_traffic(workload: str, units_per_launch: int):
+    """HBM bytes per step from the rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE in separate runs,
+    gfx950 x2 read correction), as condensed by tools/traffic.py into profiles/*_traffic*.json.  The newest file for the
+    workload and batch size wins (r02 after r01, v12 after v9)."""
     import glob
     import re
     best = None
-    natural = lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(p))]   # noqa: E731  r01_v12 after r01_v9
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=natural):
+    natural = lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(p))]   # noqa: E731
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic*.json")), key=natural):
         try:
             d = json.load(open(f))
-            if d.get("frames_per_launch") == frames_per_launch:
-                best = d
+            if d.get("workload", "frames") == workload and d.get("units_per_launch", d.get("frames_per_launch")) == units_per_launch:
+                best = dict(d, file=os.path.basename(f))
         except Exception:  # noqa: BLE001
             pass
     return best
@@ -139,8 +145,8 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         step = lambda: plan.frames(frames, out)               # noqa: E731
         units, unit, bytes_per = n, "frames/s", 4096 + 52      # 4 148 B per frame
         what = (f"BASELINE configs[2] at {n} frames: float64 Butterworth 3000-7500 Hz per 1024-sample frame from zero state "
-                "-> Hann(1024) -> 1024-pt FFT -> 128 HTK mel -> dB -> 13 coeffs (two passes: IIR kernel, then the general 1024 kernel)")
-        kernel = "iir_kernel<double,float> + mfcc1024_kernel"
+                "-> Hann(1024) -> 1024-pt FFT -> 128 HTK mel -> dB -> 13 coeffs")
+        kernel = "iir_kernel<double,float> + mfcc1024_wave_kernel"
     elif args.workload == "clips":
         n = args.clips or 12_500
         clips = torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1
@@ -185,15 +191,63 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         elapsed = float(t.item())
     if rank == 0:
         achieved = bytes_per * n / (ms * 1e-3) / 1e9
+        tr = pmc_traffic(args.workload, n)
         print(json.dumps({
             "metric": f"{args.workload}: {unit}", "value": world * units * steps / elapsed, "unit": unit, "n_gpus": world,
             "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "clock_settle_s": args.settle},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes_per_launch": bytes_per * n}}), flush=True)
+                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                         "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/" + tr["file"]) if tr else None,
+                         "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes_per_launch": bytes_per * n},
+            "step_calls": (max(1, args.warmup // 4) + steps) if args.settle <= 0 else None}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def config4(args, torch, dist, dsp_amd, dev, local, rank, world, sync):
+    """BASELINE configs[3] beside the headline number: every rank computes its 12 500-clip share ([98][13] per clip) and the
+    per-rank feature blocks (63.7 MB each) are all-gathered -- ONE RCCL collective per batch, issued asynchronously so that it
+    runs over xGMI while the next batch's MFCC kernel runs (GatherPipeline, depth 2).  Same timing protocol as the headline:
+    W warmup steps, K timed steps between barrier + synchronize, max over ranks.  At N = 1 there is nothing to gather and the
+    number is the compute-only baseline of the same workload."""
+    from dsp_amd.dist import GatherPipeline
+    n, T = args.clips or 12_500, 98
+    gen = torch.Generator(device=dev).manual_seed(3000 + rank)
+    clips = torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1
+    plan = dsp_amd.MfccPlan(dsp_amd.default_config(), local)
+    pipe = GatherPipeline(n, (T, N_MFCC), torch.float32, dev)
+
+    def step():
+        pipe.submit(lambda block: plan.clips(clips, 500, block))
+
+    for _ in range(args.warmup):
+        step()
+    pipe.drain()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    pipe.drain()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    full = pipe.result((pipe.k - 1) % pipe.depth)
+    assert tuple(full.shape) == (world * n, T, N_MFCC)
+    del clips
+    if rank != 0:
+        return None
+    return {"workload": f"BASELINE configs[3]: {world} x {n} x 1 s 16 kHz fp32 clips per step, frame 400 / hop 160 -> [98][13] per clip, "
+                        "per-clip MFCC matrices gathered on every rank",
+            "value": world * n * args.steps / elapsed, "unit": "clips/s", "frames_per_s": world * n * T * args.steps / elapsed,
+            "ms_per_step": elapsed / args.steps * 1e3, "gather": world > 1,
+            "collective": "one all_gather_into_tensor (RCCL over xGMI) per batch, async on the backend's stream, double-buffered: "
+                          "the gather of batch k overlaps the MFCC kernel of batch k + 1" if world > 1 else None,
+            "gathered_bytes_per_rank_per_step": n * T * N_MFCC * 4, "clips_per_gpu": n, "algorithmic_bytes_per_clip": 64_000 + T * 52}
 
 
 def settle(step, torch, seconds):
@@ -222,7 +276,22 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-config4", action="store_true", help="skip the config-4 (clips + all-gather) measurement of the frames workload's line")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Bare `python bench.py --gpus N`: this process has not touched the GPU (torch is not even imported yet), so it can
+        # start N fresh rank processes -- one per GPU, RCCL over xGMI -- as children, relay their output and exit code.
+        import socket
+        import subprocess
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -230,10 +299,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -256,12 +322,14 @@ def main():
     frames = torch.rand((n, FRAME), device=dev, generator=gen) * 2 - 1    # synthetic PCM in [-1, 1)
     out = torch.empty((n, N_MFCC), device=dev)
     do_gather = bool(args.gather and world > 1)
-    from dsp_amd.dist import gather_features
+    from dsp_amd.dist import GatherPipeline
+    pipe = GatherPipeline(n, (N_MFCC,), torch.float32, dev) if do_gather else None
 
     def step():
-        plan.frames(frames, out)
-        if do_gather:
-            gather_features(out, world * n)      # one RCCL all-gather of the per-rank feature blocks
+        if pipe is not None:     # the all-gather of this batch's features overlaps the next step's kernel (double-buffered)
+            pipe.submit(lambda block: plan.frames(frames, block))
+        else:
+            plan.frames(frames, out)
 
     def sync():
         if world > 1:
@@ -279,6 +347,8 @@ def main():
     for _ in range(args.steps):
         step()
     ev1.record()
+    if pipe is not None:
+        pipe.drain()                   # the last gathers are part of the timed work
     sync()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps    # back-to-back launches: avg launch duration
@@ -286,6 +356,8 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    c4 = None if args.no_config4 else config4(args, torch, dist, dsp_amd, dev, local, rank, world, sync)
 
     if rank == 0:
         total_frames = world * n * args.steps
@@ -306,7 +378,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 1 M synthetic 512-sample fp32 frames per GPU, "
                                    "Hann(512) -> 512-pt FFT -> 40 HTK mel -> per-frame dB -> 13 DCT-II coeffs, "
-                                   "inputs resident in HBM",
+                                   "inputs resident in HBM; frames sharded over the ranks with no data-path collective "
+                                   "(the exchange step of the path, config 4's gather, is the `config4` object of this line)",
                        "frames_per_gpu": n, "frame_length": FRAME, "n_fft": 512, "n_mels": 40, "n_mfcc": N_MFCC,
                        "gather": do_gather, "parallelism": f"frames sharded over {world} rank(s)",
                        "clock_settle_s": args.settle},
@@ -315,10 +388,13 @@ def main():
                          "kernel": "mfcc512_wave_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_FRAME * n},
         }
-        tr = pmc_traffic(n)
+        tr = pmc_traffic("frames", n)
         if tr:
             line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/" + tr["source"]
+            line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/" + tr["file"]
+        line["step_calls"] = args.warmup + args.steps if args.settle <= 0 else None      # tools/traffic.py divides by this
+        if c4:
+            line["config4"] = c4
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(600_000)
         print(json.dumps(line), flush=True)

@@ -826,13 +826,15 @@ int orc_classify_with(const float *data, int n, const orc_classify_cfg *cfg, orc
     float mids[64];
     int n_mid = orc_find_midpoints_thr(data, n, fs, cfg->midpoint_db, mids, 64); /* classifier.cpp:84 */
     int hit = 0;
-    if (trace) trace->n_midpoints = n_mid;
+    if (trace) {
+        trace->n_midpoints = n_mid;
+        for (int k = 0; k < n_mid; ++k) trace->midpoints[k] = mids[k];   /* all of find_midpoints' results */
+    }
     for (int k = 0; k < n_mid; ++k) {                /* classifier.cpp:93-114 */
         float above = orc_sum_intense(5000, 7000, 0.18f, freqs, SPEC_BINS, times, T, sxx, mids[k]);
         float middle = orc_sum_intense(2500, 5000, 0.05f, freqs, SPEC_BINS, times, T, sxx, mids[k]);
         float below = orc_sum_intense(500, 2500, 0.18f, freqs, SPEC_BINS, times, T, sxx, mids[k]);
         if (trace) {
-            trace->midpoints[k] = mids[k];
             trace->sums[k][0] = above; trace->sums[k][1] = middle; trace->sums[k][2] = below;
         }
         if (middle < cfg->middle_max && above > cfg->above_min && below > cfg->below_min) { hit = 1; break; }

@@ -74,3 +74,70 @@ def test_two_rank_gather_matches_single_process(n_clips):
         assert np.array_equal(got, want)
     spans = sorted((lo, hi) for _, lo, hi, _ in res)
     assert spans[0][0] == 0 and spans[-1][1] == n_clips
+
+
+def _pipe_worker(rank, world, port, n_batches, rows, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from tests import signals as S
+
+        def batch(k, r):                                     # rank r's clips of batch k
+            return [S.uniform_pm1(1200, 1000 * k + 10 * r + i) for i in range(rows)]
+
+        def compute_into(k):
+            def f(out):
+                out.copy_(torch.from_numpy(np.stack([O.compute_mfcc(c, 500) for c in batch(k, rank)])))
+            return f
+
+        # serial path: compute, gather, next batch
+        serial = []
+        for k in range(n_batches):
+            local = torch.empty((rows, 6, 13))
+            compute_into(k)(local)
+            serial.append(D.gather_features(local, world * rows).clone())
+        # pipelined path: the gather of batch k is in flight while batch k + 1 is computed; results are read one batch late
+        pipe = D.GatherPipeline(rows, (6, 13), torch.float32, "cpu")
+        piped, pending = [], None
+        for k in range(n_batches):
+            slot = pipe.submit(compute_into(k))
+            if pending is not None:
+                piped.append(pipe.result(pending).clone())
+            pending = slot
+        piped.append(pipe.result(pending).clone())
+        pipe.drain()
+        q.put((rank, [t.numpy() for t in serial], [t.numpy() for t in piped]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_equals_serial_gather_in_order():
+    """double-buffered batches, all-gather of batch k overlapping the compute of batch k + 1.  On two gloo ranks
+    the pipelined results must be the serial ones, batch by batch (slot reuse after two batches included: 5 batches, depth 2),
+    and every rank must hold rank 0's rows first, then rank 1's."""
+    from oracle import oracle as O
+    from tests import signals as S
+    world, port, n_batches, rows = 2, _free_port(), 5, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, n_batches, rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, serial, piped in res:
+        assert len(serial) == len(piped) == n_batches
+        for k in range(n_batches):
+            want = np.stack([O.compute_mfcc(S.uniform_pm1(1200, 1000 * k + 10 * r + i), 500) for r in range(world) for i in range(rows)])
+            assert np.array_equal(serial[k], want) and np.array_equal(piped[k], want), (rank, k)
+
+
+def test_pipeline_without_a_process_group_is_the_local_block():
+    pipe = D.GatherPipeline(4, (13,), torch.float32, "cpu")
+    slot = pipe.submit(lambda out: out.fill_(2.5))
+    assert pipe.world == 1 and torch.equal(pipe.result(slot), torch.full((4, 13), 2.5))
+    pipe.drain()
