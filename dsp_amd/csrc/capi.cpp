@@ -476,14 +476,16 @@ struct ClassifyCtx {
     int device = -1;
     dsp::SpecTables *d_tab = nullptr;
     // workspace for one sub-batch
-    float *d_x = nullptr, *d_bp = nullptr, *d_mp = nullptr, *d_sbp = nullptr;
-    float *d_mean_bp = nullptr, *d_mean_mp = nullptr;      // spectrogram segment means, written by the IIR kernel
+    float *d_x = nullptr, *d_sbp = nullptr;                // staged input (host entry points), 3000-7500 Hz PSD maps [clip][T][129]
+    float *d_ck_bp = nullptr, *d_ck_mp = nullptr;          // [clip][T][8]: delay line of each filter at every segment start
+    float *d_mean_mp = nullptr;                            // [clip][T]: segment means of the 1000-3000 Hz output
     int *d_labels = nullptr, *d_hits = nullptr;            // d_hits: work list of clips with midpoints
     int *d_loud = nullptr;                                 // [clip][T]: time bins of the 1000-3000 Hz map above 70 dB
     int *d_gate = nullptr;                                 // [clip][T]: 0 = the segment's energy rules a loud cell out (IIR kernel)
     dsp::ClassifyTrace *d_trace = nullptr;
     long cap_clips = 0;
     int cap_n = 0;
+    bool cap_x = false;
     float keep_min_db = 70.0f;                             // the midpoint threshold d_tab->mp_keep_min was computed for
     bool gate_ok = false;                                  // SpecTables::gate_ok of d_tab
     std::mutex mu;
@@ -540,42 +542,42 @@ int cls_init(int device = -1)
 int spec_bins(int n) { return n < dsp::kSpecSeg ? 0 : (n - dsp::kSpecSeg) / dsp::kSpecHop + 1; }
 long cls_row(int n) { return ((long)n + 3) & ~3L; }      // workspace row: n floats rounded up to 16 bytes
 
+void cls_free_workspace()
+{
+    for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_sbp, (void *)g_cls.d_ck_bp, (void *)g_cls.d_ck_mp, (void *)g_cls.d_loud, (void *)g_cls.d_gate,
+                    (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_hits, (void *)g_cls.d_trace})
+        if (p) hipFree(p);
+    g_cls.d_x = g_cls.d_sbp = g_cls.d_ck_bp = g_cls.d_ck_mp = g_cls.d_mean_mp = nullptr;
+    g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = g_cls.d_gate = nullptr; g_cls.d_trace = nullptr;
+    g_cls.cap_clips = 0; g_cls.cap_n = 0; g_cls.cap_x = false;
+}
+
 void cls_release()
 {
     hipSetDevice(g_cls.device);
     hipDeviceSynchronize();
-    for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_bp, (void *)g_cls.d_mp, (void *)g_cls.d_sbp, (void *)g_cls.d_loud, (void *)g_cls.d_gate,
-                    (void *)g_cls.d_mean_bp, (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_hits, (void *)g_cls.d_trace,
-                    (void *)g_cls.d_tab})
-        if (p) hipFree(p);
-    g_cls.d_x = g_cls.d_bp = g_cls.d_mp = g_cls.d_sbp = g_cls.d_mean_bp = g_cls.d_mean_mp = nullptr;
-    g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = g_cls.d_gate = nullptr; g_cls.d_trace = nullptr; g_cls.d_tab = nullptr;
-    g_cls.cap_clips = 0; g_cls.cap_n = 0;
+    cls_free_workspace();
+    if (g_cls.d_tab) hipFree(g_cls.d_tab);
+    g_cls.d_tab = nullptr;
 }
 
-int cls_reserve(long clips, int n)
+// workspace of one sub-batch; need_x: also a staging buffer for the clips themselves (host entry points)
+int cls_reserve(long clips, int n, bool need_x)
 {
-    if (clips <= g_cls.cap_clips && n <= g_cls.cap_n) return DSP_OK;
-    for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_bp, (void *)g_cls.d_mp, (void *)g_cls.d_sbp, (void *)g_cls.d_loud, (void *)g_cls.d_gate,
-                    (void *)g_cls.d_mean_bp, (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_hits, (void *)g_cls.d_trace})
-        if (p) hipFree(p);
-    g_cls.d_x = g_cls.d_bp = g_cls.d_mp = g_cls.d_sbp = g_cls.d_mean_bp = g_cls.d_mean_mp = nullptr;
-    g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = g_cls.d_gate = nullptr; g_cls.d_trace = nullptr;
-    g_cls.cap_clips = 0; g_cls.cap_n = 0;
-    const size_t sig = (size_t)clips * cls_row(n) * sizeof(float);
-    const size_t spec = (size_t)clips * dsp::kSpecBins * std::max(1, spec_bins(n)) * sizeof(float);
-    DSP_HIP(hipMalloc(&g_cls.d_x, sig));
-    DSP_HIP(hipMalloc(&g_cls.d_bp, sig));
-    DSP_HIP(hipMalloc(&g_cls.d_mp, sig));
-    DSP_HIP(hipMalloc(&g_cls.d_sbp, spec));
-    DSP_HIP(hipMalloc(&g_cls.d_loud, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(int)));
-    DSP_HIP(hipMalloc(&g_cls.d_gate, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(int)));
-    DSP_HIP(hipMalloc(&g_cls.d_mean_bp, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(float)));
-    DSP_HIP(hipMalloc(&g_cls.d_mean_mp, (size_t)clips * std::max(1, spec_bins(n)) * sizeof(float)));
+    if (clips <= g_cls.cap_clips && n <= g_cls.cap_n && (!need_x || g_cls.cap_x)) return DSP_OK;
+    cls_free_workspace();
+    const size_t T = (size_t)std::max(1, spec_bins(n));
+    if (need_x) DSP_HIP(hipMalloc(&g_cls.d_x, (size_t)clips * cls_row(n) * sizeof(float)));
+    DSP_HIP(hipMalloc(&g_cls.d_sbp, (size_t)clips * dsp::kSpecBins * T * sizeof(float)));
+    DSP_HIP(hipMalloc(&g_cls.d_ck_bp, (size_t)clips * T * 8 * sizeof(float)));
+    DSP_HIP(hipMalloc(&g_cls.d_ck_mp, (size_t)clips * T * 8 * sizeof(float)));
+    DSP_HIP(hipMalloc(&g_cls.d_loud, (size_t)clips * T * sizeof(int)));
+    DSP_HIP(hipMalloc(&g_cls.d_gate, (size_t)clips * T * sizeof(int)));
+    DSP_HIP(hipMalloc(&g_cls.d_mean_mp, (size_t)clips * T * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_labels, (size_t)clips * sizeof(int)));
     DSP_HIP(hipMalloc(&g_cls.d_hits, (size_t)(clips + 1) * sizeof(int)));
     DSP_HIP(hipMalloc(&g_cls.d_trace, (size_t)clips * sizeof(dsp::ClassifyTrace)));
-    g_cls.cap_clips = clips; g_cls.cap_n = n;
+    g_cls.cap_clips = clips; g_cls.cap_n = n; g_cls.cap_x = need_x;
     return DSP_OK;
 }
 
@@ -598,20 +600,21 @@ int cls_run(const dsp_classify_config &cfg, const float *d_x, long clips, int n,
         g_cls.keep_min_db = cfg.midpoint_db;
     }
     const dsp::ClassifyRule rule{cfg.keep_lo, cfg.keep_hi, cfg.middle_max, cfg.above_min, cfg.below_min};
-    // the filtered copies are packed (rows of n rounded up to 16 bytes) whatever the input's stride
-    const long ys = cls_row(n);
-    DSP_HIP(dsp::launch_iir_f32(d_x, clips, n, stride, bp, g_cls.d_bp, mp, g_cls.d_mp, st, g_cls.d_mean_bp, g_cls.d_mean_mp, g_cls.d_tab, g_cls.d_gate,
-                                ys, g_cls.gate_ok));
-    // midpoints first (1000-3000 Hz map); the 3000-7500 Hz spectrogram and its band sums only for clips that have midpoints
-    DSP_HIP(dsp::launch_spectrogram_flags(g_cls.d_mp, clips, n, ys, g_cls.d_tab, g_cls.d_loud, st, g_cls.d_mean_mp, g_cls.d_gate));
+    // ONE pass over the clips: both recurrences, the delay lines at every segment start, the 1000-3000 Hz segment means and
+    // the energy gate.  No filtered signal is written; the spectrogram kernels recompute the segments they transform.
+    DSP_HIP(dsp::launch_iir2_ckpt(d_x, clips, n, stride, bp, mp, g_cls.d_ck_bp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, g_cls.d_tab, st));
+    // midpoints first (1000-3000 Hz map, as flags, gated frames only); the 3000-7500 Hz spectrogram and its band sums only for
+    // clips that have midpoints
+    DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, mp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, nullptr, g_cls.d_tab,
+                                       reinterpret_cast<float *>(g_cls.d_loud), true, st));
     DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_loud, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st));
-    DSP_HIP(dsp::launch_spectrogram_f32(g_cls.d_bp, clips, n, ys, g_cls.d_tab, g_cls.d_sbp, st, g_cls.d_mean_bp, g_cls.d_hits, true));
+    DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, bp, g_cls.d_ck_bp, nullptr, nullptr, g_cls.d_hits, g_cls.d_tab, g_cls.d_sbp, false, st));
     DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, rule));
     return DSP_OK;
 }
 
-// clips per pass through the workspace (170 KB per 1 s clip): 768 blocks of 64 lanes = three resident IIR blocks per CU
-constexpr long kClsSubBatch = 49152;
+// clips per pass through the workspace (42 KB per 1 s clip): 1024 blocks of 64 clips = the four IIR blocks a CU holds
+constexpr long kClsSubBatch = 65536;
 
 }  // namespace
 
@@ -741,7 +744,7 @@ int dsp_classify_batch_host_cfg(const dsp_classify_config *cfgp, const float *si
     DSP_HIP(hipSetDevice(g_cls.device));
     for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
         const long cnt = std::min(kClsSubBatch, n_clips - c0);
-        if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n)) < 0) return rc;
+        if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n, true)) < 0) return rc;
         DSP_HIP(hipMemcpy2DAsync(g_cls.d_x, (size_t)cls_row(n) * sizeof(float), signal + c0 * stride, (size_t)stride * sizeof(float),
                                  (size_t)n * sizeof(float), cnt, hipMemcpyHostToDevice, nullptr));
         if ((rc = cls_run(cfg, g_cls.d_x, cnt, n, cls_row(n), nullptr)) < 0) return rc;
@@ -778,7 +781,7 @@ int dsp_classify_batch_device_cfg(const dsp_classify_config *cfgp, const float *
     if (spec_bins(n) == 0) { DSP_HIP(hipMemsetAsync(d_labels, 0, (size_t)n_clips * sizeof(int), st)); DSP_HIP(hipStreamSynchronize(st)); return DSP_OK; }
     for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
         const long cnt = std::min(kClsSubBatch, n_clips - c0);
-        if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n)) < 0) return rc;
+        if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n, false)) < 0) return rc;
         if ((rc = cls_run(cfg, d_signal + c0 * stride, cnt, n, stride, st)) < 0) return rc;
         DSP_HIP(hipMemcpyAsync(d_labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, st));
     }

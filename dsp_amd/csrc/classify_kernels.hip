@@ -396,6 +396,192 @@ hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, cons
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------
+// a9 for classify(), checkpoint form: ONE pass over x runs both band-pass recurrences and writes back NEITHER filtered
+// signal.  What classify() needs from the filtered signals are spectrogram segments (256 samples every 224), and a direct
+// form II filter can be restarted anywhere from its delay line v[n-1..n-8]: the kernel stores that state at every segment
+// start (32 bytes per segment and filter, 4.6 KB per 1 s clip instead of 128 KB of filtered samples), and the spectrogram
+// kernels recompute exactly the segments they transform -- same operations on the same values in the same order, so the
+// same bits (spec_from_ckpt_kernel).  For the 1000-3000 Hz filter the output taps run here as well, because its segments'
+// sequential sums (classifier.cpp:329-333) and the energy gate (see iir2_split_kernel) come from every sample; the
+// 3000-7500 Hz filter needs its taps only for clips that turn out to have midpoints, so they wait for the recompute.
+//   wave 0: recurrence 3000-7500 Hz (checkpoints)      wave 1: recurrence 1000-3000 Hz (checkpoints, v tiles to LDS)
+//   wave 2: taps 1000-3000 Hz one tile behind (segment means, energy gate)
+// HBM traffic: x once + 71 x (32 + 32 + 4 + 4) B per 1 s clip.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride,
+                                                        const IirCoef c_bp, const IirCoef c_mp, float *__restrict__ ck_bp,
+                                                        float *__restrict__ ck_mp, float *__restrict__ means_mp,
+                                                        int *__restrict__ gate_mp, const SpecTables *__restrict__ tab, int vec_ok)
+{
+    __shared__ float tin[2][64 * IIR_LD];
+    __shared__ float vbuf[2][64 * IIR_LD];             // v tiles of the 1000-3000 Hz filter, [tile parity]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_r = wv < 2;
+    const IirCoef c = wv == 0 ? c_bp : c_mp;
+    float *__restrict__ ck = wv == 0 ? ck_bp : ck_mp;
+    const long clip0 = (long)blockIdx.x * 64;
+    const int rows = (int)((n_clips - clip0) < 64 ? (n_clips - clip0) : 64);
+    const int n_tiles = (n + IIR_TS - 1) / IIR_TS;
+    const int n_seg = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
+    static_assert(kSpecHop % IIR_TS == 0 && kSpecSeg - kSpecHop == IIR_TS, "segments start on tile boundaries and overlap by one tile");
+    constexpr int kTilesPerHop = kSpecHop / IIR_TS;
+    float d[8];                                         // v[n-1] .. v[n-8] of this lane's clip
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = 0.0f;
+    float cur = 0.0f, prev = 0.0f;
+    const bool gating = tab->gate_ok != 0;
+    float ea_cur = 0.0f, eb_cur = 0.0f, ea_prev = 0.0f, eb_prev = 0.0f;
+
+    constexpr int CH = IIR_TS / 4, NV = 64 * CH / 128;
+    float4 pre[NV];
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * 4;
+            pre[k] = r < rows ? *reinterpret_cast<const float4 *>(x + (clip0 + r) * stride + t0 + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](float *dst) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * 4;
+            dst[r * IIR_LD + cc] = pre[k].x; dst[r * IIR_LD + cc + 1] = pre[k].y;
+            dst[r * IIR_LD + cc + 2] = pre[k].z; dst[r * IIR_LD + cc + 3] = pre[k].w;
+        }
+    };
+    auto load_scalar = [&](int t0, int cols, float *dst) {        // short last tile, or rows that are not 16-byte aligned
+        for (int e = tid; e < 64 * IIR_TS; e += 128) {
+            const int r = e / IIR_TS, ci = e % IIR_TS;
+            dst[r * IIR_LD + ci] = (r < rows && ci < cols) ? x[(clip0 + r) * stride + t0 + ci] : 0.0f;
+        }
+    };
+    auto tile_cols = [&](int s) { const int t0 = s * IIR_TS; return n - t0 < IIR_TS ? n - t0 : IIR_TS; };
+    auto fast = [&](int s) { return vec_ok && tile_cols(s) == IIR_TS; };
+    if (is_r) {                                                    // tile 0 into tin[0], tile 1 in flight
+        if (fast(0)) { issue(0); commit(tin[0]); } else load_scalar(0, tile_cols(0), tin[0]);
+        if (n_tiles > 1 && fast(1)) issue(IIR_TS);
+    }
+    __syncthreads();
+
+    for (int s = 0; s <= n_tiles; ++s) {
+        if (is_r) {
+            if (s < n_tiles) {
+                if (s + 1 < n_tiles) {
+                    if (fast(s + 1)) commit(tin[(s + 1) & 1]); else load_scalar((s + 1) * IIR_TS, tile_cols(s + 1), tin[(s + 1) & 1]);
+                    if (s + 2 < n_tiles && fast(s + 2)) issue((s + 2) * IIR_TS);
+                }
+                // segment seg starts with this tile: its restart state is the delay line as it stands
+                const int seg = s / kTilesPerHop;
+                if (s % kTilesPerHop == 0 && seg < n_seg && lane < rows) {
+                    float4 *dst = reinterpret_cast<float4 *>(ck + ((clip0 + lane) * n_seg + seg) * 8);
+                    dst[0] = make_float4(d[0], d[1], d[2], d[3]);
+                    dst[1] = make_float4(d[4], d[5], d[6], d[7]);
+                }
+                const float *xin = tin[s & 1];
+                float *vo = vbuf[s & 1];
+                const int cols = tile_cols(s);
+                auto rec = [&](float xv) {                           // classifier.cpp:199-205
+                    float v = xv;
+#pragma unroll
+                    for (int j = 1; j <= 8; ++j) v = v - c.a[j] * d[j - 1];
+#pragma unroll
+                    for (int j = 7; j > 0; --j) d[j] = d[j - 1];
+                    d[0] = v;
+                    return v;
+                };
+                if (lane < rows && cols == IIR_TS) {
+#pragma unroll
+                    for (int h = 0; h < IIR_TS; h += IIR_BURST) {
+                        float xr[IIR_BURST], vr[IIR_BURST];
+#pragma unroll
+                        for (int i = 0; i < IIR_BURST; ++i) xr[i] = xin[lane * IIR_LD + h + i];
+#pragma unroll
+                        for (int i = 0; i < IIR_BURST; ++i) vr[i] = rec(xr[i]);
+                        if (wv == 1) {
+#pragma unroll
+                            for (int i = 0; i < IIR_BURST; ++i) vo[lane * IIR_LD + h + i] = vr[i];
+                        }
+                    }
+                } else if (lane < rows) {
+                    for (int i = 0; i < cols; ++i) { const float v = rec(xin[lane * IIR_LD + i]); if (wv == 1) vo[lane * IIR_LD + i] = v; }
+                }
+            }
+        } else if (s >= 1) {
+            const int cols = tile_cols(s - 1);
+            const float *vin = vbuf[(s - 1) & 1];
+            auto taps = [&](float v) {                               // classifier.cpp:207-216
+                float o = c.b[0] * v;
+#pragma unroll
+                for (int j = 1; j <= 8; ++j) o = o + c.b[j] * d[j - 1];
+#pragma unroll
+                for (int j = 7; j > 0; --j) d[j] = d[j - 1];
+                d[0] = v;
+                return o;
+            };
+            const int ti = s - 1, seg_k = ti / kTilesPerHop;
+            const bool seg_start = ti % kTilesPerHop == 0;
+            const bool seg_both = seg_start && seg_k >= 1;           // the tile also closes segment seg_k - 1
+            if (seg_start) { prev = cur; cur = 0.0f; ea_prev = ea_cur; eb_prev = eb_cur; ea_cur = eb_cur = 0.0f; }
+            if (lane < rows && cols == IIR_TS) {
+#pragma unroll
+                for (int h = 0; h < IIR_TS; h += IIR_BURST) {
+                    float vr[IIR_BURST], orr[IIR_BURST];
+#pragma unroll
+                    for (int i = 0; i < IIR_BURST; ++i) vr[i] = vin[lane * IIR_LD + h + i];
+#pragma unroll
+                    for (int i = 0; i < IIR_BURST; ++i) orr[i] = taps(vr[i]);
+                    if (seg_both) {
+#pragma unroll
+                        for (int i = 0; i < IIR_BURST; ++i) { cur = cur + orr[i]; prev = prev + orr[i]; }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < IIR_BURST; ++i) cur = cur + orr[i];
+                    }
+                    if (gating) {
+                        if (seg_start) {                             // tapered tile: in for the new segment, out for the old one
+#pragma unroll
+                            for (int i = 0; i < IIR_BURST; ++i) {
+                                const float wi = tab->win2_in[h + i] * orr[i], wo = tab->win2_out[h + i] * orr[i];
+                                ea_cur = fmaf(wi, orr[i], ea_cur); eb_cur = eb_cur + wi;
+                                ea_prev = fmaf(wo, orr[i], ea_prev); eb_prev = eb_prev + wo;
+                            }
+                        } else {                                     // the window is 1 here
+#pragma unroll
+                            for (int i = 0; i < IIR_BURST; ++i) { ea_cur = fmaf(orr[i], orr[i], ea_cur); eb_cur = eb_cur + orr[i]; }
+                        }
+                    }
+                }
+                if (seg_both && seg_k - 1 < n_seg) {
+                    const float m = prev / (float)kSpecSeg;
+                    means_mp[(clip0 + lane) * n_seg + seg_k - 1] = m;
+                    int g = 1;
+                    if (gating) {
+                        const float e = ea_prev + 2.0f * fabsf(m) * fabsf(eb_prev) + m * m * tab->win2_sum;
+                        g = e * tab->gate_scale >= tab->mp_keep_min ? 1 : 0;
+                    }
+                    gate_mp[(clip0 + lane) * n_seg + seg_k - 1] = g;
+                }
+            } else if (lane < rows) {
+                for (int i = 0; i < cols; ++i) (void)taps(vin[lane * IIR_LD + i]);    // a short last tile lies past every whole segment
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
+                            float *ck_bp, float *ck_mp, float *means_mp, int *gate_mp, const SpecTables *tables, hipStream_t stream)
+{
+    if (n_clips <= 0 || n <= 0) return hipSuccess;
+    const int blocks = (int)((n_clips + 63) / 64);
+    const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    hipLaunchKernelGGL(iir2_ckpt_kernel, dim3(blocks), dim3(192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, means_mp, gate_mp,
+                       tables, vec_ok);
+    return hipGetLastError();
+}
+
 hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long stride, const IirCoefD &c, float *y,
                                  hipStream_t stream)
 {
@@ -649,6 +835,275 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
         if (++t == T) { t = 0; ++slot; if (f + 1 < n_here) clip = clip_of(slot); }
     }
     if (OUT == SPEC_FLAGS && lane < n_here) reinterpret_cast<int *>(sxx)[gid0 + lane] = flag;      // [clip][T] (no work list here)
+}
+
+// ---------------------------------------------------------------------------------
+// a10 from checkpoints: the spectrogram of segments that were never written to HBM.  A 256-thread block takes 64 frame
+// slots ((clip, time bin) pairs); for the wanted ones it
+//   R  recomputes the recurrence v over the segment's 256 samples, lane per frame (wave 0), from the delay line
+//      iir2_ckpt_kernel stored at the segment start: classifier.cpp:199-205 on the same x with the same state;
+//   T  applies the output taps y[n] = b0 v[n] + sum b[j] v[n-j] (classifier.cpp:207-216): no feedback, so the four waves
+//      take a quarter of every segment each, and y overwrites v in place;
+//   M  (3000-7500 Hz map only) sums each segment in order for its mean (classifier.cpp:329-333), lane per frame;
+//   F  runs the 256-point PlainFFT of each wanted frame, a wave per frame, 16 frames per wave, exactly as
+//      spectrogram_kernel does, reading the samples from the block's LDS rows.
+// OUT = SPEC_FLAGS: slot = clip * T + t over all clips, wanted = gate != 0, output one flag per slot (0 for the others);
+// OUT = SPEC_FRAME_MAJOR: slots walk the work list `hits`, every frame is wanted, output [time][bin] PSD rows.
+// ---------------------------------------------------------------------------------
+constexpr int RC_ROW = 8 + kSpecSeg + 1;      // v[-8..-1] | 256 samples | pad: odd stride, lane l <-> row l is conflict free
+
+struct SpecLane {                             // per-lane constants of the 256-point FFT (see spectrogram_kernel)
+    int pos[4][4];
+    cpx ua[4], ub0[4], ub1[4];
+    int src[4];
+    float win[4];
+    __device__ __forceinline__ void init(int lane, const SpecTables *__restrict__ tab)
+    {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int l = 2 * p, l1 = 1 << l, m = lane & (l1 - 1);
+            const int base = ((lane >> l) << (l + 2)) | m;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pos[p][j] = spec_swz(base + (j << l));
+            ua[p] = {tab->tw_re[l1 - 1 + m], tab->tw_im[l1 - 1 + m]};
+            ub0[p] = {tab->tw_re[2 * l1 - 1 + m], tab->tw_im[2 * l1 - 1 + m]};
+            ub1[p] = {tab->tw_re[2 * l1 - 1 + m + l1], tab->tw_im[2 * l1 - 1 + m + l1]};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            src[j] = 64 * (((j & 1) << 1) | (j >> 1)) + (int)bitrev6(lane);
+            win[j] = tab->window[src[j]];
+        }
+    }
+    // cur[j] = sample src[j] of the frame; returns the PSD cells lane, lane + 64 and (lane 0) 128
+    __device__ __forceinline__ void psd(const float (&cur)[4], float mean_f, float U, bool trivial01, float2 *buf, int lane,
+                                        float &p0, float &p1, float &p2) const
+    {
+        cpx v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = {(cur[j] - mean_f) * win[j], 0.0f};          // classifier.cpp:336-346
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (p > 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float2 q = buf[pos[p][j]]; v[j] = {q.x, q.y}; }
+            }
+            if (p == 0 && trivial01) {
+                const float a0 = v[0].x + v[1].x, a1 = v[0].x - v[1].x, a2 = v[2].x + v[3].x, a3 = v[2].x - v[3].x;
+                v[0] = {a0 + a2, 0.0f};
+                v[2] = {a0 - a2, 0.0f};
+                v[1] = {a1, -a3};
+                v[3] = {a1, a3};
+            } else {
+                butterfly(v[0], v[1], ua[p]);
+                butterfly(v[2], v[3], ua[p]);
+                butterfly(v[0], v[2], ub0[p]);
+                butterfly(v[1], v[3], ub1[p]);
+            }
+            if (p < 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) buf[pos[p][j]] = make_float2(v[j].x, v[j].y);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        p0 = (v[0].x * v[0].x + v[0].y * v[0].y) / U;                                    // classifier.cpp:350-365
+        if (lane >= 1) p0 = p0 * 2.0f;
+        p1 = (v[1].x * v[1].x + v[1].y * v[1].y) / U;
+        p1 = p1 * 2.0f;
+        p2 = (v[2].x * v[2].x + v[2].y * v[2].y) / U;
+        // the next frame's first butterfly level writes buf: order it behind this frame's last reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
+template <int OUT>
+__global__ __launch_bounds__(256) void spec_from_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride, const IirCoef c,
+                                                             const float *__restrict__ ck, const float *__restrict__ means,
+                                                             const int *__restrict__ gate, const int *__restrict__ hits,
+                                                             const SpecTables *__restrict__ tab, float *__restrict__ out, int T, int vec_ok)
+{
+    static_assert(OUT == SPEC_FLAGS || OUT == SPEC_FRAME_MAJOR, "flags or [time][bin]");
+    __shared__ float rows[64 * RC_ROW];
+    __shared__ float2 fftbuf[4][kSpecSeg];
+    __shared__ float smean[64];
+    __shared__ int sflag[64];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long total = (hits ? (long)hits[0] : n_clips) * T;
+    const long gid0 = (long)blockIdx.x * 64;
+    if (gid0 >= total) return;
+    // every wave's lane l describes frame slot gid0 + l
+    const long gid = gid0 + lane;
+    const bool valid = gid < total;
+    long clip = 0;
+    int t = 0;
+    if (valid) {
+        const long slotc = gid / T;
+        t = (int)(gid - slotc * T);
+        clip = hits ? (long)hits[1 + slotc] : slotc;
+    }
+    const bool want = valid && (OUT != SPEC_FLAGS || gate[clip * T + t] != 0);
+    const unsigned long long todo = __ballot(want);
+    if (todo == 0) {                                        // same decision in all four waves
+        if (OUT == SPEC_FLAGS && wib == 0 && valid) reinterpret_cast<int *>(out)[gid] = 0;
+        return;
+    }
+    float *row = rows + lane * RC_ROW;
+
+    // ---- R: v over the segment, from the stored delay line
+    if (wib == 0) {
+        sflag[lane] = 0;
+        if (want) {
+            const float *xs = x + clip * stride + (long)t * kSpecHop;
+            float d[8];
+            {
+                const float4 *src = reinterpret_cast<const float4 *>(ck + (clip * T + t) * 8);
+                const float4 a = src[0], b = src[1];
+                d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) row[7 - j] = d[j];                   // row[8 + m] = v[m], m = -8 .. 255
+            auto fetch = [&](int h, float (&dst)[IIR_BURST]) {
+                if (vec_ok) {
+#pragma unroll
+                    for (int q = 0; q < IIR_BURST / 4; ++q) {
+                        const float4 v4 = *reinterpret_cast<const float4 *>(xs + h + 4 * q);
+                        dst[4 * q] = v4.x; dst[4 * q + 1] = v4.y; dst[4 * q + 2] = v4.z; dst[4 * q + 3] = v4.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < IIR_BURST; ++i) dst[i] = xs[h + i];
+                }
+            };
+            float nx[IIR_BURST];
+            fetch(0, nx);
+#pragma unroll 1
+            for (int h = 0; h < kSpecSeg; h += IIR_BURST) {
+                float xr[IIR_BURST], vr[IIR_BURST];
+#pragma unroll
+                for (int i = 0; i < IIR_BURST; ++i) xr[i] = nx[i];
+                if (h + IIR_BURST < kSpecSeg) fetch(h + IIR_BURST, nx);      // in flight during this burst's recurrence
+#pragma unroll
+                for (int i = 0; i < IIR_BURST; ++i) {                       // classifier.cpp:199-205
+                    float v = xr[i];
+#pragma unroll
+                    for (int j = 1; j <= 8; ++j) v = v - c.a[j] * d[j - 1];
+#pragma unroll
+                    for (int j = 7; j > 0; --j) d[j] = d[j - 1];
+                    d[0] = v;
+                    vr[i] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < IIR_BURST; ++i) row[8 + h + i] = vr[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- T: output taps, wave w takes samples [64 w, 64 w + 64) of every wanted frame; y replaces v
+    {
+        const int n0 = 64 * wib;
+        float d[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = want ? row[8 + n0 - 1 - j] : 0.0f;       // v[n0-1] .. v[n0-8]
+        __syncthreads();                                                         // every history is read before any y lands
+        if (want) {
+#pragma unroll 1
+            for (int h = 0; h < 64; h += IIR_BURST) {
+                float vr[IIR_BURST], orr[IIR_BURST];
+#pragma unroll
+                for (int i = 0; i < IIR_BURST; ++i) vr[i] = row[8 + n0 + h + i];
+#pragma unroll
+                for (int i = 0; i < IIR_BURST; ++i) {                           // classifier.cpp:207-216
+                    float o = c.b[0] * vr[i];
+#pragma unroll
+                    for (int j = 1; j <= 8; ++j) o = o + c.b[j] * d[j - 1];
+#pragma unroll
+                    for (int j = 7; j > 0; --j) d[j] = d[j - 1];
+                    d[0] = vr[i];
+                    orr[i] = o;
+                }
+#pragma unroll
+                for (int i = 0; i < IIR_BURST; ++i) row[8 + n0 + h + i] = orr[i];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- M: segment means (sequential sums, classifier.cpp:329-333)
+    if (wib == 0 && want) {
+        float mean;
+        if (means) {
+            mean = means[clip * T + t];                      // summed in the same order by iir2_ckpt_kernel's taps wave
+        } else {
+            float sum = 0.0f;
+#pragma unroll 1
+            for (int h = 0; h < kSpecSeg; h += IIR_BURST) {
+                float yr[IIR_BURST];
+#pragma unroll
+                for (int i = 0; i < IIR_BURST; ++i) yr[i] = row[8 + h + i];
+#pragma unroll
+                for (int i = 0; i < IIR_BURST; ++i) sum = sum + yr[i];
+            }
+            mean = sum / (float)kSpecSeg;
+        }
+        smean[lane] = mean;
+    }
+    __syncthreads();
+
+    // ---- F: one frame at a time per wave
+    SpecLane K;
+    K.init(lane, tab);
+    const float U = tab->U, keep_min = tab->mp_keep_min;
+    const bool trivial01 = tab->trivial_first_levels != 0;
+    float2 *buf = fftbuf[wib];
+    const unsigned clip_lo = (unsigned)clip, clip_hi = (unsigned)((unsigned long long)clip >> 32);
+#pragma unroll 1
+    for (int f = 16 * wib; f < 16 * wib + 16; ++f) {
+        if (!((todo >> f) & 1)) continue;
+        const float *fr = rows + f * RC_ROW + 8;
+        float cur[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = fr[K.src[j]];
+        float p0, p1, p2;
+        K.psd(cur, smean[f], U, trivial01, buf, lane, p0, p1, p2);
+        if (OUT == SPEC_FLAGS) {
+            const bool loud = p0 >= keep_min || p1 >= keep_min || (lane == 0 && p2 >= keep_min);
+            if (__ballot(loud) != 0 && lane == 0) sflag[f] = 1;
+        } else {
+            const long fclip = (long)(((unsigned long long)__builtin_amdgcn_readlane(clip_hi, f) << 32) | __builtin_amdgcn_readlane(clip_lo, f));
+            const int ft = __builtin_amdgcn_readlane(t, f);
+            float *o = out + (fclip * T + ft) * (long)kSpecBins;
+            o[lane] = p0;
+            o[lane + 64] = p1;
+            if (lane == 0) o[128] = p2;
+        }
+    }
+    if (OUT == SPEC_FLAGS) {
+        __syncthreads();
+        if (wib == 0 && valid) reinterpret_cast<int *>(out)[gid] = want ? sflag[lane] : 0;
+    }
+}
+
+hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
+                                 const int *gate, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream)
+{
+    const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
+    if (n_clips <= 0 || T <= 0) return hipSuccess;
+    const long total = n_clips * T;                       // with a work list: the bound; blocks past hits[0] * T exit at once
+    const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    const dim3 grid((unsigned)((total + 63) / 64));
+    if (flags)
+        hipLaunchKernelGGL(spec_from_ckpt_kernel<SPEC_FLAGS>, grid, dim3(256), 0, stream, x, n_clips, n, stride, c, ck, means, gate,
+                           (const int *)nullptr, tables, out, T, vec_ok);
+    else
+        hipLaunchKernelGGL(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR>, grid, dim3(256), 0, stream, x, n_clips, n, stride, c, ck, means,
+                           (const int *)nullptr, hits, tables, out, T, vec_ok);
+    return hipGetLastError();
 }
 
 hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
