@@ -591,7 +591,7 @@ dsp::IirCoef coef_f32(double lo, double hi)
 }
 
 // one sub-batch already resident at d_x (row stride n): labels (+ trace) into the workspace
-int cls_run(const dsp_classify_config &cfg, const float *d_x, long clips, int n, long stride, hipStream_t st)
+int cls_run(const dsp_classify_config &cfg, const float *d_x, long clips, int n, long stride, hipStream_t st, bool want_trace)
 {
     const dsp::IirCoef bp = coef_f32(3000, 7500), mp = coef_f32(1000, 3000);   // classifier.cpp:14-19, 438-442
     if (cfg.midpoint_db != g_cls.keep_min_db) {      // the table's threshold PSD value follows the configured dB threshold
@@ -607,7 +607,7 @@ int cls_run(const dsp_classify_config &cfg, const float *d_x, long clips, int n,
     // clips that have midpoints
     DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, mp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, nullptr, g_cls.d_tab,
                                        reinterpret_cast<float *>(g_cls.d_loud), true, st));
-    DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_loud, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st));
+    DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_loud, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, want_trace));
     DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, bp, g_cls.d_ck_bp, nullptr, nullptr, g_cls.d_hits, g_cls.d_tab, g_cls.d_sbp, false, st));
     DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, rule));
     return DSP_OK;
@@ -747,7 +747,7 @@ int dsp_classify_batch_host_cfg(const dsp_classify_config *cfgp, const float *si
         if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n, true)) < 0) return rc;
         DSP_HIP(hipMemcpy2DAsync(g_cls.d_x, (size_t)cls_row(n) * sizeof(float), signal + c0 * stride, (size_t)stride * sizeof(float),
                                  (size_t)n * sizeof(float), cnt, hipMemcpyHostToDevice, nullptr));
-        if ((rc = cls_run(cfg, g_cls.d_x, cnt, n, cls_row(n), nullptr)) < 0) return rc;
+        if ((rc = cls_run(cfg, g_cls.d_x, cnt, n, cls_row(n), nullptr, trace != nullptr)) < 0) return rc;
         DSP_HIP(hipMemcpyAsync(labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, nullptr));
         if (trace) DSP_HIP(hipMemcpyAsync(trace + c0, g_cls.d_trace, (size_t)cnt * sizeof(dsp::ClassifyTrace), hipMemcpyDeviceToHost, nullptr));
         DSP_HIP(hipStreamSynchronize(nullptr));
@@ -782,7 +782,7 @@ int dsp_classify_batch_device_cfg(const dsp_classify_config *cfgp, const float *
     for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
         const long cnt = std::min(kClsSubBatch, n_clips - c0);
         if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n, false)) < 0) return rc;
-        if ((rc = cls_run(cfg, d_signal + c0 * stride, cnt, n, stride, st)) < 0) return rc;
+        if ((rc = cls_run(cfg, d_signal + c0 * stride, cnt, n, stride, st, false)) < 0) return rc;
         DSP_HIP(hipMemcpyAsync(d_labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, st));
     }
     DSP_HIP(hipStreamSynchronize(st));      // the workspace is shared: it must be idle before the lock is released

@@ -434,16 +434,18 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
     const bool gating = tab->gate_ok != 0;
     float ea_cur = 0.0f, eb_cur = 0.0f, ea_prev = 0.0f, eb_prev = 0.0f;
 
+    // x tiles travel HBM -> registers -> LDS, TWO tiles ahead of the recurrence (a tile is ~1 us of recurrence, an HBM load
+    // under a full-chip stream takes longer): register set P holds tile s + 1 while set Q's loads of tile s + 2 are in flight
     constexpr int CH = IIR_TS / 4, NV = 64 * CH / 128;
-    float4 pre[NV];
-    auto issue = [&](int t0) {
+    float4 preA[NV], preB[NV];
+    auto issue = [&](int t0, float4 (&pre)[NV]) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * 4;
             pre[k] = r < rows ? *reinterpret_cast<const float4 *>(x + (clip0 + r) * stride + t0 + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto commit = [&](float *dst) {
+    auto commit = [&](float *dst, const float4 (&pre)[NV]) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * 4;
@@ -459,18 +461,25 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
     };
     auto tile_cols = [&](int s) { const int t0 = s * IIR_TS; return n - t0 < IIR_TS ? n - t0 : IIR_TS; };
     auto fast = [&](int s) { return vec_ok && tile_cols(s) == IIR_TS; };
-    if (is_r) {                                                    // tile 0 into tin[0], tile 1 in flight
-        if (fast(0)) { issue(0); commit(tin[0]); } else load_scalar(0, tile_cols(0), tin[0]);
-        if (n_tiles > 1 && fast(1)) issue(IIR_TS);
+    if (is_r) {                                                    // tile 0 into tin[0]; tiles 1 (set B) and 2 (set A) in flight
+        if (fast(0)) { issue(0, preA); commit(tin[0], preA); } else load_scalar(0, tile_cols(0), tin[0]);
+        if (n_tiles > 1 && fast(1)) issue(IIR_TS, preB);
+        if (n_tiles > 2 && fast(2)) issue(2 * IIR_TS, preA);
     }
     __syncthreads();
 
     for (int s = 0; s <= n_tiles; ++s) {
         if (is_r) {
             if (s < n_tiles) {
+                // stage tile s + 1 for the next step from its register set, then reuse that set for tile s + 3
                 if (s + 1 < n_tiles) {
-                    if (fast(s + 1)) commit(tin[(s + 1) & 1]); else load_scalar((s + 1) * IIR_TS, tile_cols(s + 1), tin[(s + 1) & 1]);
-                    if (s + 2 < n_tiles && fast(s + 2)) issue((s + 2) * IIR_TS);
+                    if ((s + 1) & 1) {
+                        if (fast(s + 1)) commit(tin[1], preB); else load_scalar((s + 1) * IIR_TS, tile_cols(s + 1), tin[1]);
+                        if (s + 3 < n_tiles && fast(s + 3)) issue((s + 3) * IIR_TS, preB);
+                    } else {
+                        if (fast(s + 1)) commit(tin[0], preA); else load_scalar((s + 1) * IIR_TS, tile_cols(s + 1), tin[0]);
+                        if (s + 3 < n_tiles && fast(s + 3)) issue((s + 3) * IIR_TS, preA);
+                    }
                 }
                 // segment seg starts with this tile: its restart state is the delay line as it stands
                 const int seg = s / kTilesPerHop;
@@ -840,6 +849,7 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
 // ---------------------------------------------------------------------------------
 // a10 from checkpoints: the spectrogram of segments that were never written to HBM.  A 256-thread block takes 64 frame
 // slots ((clip, time bin) pairs); for the wanted ones it
+//   L  loads the segments' 256 input samples into its LDS rows (all waves, coalesced 1 KB rows);
 //   R  recomputes the recurrence v over the segment's 256 samples, lane per frame (wave 0), from the delay line
 //      iir2_ckpt_kernel stored at the segment start: classifier.cpp:199-205 on the same x with the same state;
 //   T  applies the output taps y[n] = b0 v[n] + sum b[j] v[n-j] (classifier.cpp:207-216): no feedback, so the four waves
@@ -850,6 +860,8 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
 // OUT = SPEC_FLAGS: slot = clip * T + t over all clips, wanted = gate != 0, output one flag per slot (0 for the others);
 // OUT = SPEC_FRAME_MAJOR: slots walk the work list `hits`, every frame is wanted, output [time][bin] PSD rows.
 // ---------------------------------------------------------------------------------
+constexpr int RC_THREADS = 256, RC_WAVES = RC_THREADS / 64;
+static_assert((kSpecSeg / RC_WAVES) % IIR_BURST == 0 && 64 % RC_WAVES == 0, "taps and frames split evenly over the waves");
 constexpr int RC_ROW = 8 + kSpecSeg + 1;      // v[-8..-1] | 256 samples | pad: odd stride, lane l <-> row l is conflict free
 
 struct SpecLane {                             // per-lane constants of the 256-point FFT (see spectrogram_kernel)
@@ -921,14 +933,14 @@ struct SpecLane {                             // per-lane constants of the 256-p
 };
 
 template <int OUT>
-__global__ __launch_bounds__(256) void spec_from_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride, const IirCoef c,
+__global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void spec_from_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride, const IirCoef c,
                                                              const float *__restrict__ ck, const float *__restrict__ means,
                                                              const int *__restrict__ gate, const int *__restrict__ hits,
                                                              const SpecTables *__restrict__ tab, float *__restrict__ out, int T, int vec_ok)
 {
     static_assert(OUT == SPEC_FLAGS || OUT == SPEC_FRAME_MAJOR, "flags or [time][bin]");
     __shared__ float rows[64 * RC_ROW];
-    __shared__ float2 fftbuf[4][kSpecSeg];
+    __shared__ float2 fftbuf[RC_WAVES][kSpecSeg];
     __shared__ float smean[64];
     __shared__ int sflag[64];
     const int lane = threadIdx.x & 63;
@@ -954,11 +966,29 @@ __global__ __launch_bounds__(256) void spec_from_ckpt_kernel(const float *__rest
     }
     float *row = rows + lane * RC_ROW;
 
-    // ---- R: v over the segment, from the stored delay line
+    // ---- L: the wanted segments of x into the rows, all loads of the block in flight together (lane-per-frame loads in the
+    // recurrence loop would each pay an HBM round trip the serial arithmetic cannot cover)
+    {
+        constexpr int PER_ROW = kSpecSeg / 4;                       // float4 pieces per segment: one wave-instruction = one row
+        for (int e = threadIdx.x; e < 64 * PER_ROW; e += RC_THREADS) {
+            const int r = e / PER_ROW, c4 = (e % PER_ROW) * 4;
+            if (!((todo >> r) & 1)) continue;
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)clip, r), hi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)clip >> 32), r);
+            const long rclip = (long)(((unsigned long long)hi << 32) | lo);
+            const float *xs = x + rclip * stride + (long)__builtin_amdgcn_readlane(t, r) * kSpecHop + c4;
+            float4 v4;
+            if (vec_ok) v4 = *reinterpret_cast<const float4 *>(xs);
+            else v4 = make_float4(xs[0], xs[1], xs[2], xs[3]);
+            float *dst = rows + r * RC_ROW + 8 + c4;
+            dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
+        }
+    }
+    __syncthreads();
+
+    // ---- R: v over the segment, from the stored delay line; v replaces x in the row
     if (wib == 0) {
         sflag[lane] = 0;
         if (want) {
-            const float *xs = x + clip * stride + (long)t * kSpecHop;
             float d[8];
             {
                 const float4 *src = reinterpret_cast<const float4 *>(ck + (clip * T + t) * 8);
@@ -967,26 +997,11 @@ __global__ __launch_bounds__(256) void spec_from_ckpt_kernel(const float *__rest
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) row[7 - j] = d[j];                   // row[8 + m] = v[m], m = -8 .. 255
-            auto fetch = [&](int h, float (&dst)[IIR_BURST]) {
-                if (vec_ok) {
-#pragma unroll
-                    for (int q = 0; q < IIR_BURST / 4; ++q) {
-                        const float4 v4 = *reinterpret_cast<const float4 *>(xs + h + 4 * q);
-                        dst[4 * q] = v4.x; dst[4 * q + 1] = v4.y; dst[4 * q + 2] = v4.z; dst[4 * q + 3] = v4.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < IIR_BURST; ++i) dst[i] = xs[h + i];
-                }
-            };
-            float nx[IIR_BURST];
-            fetch(0, nx);
 #pragma unroll 1
             for (int h = 0; h < kSpecSeg; h += IIR_BURST) {
                 float xr[IIR_BURST], vr[IIR_BURST];
 #pragma unroll
-                for (int i = 0; i < IIR_BURST; ++i) xr[i] = nx[i];
-                if (h + IIR_BURST < kSpecSeg) fetch(h + IIR_BURST, nx);      // in flight during this burst's recurrence
+                for (int i = 0; i < IIR_BURST; ++i) xr[i] = row[8 + h + i];
 #pragma unroll
                 for (int i = 0; i < IIR_BURST; ++i) {                       // classifier.cpp:199-205
                     float v = xr[i];
@@ -1004,16 +1019,17 @@ __global__ __launch_bounds__(256) void spec_from_ckpt_kernel(const float *__rest
     }
     __syncthreads();
 
-    // ---- T: output taps, wave w takes samples [64 w, 64 w + 64) of every wanted frame; y replaces v
+    // ---- T: output taps, wave w takes samples [RC_TQ w, RC_TQ (w + 1)) of every wanted frame; y replaces v
     {
-        const int n0 = 64 * wib;
+        constexpr int RC_TQ = kSpecSeg / RC_WAVES;
+        const int n0 = RC_TQ * wib;
         float d[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) d[j] = want ? row[8 + n0 - 1 - j] : 0.0f;       // v[n0-1] .. v[n0-8]
         __syncthreads();                                                         // every history is read before any y lands
         if (want) {
 #pragma unroll 1
-            for (int h = 0; h < 64; h += IIR_BURST) {
+            for (int h = 0; h < RC_TQ; h += IIR_BURST) {
                 float vr[IIR_BURST], orr[IIR_BURST];
 #pragma unroll
                 for (int i = 0; i < IIR_BURST; ++i) vr[i] = row[8 + n0 + h + i];
@@ -1063,7 +1079,7 @@ __global__ __launch_bounds__(256) void spec_from_ckpt_kernel(const float *__rest
     float2 *buf = fftbuf[wib];
     const unsigned clip_lo = (unsigned)clip, clip_hi = (unsigned)((unsigned long long)clip >> 32);
 #pragma unroll 1
-    for (int f = 16 * wib; f < 16 * wib + 16; ++f) {
+    for (int f = (64 / RC_WAVES) * wib; f < (64 / RC_WAVES) * (wib + 1); ++f) {
         if (!((todo >> f) & 1)) continue;
         const float *fr = rows + f * RC_ROW + 8;
         float cur[4];
@@ -1098,10 +1114,10 @@ hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long strid
     const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
     const dim3 grid((unsigned)((total + 63) / 64));
     if (flags)
-        hipLaunchKernelGGL(spec_from_ckpt_kernel<SPEC_FLAGS>, grid, dim3(256), 0, stream, x, n_clips, n, stride, c, ck, means, gate,
+        hipLaunchKernelGGL(spec_from_ckpt_kernel<SPEC_FLAGS>, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, gate,
                            (const int *)nullptr, tables, out, T, vec_ok);
     else
-        hipLaunchKernelGGL(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR>, grid, dim3(256), 0, stream, x, n_clips, n, stride, c, ck, means,
+        hipLaunchKernelGGL(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR>, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means,
                            (const int *)nullptr, hits, tables, out, T, vec_ok);
     return hipGetLastError();
 }
@@ -1279,7 +1295,7 @@ hipError_t launch_spec_threshold(SpecTables *tables, float threshold_db, hipStre
 //                              band sums per midpoint in the reference's order, the rule
 __global__ __launch_bounds__(256) void classify_midpoints_kernel(const int *__restrict__ loud, long n_clips, int T, int fs,
                                                                  int *__restrict__ labels, ClassifyTrace *__restrict__ trace,
-                                                                 int *__restrict__ hits)
+                                                                 int *__restrict__ hits, int full_records)
 {
     // a wavefront per clip; loud[clip][T] are the time bins with a cell above 70 dB (spectrogram_kernel<SPEC_FLAGS>)
     __shared__ float blob_all[4][1024];
@@ -1323,6 +1339,7 @@ __global__ __launch_bounds__(256) void classify_midpoints_kernel(const int *__re
         if (count == 0) labels[clip] = 0;                   // classifier.cpp:93-114: no midpoint can fire the rule
         else hits[1 + atomicAdd(hits, 1)] = (int)clip;      // work list of the band kernels, any order
     }
+    if (!full_records) return;          // nobody reads the records of this batch (labels only): 1 KB per clip not written
     count = __builtin_amdgcn_readfirstlane(count);
     // a whole record per clip: unused midpoints and the band sums the rule never reaches (no midpoints, or after the
     // first hit) read as 0.  midpoints[64] and sums[64][3] are 256 consecutive floats.
@@ -1467,14 +1484,14 @@ __global__ __launch_bounds__(256) void classify_bands_kernel(float *__restrict__
 }
 
 hipError_t launch_classify_midpoints(const int *loud, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, int *hits,
-                                     hipStream_t stream)
+                                     hipStream_t stream, bool full_records)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0) return hipSuccess;
     if (T <= 0 || T > 1024 || !trace || !hits) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(hits, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(classify_midpoints_kernel, dim3((unsigned)((n_clips + 3) / 4)), dim3(256), 0, stream, loud, n_clips, T, fs, labels, trace, hits);
+    hipLaunchKernelGGL(classify_midpoints_kernel, dim3((unsigned)((n_clips + 3) / 4)), dim3(256), 0, stream, loud, n_clips, T, fs, labels, trace, hits, full_records ? 1 : 0);
     return hipGetLastError();
 }
 

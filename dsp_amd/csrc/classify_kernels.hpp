@@ -82,8 +82,10 @@ hipError_t launch_spectrogram_flags(const float *y, long n_clips, int n, long st
 // `trace`, label 0 when there are none), then the band sums + rule from the frame_major 3000-7500 Hz map for the clips that
 // have midpoints (sxx_bp is overwritten with its dB map when it does not fit LDS).  `trace` is required (it carries the
 // midpoints); `hits` (1 + n_clips ints) is the work list between the two: hits[0] = clips with midpoints, then their numbers.
+// full_records = false: only what the band kernel reads (count + midpoints) is written, not the zero-filled remainder of the
+// 1 KB record (callers that return labels only).
 hipError_t launch_classify_midpoints(const int *loud, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, int *hits,
-                                     hipStream_t stream);
+                                     hipStream_t stream, bool full_records = true);
 // the thresholds of classify() the reference's variants differ in (dsp_classify_config): keep band of the normalised dB
 // map (classifier.cpp:67-68) and the rule middle < . && above > . && below > . (classifier.cpp:109)
 struct ClassifyRule { float keep_lo, keep_hi, middle_max, above_min, below_min; };
