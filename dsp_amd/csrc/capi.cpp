@@ -481,7 +481,7 @@ struct ClassifyCtx {
     float *d_mean_mp = nullptr;                            // [clip][T]: segment means of the 1000-3000 Hz output
     int *d_labels = nullptr, *d_hits = nullptr;            // d_hits: work list of clips with midpoints
     int *d_loud = nullptr;                                 // [clip][T]: time bins of the 1000-3000 Hz map above 70 dB
-    int *d_gate = nullptr;                                 // [clip][T]: 0 = the segment's energy rules a loud cell out (IIR kernel)
+    int *d_gate = nullptr;                                 // work list of the segments whose energy does not rule a loud cell out (IIR kernel)
     dsp::ClassifyTrace *d_trace = nullptr;
     long cap_clips = 0;
     int cap_n = 0;
@@ -572,7 +572,7 @@ int cls_reserve(long clips, int n, bool need_x)
     DSP_HIP(hipMalloc(&g_cls.d_ck_bp, (size_t)clips * T * 8 * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_ck_mp, (size_t)clips * T * 8 * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_loud, (size_t)clips * T * sizeof(int)));
-    DSP_HIP(hipMalloc(&g_cls.d_gate, (size_t)clips * T * sizeof(int)));
+    DSP_HIP(hipMalloc(&g_cls.d_gate, ((size_t)clips * T + 1) * sizeof(int)));      // work list of gated-in frames: count + frame numbers
     DSP_HIP(hipMalloc(&g_cls.d_mean_mp, (size_t)clips * T * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_labels, (size_t)clips * sizeof(int)));
     DSP_HIP(hipMalloc(&g_cls.d_hits, (size_t)(clips + 1) * sizeof(int)));

@@ -412,7 +412,7 @@ hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, cons
 __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride,
                                                         const IirCoef c_bp, const IirCoef c_mp, float *__restrict__ ck_bp,
                                                         float *__restrict__ ck_mp, float *__restrict__ means_mp,
-                                                        int *__restrict__ gate_mp, const SpecTables *__restrict__ tab, int vec_ok)
+                                                        int *__restrict__ want_mp, const SpecTables *__restrict__ tab, int vec_ok)
 {
     __shared__ float tin[2][64 * IIR_LD];
     __shared__ float vbuf[2][64 * IIR_LD];             // v tiles of the 1000-3000 Hz filter, [tile parity]
@@ -434,18 +434,19 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
     const bool gating = tab->gate_ok != 0;
     float ea_cur = 0.0f, eb_cur = 0.0f, ea_prev = 0.0f, eb_prev = 0.0f;
 
-    // x tiles travel HBM -> registers -> LDS, TWO tiles ahead of the recurrence (a tile is ~1 us of recurrence, an HBM load
-    // under a full-chip stream takes longer): register set P holds tile s + 1 while set Q's loads of tile s + 2 are in flight
+    // x tiles: the 128 recurrence threads load them (4 float4 each per full tile), one tile ahead in registers.  (Two tiles
+    // ahead in a second register set measured slower, 1.50 vs 1.34 ms per 49 152 clips: the kernel is bound by VALU issue --
+    // 17 + 17 + ~26 instructions per sample and clip --, not by the load latency.)
     constexpr int CH = IIR_TS / 4, NV = 64 * CH / 128;
-    float4 preA[NV], preB[NV];
-    auto issue = [&](int t0, float4 (&pre)[NV]) {
+    float4 pre[NV];
+    auto issue = [&](int t0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * 4;
             pre[k] = r < rows ? *reinterpret_cast<const float4 *>(x + (clip0 + r) * stride + t0 + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto commit = [&](float *dst, const float4 (&pre)[NV]) {
+    auto commit = [&](float *dst) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * 4;
@@ -461,25 +462,19 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
     };
     auto tile_cols = [&](int s) { const int t0 = s * IIR_TS; return n - t0 < IIR_TS ? n - t0 : IIR_TS; };
     auto fast = [&](int s) { return vec_ok && tile_cols(s) == IIR_TS; };
-    if (is_r) {                                                    // tile 0 into tin[0]; tiles 1 (set B) and 2 (set A) in flight
-        if (fast(0)) { issue(0, preA); commit(tin[0], preA); } else load_scalar(0, tile_cols(0), tin[0]);
-        if (n_tiles > 1 && fast(1)) issue(IIR_TS, preB);
-        if (n_tiles > 2 && fast(2)) issue(2 * IIR_TS, preA);
+    if (is_r) {                                                    // tile 0 into tin[0], tile 1 in flight
+        if (fast(0)) { issue(0); commit(tin[0]); } else load_scalar(0, tile_cols(0), tin[0]);
+        if (n_tiles > 1 && fast(1)) issue(IIR_TS);
     }
     __syncthreads();
 
     for (int s = 0; s <= n_tiles; ++s) {
         if (is_r) {
             if (s < n_tiles) {
-                // stage tile s + 1 for the next step from its register set, then reuse that set for tile s + 3
+                // stage x tile s+1 for the next step, start the loads of tile s+2
                 if (s + 1 < n_tiles) {
-                    if ((s + 1) & 1) {
-                        if (fast(s + 1)) commit(tin[1], preB); else load_scalar((s + 1) * IIR_TS, tile_cols(s + 1), tin[1]);
-                        if (s + 3 < n_tiles && fast(s + 3)) issue((s + 3) * IIR_TS, preB);
-                    } else {
-                        if (fast(s + 1)) commit(tin[0], preA); else load_scalar((s + 1) * IIR_TS, tile_cols(s + 1), tin[0]);
-                        if (s + 3 < n_tiles && fast(s + 3)) issue((s + 3) * IIR_TS, preA);
-                    }
+                    if (fast(s + 1)) commit(tin[(s + 1) & 1]); else load_scalar((s + 1) * IIR_TS, tile_cols(s + 1), tin[(s + 1) & 1]);
+                    if (s + 2 < n_tiles && fast(s + 2)) issue((s + 2) * IIR_TS);
                 }
                 // segment seg starts with this tile: its restart state is the delay line as it stands
                 const int seg = s / kTilesPerHop;
@@ -570,7 +565,9 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
                         const float e = ea_prev + 2.0f * fabsf(m) * fabsf(eb_prev) + m * m * tab->win2_sum;
                         g = e * tab->gate_scale >= tab->mp_keep_min ? 1 : 0;
                     }
-                    gate_mp[(clip0 + lane) * n_seg + seg_k - 1] = g;
+                    // work list of the flag spectrogram: want_mp[0] = count, then frame numbers clip * T + t, in any order
+                    // (hipcc turns the per-lane add into one atomic per wave)
+                    if (g) want_mp[1 + atomicAdd(want_mp, 1)] = (int)((clip0 + lane) * n_seg + seg_k - 1);
                 }
             } else if (lane < rows) {
                 for (int i = 0; i < cols; ++i) (void)taps(vin[lane * IIR_LD + i]);    // a short last tile lies past every whole segment
@@ -581,12 +578,18 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
 }
 
 hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
-                            float *ck_bp, float *ck_mp, float *means_mp, int *gate_mp, const SpecTables *tables, hipStream_t stream)
+                            float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream)
 {
     if (n_clips <= 0 || n <= 0) return hipSuccess;
+    {
+        const long n_seg = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
+        if (n_clips * n_seg >= (1L << 31)) return hipErrorInvalidValue;          // frame numbers are ints
+        hipError_t e = hipMemsetAsync(want_mp, 0, sizeof(int), stream);
+        if (e != hipSuccess) return e;
+    }
     const int blocks = (int)((n_clips + 63) / 64);
     const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
-    hipLaunchKernelGGL(iir2_ckpt_kernel, dim3(blocks), dim3(192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, means_mp, gate_mp,
+    hipLaunchKernelGGL(iir2_ckpt_kernel, dim3(blocks), dim3(192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, means_mp, want_mp,
                        tables, vec_ok);
     return hipGetLastError();
 }
@@ -935,7 +938,7 @@ struct SpecLane {                             // per-lane constants of the 256-p
 template <int OUT>
 __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void spec_from_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride, const IirCoef c,
                                                              const float *__restrict__ ck, const float *__restrict__ means,
-                                                             const int *__restrict__ gate, const int *__restrict__ hits,
+                                                             const int *__restrict__ wantlist, const int *__restrict__ hits,
                                                              const SpecTables *__restrict__ tab, float *__restrict__ out, int T, int vec_ok)
 {
     static_assert(OUT == SPEC_FLAGS || OUT == SPEC_FRAME_MAJOR, "flags or [time][bin]");
@@ -945,42 +948,50 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     __shared__ int sflag[64];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long total = (hits ? (long)hits[0] : n_clips) * T;
+    // frame slots of this launch: SPEC_FLAGS walks the work list of gated-in frames (wantlist[0] = count, then clip * T + t),
+    // SPEC_FRAME_MAJOR every time bin of the clips on `hits` (hits[0] = count, then clip numbers)
+    const long total = OUT == SPEC_FLAGS ? (long)wantlist[0] : (long)hits[0] * T;
     const long gid0 = (long)blockIdx.x * 64;
     if (gid0 >= total) return;
     // every wave's lane l describes frame slot gid0 + l
     const long gid = gid0 + lane;
-    const bool valid = gid < total;
+    const bool want = gid < total;
     long clip = 0;
     int t = 0;
-    if (valid) {
-        const long slotc = gid / T;
-        t = (int)(gid - slotc * T);
-        clip = hits ? (long)hits[1 + slotc] : slotc;
+    if (want) {
+        if (OUT == SPEC_FLAGS) {
+            const int fr = wantlist[1 + gid];
+            clip = fr / T;
+            t = fr - (int)clip * T;
+        } else {
+            const long slotc = gid / T;
+            t = (int)(gid - slotc * T);
+            clip = (long)hits[1 + slotc];
+        }
     }
-    const bool want = valid && (OUT != SPEC_FLAGS || gate[clip * T + t] != 0);
     const unsigned long long todo = __ballot(want);
-    if (todo == 0) {                                        // same decision in all four waves
-        if (OUT == SPEC_FLAGS && wib == 0 && valid) reinterpret_cast<int *>(out)[gid] = 0;
-        return;
-    }
     float *row = rows + lane * RC_ROW;
 
-    // ---- L: the wanted segments of x into the rows, all loads of the block in flight together (lane-per-frame loads in the
-    // recurrence loop would each pay an HBM round trip the serial arithmetic cannot cover)
+    // ---- L: the wanted segments of x into the rows.  Every load of the block is issued before the first LDS store (16
+    // float4 per thread in flight): loads inside the recurrence loop would each pay an HBM round trip that the serial
+    // arithmetic cannot cover.  One wave-instruction = one row = 1 KB contiguous.
     {
-        constexpr int PER_ROW = kSpecSeg / 4;                       // float4 pieces per segment: one wave-instruction = one row
-        for (int e = threadIdx.x; e < 64 * PER_ROW; e += RC_THREADS) {
-            const int r = e / PER_ROW, c4 = (e % PER_ROW) * 4;
-            if (!((todo >> r) & 1)) continue;
-            const unsigned lo = __builtin_amdgcn_readlane((unsigned)clip, r), hi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)clip >> 32), r);
-            const long rclip = (long)(((unsigned long long)hi << 32) | lo);
-            const float *xs = x + rclip * stride + (long)__builtin_amdgcn_readlane(t, r) * kSpecHop + c4;
-            float4 v4;
-            if (vec_ok) v4 = *reinterpret_cast<const float4 *>(xs);
-            else v4 = make_float4(xs[0], xs[1], xs[2], xs[3]);
+        constexpr int PER_ROW = kSpecSeg / 4, NL = 64 * PER_ROW / RC_THREADS;
+        float4 v4[NL];
+        const unsigned clip_lo = (unsigned)clip, clip_hi = (unsigned)((unsigned long long)clip >> 32);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = threadIdx.x + RC_THREADS * i, r = e / PER_ROW, c4 = (e % PER_ROW) * 4;      // r is wave-uniform
+            const long rclip = (long)(((unsigned long long)__builtin_amdgcn_readlane(clip_hi, r) << 32) | __builtin_amdgcn_readlane(clip_lo, r));
+            const float *xs = x + rclip * stride + (long)__builtin_amdgcn_readlane(t, r) * kSpecHop + c4;     // unwanted slots: clip 0, t 0
+            if (vec_ok) v4[i] = *reinterpret_cast<const float4 *>(xs);
+            else v4[i] = make_float4(xs[0], xs[1], xs[2], xs[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = threadIdx.x + RC_THREADS * i, r = e / PER_ROW, c4 = (e % PER_ROW) * 4;
             float *dst = rows + r * RC_ROW + 8 + c4;
-            dst[0] = v4.x; dst[1] = v4.y; dst[2] = v4.z; dst[3] = v4.w;
+            dst[0] = v4[i].x; dst[1] = v4[i].y; dst[2] = v4[i].z; dst[3] = v4[i].w;
         }
     }
     __syncthreads();
@@ -1101,24 +1112,27 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     }
     if (OUT == SPEC_FLAGS) {
         __syncthreads();
-        if (wib == 0 && valid) reinterpret_cast<int *>(out)[gid] = want ? sflag[lane] : 0;
+        if (wib == 0 && want) reinterpret_cast<int *>(out)[clip * T + t] = sflag[lane];      // the rest of loud[] was zeroed by the launcher
     }
 }
 
 hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
-                                 const int *gate, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream)
+                                 const int *wantlist, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0 || T <= 0) return hipSuccess;
-    const long total = n_clips * T;                       // with a work list: the bound; blocks past hits[0] * T exit at once
+    const long total = n_clips * T;                       // the bound: blocks past the list's count exit at once
     const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
     const dim3 grid((unsigned)((total + 63) / 64));
-    if (flags)
-        hipLaunchKernelGGL(spec_from_ckpt_kernel<SPEC_FLAGS>, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, gate,
+    if (flags) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)total * sizeof(int), stream);      // frames not on the list are not loud
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(spec_from_ckpt_kernel<SPEC_FLAGS>, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wantlist,
                            (const int *)nullptr, tables, out, T, vec_ok);
-    else
+    } else {
         hipLaunchKernelGGL(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR>, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means,
                            (const int *)nullptr, hits, tables, out, T, vec_ok);
+    }
     return hipGetLastError();
 }
 

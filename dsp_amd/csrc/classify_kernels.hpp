@@ -48,15 +48,16 @@ hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long strid
 
 // classify()'s form of a9: both recurrences in one pass over x, no filtered signal written.  Per clip and spectrogram segment
 // k (n_seg = (n-256)/224+1): ck_bp / ck_mp [c][k][8] = the filter's delay line v[224k-1 .. 224k-8] (restart state of the
-// segment), means_mp[c][k] = mean of the 1000-3000 Hz output over the segment (classifier.cpp:329-333), gate_mp[c][k] = 0 when
-// the segment's energy proves that no PSD cell reaches SpecTables::mp_keep_min.
+// segment), means_mp[c][k] = mean of the 1000-3000 Hz output over the segment (classifier.cpp:329-333), want_mp = work list
+// (want_mp[0] = count, then frame numbers c * n_seg + k, 1 + n_clips * n_seg ints) of the segments whose energy does NOT prove
+// that every PSD cell stays below SpecTables::mp_keep_min -- the only ones the flag spectrogram has to transform.
 hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
-                            float *ck_bp, float *ck_mp, float *means_mp, int *gate_mp, const SpecTables *tables, hipStream_t stream);
+                            float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream);
 // Spectrogram of segments recomputed from those checkpoints (filter c, checkpoints ck).  flags = true: out = int loud[c][T]
-// (1 = some cell >= mp_keep_min) for the segments with gate != 0, means = means_mp; flags = false: out = PSD [c][T][129] of
-// every segment of the clips on the work list `hits` (means computed here).
+// (1 = some cell >= mp_keep_min; 0 for every segment not on `wantlist`), means = means_mp; flags = false: out = PSD
+// [c][T][129] of every segment of the clips on the work list `hits` (means computed here).
 hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
-                                 const int *gate, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream);
+                                 const int *wantlist, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream);
 
 // sxx[c][129][T] (T = (n-256)/224+1) of clip rows y[c][0..n)
 struct ClassifyTrace {           // per clip, for parity tests

@@ -134,13 +134,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
     static_assert(!POOL || (TILE && CLIPS), "pooling lives in the tile epilogue of the clip-mode kernel");
     constexpr int KS = DCT_SPLIT == 2 ? DCT_LEN / 2 : DCT_LEN;    // MFMA k-steps (4 mel filters each)
     constexpr int CT = DCT_SPLIT == 2 ? 2 : 1;                    // 16-coefficient output tiles
-    constexpr int WAVE_BYTES = LDS_WAVE_BYTES + (TILE ? LDS_TILE_BYTES : 0);
+    constexpr int WAVE_BYTES = LDS_WAVE_BYTES + (TILE ? LDS_TILE_BYTES : 0) + (POOL ? LDS_POOL_BYTES : 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char *wl = smem + wib * WAVE_BYTES;
     float *etile = reinterpret_cast<float *>(wl + LDS_WAVE_BYTES);
-    (void)etile;
+    // POOL: the clip's running sums live in LDS between tiles (lane c: sum, sum of squares of coefficient c), not in four
+    // VGPRs for the whole kernel: the per-frame loop has no registers to spare at 128
+    double *pool_acc = reinterpret_cast<double *>(wl + LDS_WAVE_BYTES + LDS_TILE_BYTES);
+    (void)etile; (void)pool_acc;
     float2 *xchg = reinterpret_cast<float2 *>(wl + LDS_XCHG);
     float *pbuf = reinterpret_cast<float *>(wl + LDS_XCHG);
     float *part = reinterpret_cast<float *>(wl + LDS_PART);
@@ -240,11 +243,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
     if (fq[0] < 0) return;
 
     // ---- POOL: per-clip running sums of lane c's coefficient (float64, frames in order), the clip's end -------------
-    double pool_s = 0.0, pool_q = 0.0;
     int pool_t = 0;
+    if (POOL && lane < 32) { pool_acc[2 * lane] = 0.0; pool_acc[2 * lane + 1] = 0.0; }
     auto pool_tile = [&](const f4v (&d)[CT], int count) {
         // coefficients of the tile -> LDS as Dt[c][n] (the mel-energy tile has been consumed), then lane c adds its
         // row frame by frame: the same order of float64 additions as mfcc_stats (svm_kernels.hip / scrubjay_infer.c:36-66)
+        int lane = threadIdx.x & 63;                         // opaque copy: addresses formed here, not hoisted (see pool_finish)
+        asm volatile("" : "+v"(lane));
         const int n = lane & 15, q = lane >> 4;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -253,11 +258,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         wave_lds_sync();
         if (lane < n_mfcc) {
 #pragma clang fp contract(off)
+            double pool_s = pool_acc[2 * lane], pool_q = pool_acc[2 * lane + 1];
             for (int t = 0; t < count; ++t) {
                 const double v = (double)etile[lane * 16 + t];
                 pool_s = pool_s + v;
                 pool_q = pool_q + v * v;
             }
+            pool_acc[2 * lane] = pool_s; pool_acc[2 * lane + 1] = pool_q;
         }
         pool_t += count;
         wave_lds_sync();
@@ -266,7 +273,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 #pragma clang fp contract(off)
         const SvmModelDev &m = args.pool.svm;
         float *z = etile;                                    // 2 * n_mfcc standardised features
+        // once per clip: every per-lane address below is formed HERE from an opaque copy of the lane number, so that the
+        // compiler cannot hoist a dozen 64-bit addresses out of the frame loop and then spill them (it did: 12 VGPR spills)
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
         if (lane < n_mfcc) {
+            const double pool_s = pool_acc[2 * lane], pool_q = pool_acc[2 * lane + 1];
+            pool_acc[2 * lane] = 0.0; pool_acc[2 * lane + 1] = 0.0;
             const double mean = pool_s / (double)pool_t;
             const double var = pool_q / (double)pool_t - mean * mean;
             const float f_mean = (float)mean, f_std = sqrtf((float)(var > 0 ? var : 0));
@@ -298,16 +311,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
             if (args.pool.decision) args.pool.decision[clip] = score;
             if (args.pool.prob1) args.pool.prob1[clip] = p1;
         }
-        pool_s = 0.0; pool_q = 0.0; pool_t = 0;
+        pool_t = 0;
         wave_lds_sync();
     };
-    (void)pool_tile; (void)pool_finish; (void)pool_s; (void)pool_q; (void)pool_t;
+    (void)pool_tile; (void)pool_finish; (void)pool_t;
 
     // ---- 16-frame tile epilogue (TILE): log + DCT for the frames in slots [0, count) ----
     int slot = 0;               // frames in the tile
     long fb0 = 0, fb1 = 0;      // first frame of slots 0..7 / 8..15 (each half is 8 consecutive frames)
     auto flush = [&](int count) {
         wave_lds_sync();
+        int lane = threadIdx.x & 63;                         // POOL: opaque copy, the epilogue's addresses are formed here (see pool_finish)
+        if (POOL) asm volatile("" : "+v"(lane));
         const int n = lane & 15, q = lane >> 4;
         // reference shape: the tile column stays in registers between the max and the log passes; larger shapes
         // (more k-steps or two coefficient tiles) re-read it from LDS in a rolled loop instead of spilling
@@ -606,7 +621,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 // shapes of BASELINE configs 4 and 5; other frame lengths below 512 take the run-time predicate (FLEN = 0).
 #define DSP_FOR_SHAPES(X) X(4, 10, 3) X(4, 10, 6) X(4, 16, 3) X(4, 16, 6) X(2, 20, 3) X(2, 20, 6)
 
-static size_t lds_bytes(bool tile) { return (size_t)4 * (LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0)); }
+static size_t lds_bytes(bool tile, bool pool = false) { return (size_t)4 * (LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0) + (pool ? LDS_POOL_BYTES : 0)); }
 
 template <int S, int L, int G>
 constexpr bool kHas400 = (S == 4 && L == 10 && G == 3) || (S == 2 && L == 20 && G == 3);
@@ -639,7 +654,7 @@ hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_l
     if (args.frames_per_clip <= 0 || args.chunk != args.frames_per_clip || args.log_mode != 0 || args.in_kind != 0 || !args.pool.labels ||
         args.pool.svm.n_features != 2 * args.n_mfcc || args.pool.svm.n_features > 64)
         return hipErrorInvalidConfiguration;
-    const size_t lds = lds_bytes(true);
+    const size_t lds = lds_bytes(true, true);
     const dim3 g(blocks), b(256);
 #define DSP_LAUNCH_POOL(S, L, G)                                                                                            \
     if (dct_split == S && dct_len == L && gather == G) {                                                                    \
