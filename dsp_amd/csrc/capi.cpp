@@ -78,6 +78,8 @@ struct dsp_mfcc_plan {
     int resident_blocks_gen = 3;
     int gen_slots = 0;                            // mel chunk slots per lane the 1024-point tables use (<= 3: wave kernel)
     int resident_blocks_gen_wave = 2;
+    dsp::PrefilterScan *d_scan = nullptr;         // prefilter fused into the 1024-point wave kernel (full frames): its parallel form
+    int resident_blocks_gen_pre = 2;
     float *d_filtered = nullptr;                  // per-frame prefilter output (sub-batch)
     size_t filtered_cap = 0;
     float *d_frame_max = nullptr, *d_clip_floor = nullptr;   // DSP_LOG_GLOBAL_REF1 two-pass workspace
@@ -212,6 +214,16 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
     }
     if (gen) p->gen_slots = gen->n_chunk_slots;
     delete gen;
+    if (e == hipSuccess && cfg->n_fft == 1024 && cfg->prefilter != DSP_PREFILTER_NONE && cfg->frame_length == 1024 && p->gen_slots <= 3) {
+        // BASELINE config 3 in ONE pass: the per-frame Butterworth as a scan inside the MFCC kernel (tables.hpp PrefilterScan)
+        double b[9], a[9];
+        dsp_butter_bandpass(cfg->prefilter == DSP_PREFILTER_BUTTER_1000_3000 ? 1000 : 3000,
+                            cfg->prefilter == DSP_PREFILTER_BUTTER_1000_3000 ? 3000 : 7500, b, a);
+        dsp::PrefilterScan sc;
+        if (!dsp::build_prefilter_scan(b, a, sc, why)) { hipFree(p->d_tables); if (p->d_gen_tables) hipFree(p->d_gen_tables); delete p; return fail(DSP_EINVAL, why); }
+        e = hipMalloc(&p->d_scan, sizeof(sc));
+        if (e == hipSuccess) e = hipMemcpy(p->d_scan, &sc, sizeof(sc), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc(&p->d_row_tables, sizeof(dsp::RowTables512));
     if (e == hipSuccess && cfg->n_fft == 512) {
         auto *rt = new dsp::RowTables512;
@@ -236,6 +248,7 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
     } else {
         p->resident_blocks_gen = dsp::mfcc1024_blocks_per_cu(cfg->frame_length == 1024);
         p->resident_blocks_gen_wave = dsp::mfcc1024_wave_blocks_per_cu(cfg->frame_length == 1024);
+        if (p->d_scan) p->resident_blocks_gen_pre = dsp::mfcc1024_wave_blocks_per_cu(true, true);
     }
     if (const char *k = std::getenv("DSP_AMD_KERNEL")) {
         const int id = std::atoi(k);
@@ -252,6 +265,7 @@ void dsp_mfcc_plan_destroy(dsp_mfcc_plan *p)
     if (p->d_tables) hipFree(p->d_tables);
     if (p->d_row_tables) hipFree(p->d_row_tables);
     if (p->d_gen_tables) hipFree(p->d_gen_tables);
+    if (p->d_scan) hipFree(p->d_scan);
     if (p->d_filtered) hipFree(p->d_filtered);
     if (p->d_frame_max) hipFree(p->d_frame_max);
     if (p->d_clip_floor) hipFree(p->d_clip_floor);
@@ -292,7 +306,7 @@ static int reserve(float **buf, size_t *cap, size_t need)
 }
 
 static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, int frames_per_clip,
-               long clip_stride, void *stream, int in_kind = 0)
+               long clip_stride, void *stream, int in_kind = 0, bool fused_prefilter = false)
 {
     if (n_frames == 0) return DSP_OK;
     DSP_HIP(hipSetDevice(p->device));       // the caller's current device may be another GPU: tables and workspaces live on the plan's
@@ -332,7 +346,7 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     // extra block per CU would run as a second, mostly idle round: measured +14 %),
     // never more blocks than there are chunks of work
     const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu
-                       : (gen ? (gen_wave ? p->resident_blocks_gen_wave : p->resident_blocks_gen)
+                       : (gen ? (gen_wave ? (fused_prefilter ? p->resident_blocks_gen_pre : p->resident_blocks_gen_wave) : p->resident_blocks_gen)
                               : (row ? p->resident_blocks_row : (tile ? p->resident_blocks : p->resident_blocks_frame)));
     long blocks = (long)p->n_cu * per_cu;
     const long chunks = (n_frames + a.chunk - 1) / a.chunk;
@@ -357,8 +371,9 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
         DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream, false));
         return DSP_OK;
     }
+    if (fused_prefilter && !(gen_wave && p->d_scan)) return fail(DSP_EINVAL, "internal: fused prefilter without its tables");
     if (gen_wave)
-        DSP_HIP(dsp::launch_mfcc1024_wave(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream));
+        DSP_HIP(dsp::launch_mfcc1024_wave(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream, fused_prefilter ? p->d_scan : nullptr));
     else if (gen)
         DSP_HIP(dsp::launch_mfcc1024(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream));
     else if (row)
@@ -374,8 +389,14 @@ int dsp_mfcc_frames_device(dsp_mfcc_plan *p, const float *d_frames, long n_frame
     if (!p || n_frames < 0 || (n_frames > 0 && (!d_frames || !d_out))) return fail(DSP_EINVAL, "bad argument");
     if (p->cfg.prefilter == DSP_PREFILTER_NONE) return run(p, d_frames, d_out, n_frames, 0, 0, stream);
     // BASELINE config 3: 8th-order Butterworth (donut-classifier/classifier.c:420-446, float64) over each
-    // frame from zero state, rounded to float, then the MFCC chain.  Filtered frames go through a
-    // bounded workspace (sub-batches of <= 1 Mi frames) instead of a second full-size buffer.
+    // frame from zero state, rounded to float, then the MFCC chain.
+    // One pass (1024-sample frames on the wave kernel, 16-byte aligned input): the filter runs inside the MFCC kernel as a
+    // float64 parallel-form scan over the wave's lanes -- the frame is read once, nothing filtered is written.  This entry
+    // point is tolerance-gated (1e-4 of the frame's L-inf norm); the scan equals the serial recurrence to ~1e-13 before the
+    // rounding to float.  dsp_butter_bandpass_filter_* keep the bit-exact serial recurrence.
+    if (p->d_scan && p->kernel != DSP_KERNEL_ROW && (reinterpret_cast<uintptr_t>(d_frames) & 15) == 0 && !std::getenv("DSP_AMD_PREFILTER_TWO_PASS"))
+        return run(p, d_frames, d_out, n_frames, 0, 0, stream, 0, true);
+    // Otherwise two passes: filtered frames go through a bounded workspace (sub-batches of <= 1 Mi frames).
     std::lock_guard<std::recursive_mutex> lock(p->mu);
     DSP_HIP(hipSetDevice(p->device));
     const int fl = p->cfg.frame_length;

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mfcc_device.hpp"
+#include "tables.hpp"
 
 namespace dsp {
 
@@ -49,11 +50,81 @@ __device__ __forceinline__ void radix8w(c32 (&v)[8])
     v[3] = cadd(e[3], t3);   v[7] = csub(e[3], t3);
 }
 
+__device__ __forceinline__ double shfl_up_f64(double v, int byte_addr)
+{
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)bits), hi = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(bits >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+// Per-frame Butterworth prefilter (BASELINE config 3) on the wave that owns the frame: lane l holds samples [16 l, 16 l + 16).
+// Parallel form + scan over the lanes, float64 (PrefilterScan, tables.hpp); y = the filtered samples rounded to float, as
+// the two-pass path stores them.  ~500 v_fma_f64 per lane and frame, no HBM traffic.
+__device__ __forceinline__ void prefilter_scan(const float (&x)[kScanChunk], float (&y)[kScanChunk], const PrefilterScan *__restrict__ S, int lane)
+{
+    double t0[4], t1[4];
+    // pass 1: each section over the chunk from zero state -> the chunk's own contribution to the state at its end
+#pragma unroll
+    for (int sc = 0; sc < 4; ++sc) { t0[sc] = 0.0; t1[sc] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < kScanChunk; ++i) {
+        const double xi = (double)x[i];
+#pragma unroll
+        for (int sc = 0; sc < 4; ++sc) {
+            const double w0 = xi - S->a1[sc] * t0[sc] - S->a2[sc] * t1[sc];
+            t1[sc] = t0[sc];
+            t0[sc] = w0;
+        }
+    }
+    // inclusive scan: after step d lane l holds the contribution of chunks (l - 2^(d+1), l] to the state at the end of chunk l
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        const int from = ((lane - (1 << d)) & 63) << 2;
+        const bool on = lane >= (1 << d);
+#pragma unroll
+        for (int sc = 0; sc < 4; ++sc) {
+            const double u0 = shfl_up_f64(t0[sc], from), u1 = shfl_up_f64(t1[sc], from);
+            const double *m = S->pw[d][sc];
+            const double n0 = t0[sc] + m[0] * u0 + m[1] * u1, n1 = t1[sc] + m[2] * u0 + m[3] * u1;
+            t0[sc] = on ? n0 : t0[sc];
+            t1[sc] = on ? n1 : t1[sc];
+        }
+    }
+    // the state a chunk starts from is the scan value of the lane before it (zero for lane 0)
+    {
+        const int from = ((lane - 1) & 63) << 2;
+#pragma unroll
+        for (int sc = 0; sc < 4; ++sc) {
+            const double u0 = shfl_up_f64(t0[sc], from), u1 = shfl_up_f64(t1[sc], from);
+            t0[sc] = lane ? u0 : 0.0;
+            t1[sc] = lane ? u1 : 0.0;
+        }
+    }
+    // pass 2: the chunk again from its true state, with the output taps
+#pragma unroll
+    for (int i = 0; i < kScanChunk; ++i) {
+        const double xi = (double)x[i];
+        double acc = S->k0 * xi;
+#pragma unroll
+        for (int sc = 0; sc < 4; ++sc) {
+            const double w0 = xi - S->a1[sc] * t0[sc] - S->a2[sc] * t1[sc];
+            acc += S->b0[sc] * w0 + S->b1[sc] * t0[sc];
+            t1[sc] = t0[sc];
+            t0[sc] = w0;
+        }
+        y[i] = (float)acc;
+    }
+}
+
 }  // namespace
 
-template <bool FULL, bool CLIPS>
-__global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args args, const GenTables1024 *__restrict__ G)
+// PRE: independent full frames run through the Butterworth prefilter in this kernel (lane-contiguous loads, scan, one LDS
+// transpose into the FFT's sample order) instead of a separate pass that writes a filtered copy to HBM.
+template <bool FULL, bool CLIPS, bool PRE = false>
+__global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args args, const GenTables1024 *__restrict__ G,
+                                                            const PrefilterScan *__restrict__ S = nullptr)
 {
+    static_assert(!PRE || (FULL && !CLIPS), "the fused prefilter runs on independent 1024-sample frames");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -75,13 +146,17 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) twp[t] = {G->twp[2 * t][lane], G->twp[2 * t + 1][lane]};
+    // mel weights: in registers (36 VGPRs), except in the PRE variant, whose float64 scan needs the room: there they are
+    // re-read per frame (coalesced dwords, L1-resident 9 KB table)
     float melw[kWaveSlots][kMelChunk];
     int mel_k0[kWaveSlots];
 #pragma unroll
     for (int c = 0; c < kWaveSlots; ++c) {
         mel_k0[c] = G->mel_k0[c][lane];
+        if (!PRE) {
 #pragma unroll
-        for (int i = 0; i < kMelChunk; ++i) melw[c][i] = G->mel_w[c][i][lane];
+            for (int i = 0; i < kMelChunk; ++i) melw[c][i] = G->mel_w[c][i][lane];
+        }
     }
     int gat[kGenMelsPerLane][kGenGather];           // partial slots of filters lane and lane + 64 (slots >= 128 read the zero slot)
 #pragma unroll
@@ -107,6 +182,15 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
 
     auto load_frame8 = [&](long off, c32 (&z)[8]) {
         const float *src = static_cast<const float *>(args.in) + off;
+        if (PRE) {                       // lane l: samples [16 l, 16 l + 16), four 16-byte loads (the wave reads 4 KB contiguously)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(src + 16 * lane + 4 * a));
+                z[2 * a] = {x.x, x.y};
+                z[2 * a + 1] = {x.z, x.w};
+            }
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             const int i = 2 * (lane + 64 * a);
@@ -171,8 +255,26 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
     while (true) {
         const long f = f_next;
         c32 v[8];
+        if (PRE) {
+            float xs[kScanChunk], ys[kScanChunk];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) v[a] = {nxt[a].x * win[2 * a], nxt[a].y * win[2 * a + 1]};
+            for (int a = 0; a < 8; ++a) { xs[2 * a] = nxt[a].x; xs[2 * a + 1] = nxt[a].y; }
+            prefilter_scan(xs, ys, S, lane);
+            // filtered samples into the FFT's order: lane l takes the pairs (2 (l + 64 a), 2 (l + 64 a) + 1)
+            float *yb = reinterpret_cast<float *>(zbuf);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) *reinterpret_cast<float4 *>(yb + 16 * lane + 4 * a) = make_float4(ys[4 * a], ys[4 * a + 1], ys[4 * a + 2], ys[4 * a + 3]);
+            wave_lds_sync();
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const float2 q = zbuf[lane + 64 * a];
+                v[a] = {q.x * win[2 * a], q.y * win[2 * a + 1]};
+            }
+            wave_lds_sync();
+        } else {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) v[a] = {nxt[a].x * win[2 * a], nxt[a].y * win[2 * a + 1]};
+        }
         const bool more = pre.valid();
         if (more) { f_next = pre.f; load_frame8(pre.off, nxt); pre.next(); }
 
@@ -241,12 +343,14 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
         wave_lds_sync();
 
         // ---- sparse mel: two chunk slots per lane, weights in registers ---------------------------------------------
+        int wl_lane = lane;
+        if (PRE) asm volatile("" : "+v"(wl_lane));       // opaque per frame: the weight loads stay in the loop (not hoisted back into registers)
 #pragma unroll
         for (int c = 0; c < kWaveSlots; ++c) {
             const float *rd = pbuf + mel_k0[c];
             float acc = 0.0f;
 #pragma unroll
-            for (int i = 0; i < kMelChunk; ++i) acc = fmaf(melw[c][i], rd[i], acc);
+            for (int i = 0; i < kMelChunk; ++i) acc = fmaf(PRE ? G->mel_w[c][i][wl_lane] : melw[c][i], rd[i], acc);
             part[c * 64 + lane] = acc;
         }
         wave_lds_sync();
@@ -266,23 +370,33 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
     }
 }
 
-hipError_t launch_mfcc1024_wave(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream)
+hipError_t launch_mfcc1024_wave(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream, const PrefilterScan *scan)
 {
     const bool full = args.frame_len == 1024, clips = args.frames_per_clip > 0;
     if (args.chunk % 8 != 0) return hipErrorInvalidConfiguration;
     const size_t lds = (size_t)4 * W_WAVE_BYTES;
     const dim3 g(blocks), b(256);
-    if (full && !clips) hipLaunchKernelGGL((mfcc1024_wave_kernel<true, false>), g, b, lds, stream, args, tables);
-    else if (full) hipLaunchKernelGGL((mfcc1024_wave_kernel<true, true>), g, b, lds, stream, args, tables);
-    else if (!clips) hipLaunchKernelGGL((mfcc1024_wave_kernel<false, false>), g, b, lds, stream, args, tables);
-    else hipLaunchKernelGGL((mfcc1024_wave_kernel<false, true>), g, b, lds, stream, args, tables);
+    if (scan) {
+        if (!full || clips || (reinterpret_cast<uintptr_t>(args.in) & 15)) return hipErrorInvalidConfiguration;
+        hipLaunchKernelGGL((mfcc1024_wave_kernel<true, false, true>), g, b, lds, stream, args, tables, scan);
+        return hipGetLastError();
+    }
+    const PrefilterScan *none = nullptr;
+    if (full && !clips) hipLaunchKernelGGL((mfcc1024_wave_kernel<true, false>), g, b, lds, stream, args, tables, none);
+    else if (full) hipLaunchKernelGGL((mfcc1024_wave_kernel<true, true>), g, b, lds, stream, args, tables, none);
+    else if (!clips) hipLaunchKernelGGL((mfcc1024_wave_kernel<false, false>), g, b, lds, stream, args, tables, none);
+    else hipLaunchKernelGGL((mfcc1024_wave_kernel<false, true>), g, b, lds, stream, args, tables, none);
     return hipGetLastError();
 }
 
-int mfcc1024_wave_blocks_per_cu(bool full)
+int mfcc1024_wave_blocks_per_cu(bool full, bool prefilter)
 {
     int n = 0;
     const size_t lds = (size_t)4 * W_WAVE_BYTES;
+    if (prefilter) {
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc1024_wave_kernel<true, false, true>, 256, lds);
+        return e == hipSuccess && n > 0 ? n : 1;
+    }
     hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc1024_wave_kernel<true, false>, 256, lds)
                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc1024_wave_kernel<false, false>, 256, lds);
     return e == hipSuccess && n > 0 ? n : 2;

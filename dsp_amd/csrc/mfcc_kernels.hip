@@ -173,10 +173,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 #pragma unroll
     for (int g = 0; g < GATHER; ++g) gat[g] = T->mel_src[g][lane];
     float dctw[(DCT_LEN + 3) & ~3];
-    // the MFMA A operand stays in registers for the reference's shape (10 VGPRs); larger shapes
-    // re-read it (L1/L2-resident, once per 16 frames) to stay within 128 VGPRs = 4 waves/SIMD
+    // the MFMA A operand stays in registers for the reference's shape (10 VGPRs); larger shapes read it from a block-shared
+    // LDS copy (once per 16 frames; a global re-read sat latency-exposed in the rolled k loop) to stay within 128 VGPRs
     constexpr bool A_IN_REGS = CT * KS <= 10;
     float dcta[CT][KS];
+    float *a_lds = reinterpret_cast<float *>(smem + 4 * WAVE_BYTES);
+    (void)a_lds;
+    if (TILE && !A_IN_REGS) {
+        for (int i = threadIdx.x; i < CT * KS * 64; i += 256) a_lds[i] = (&T->dct_a[0][0][0])[(i / (KS * 64)) * (kDctSteps * 64) + i % (KS * 64)];
+        __syncthreads();
+    }
     if (TILE && A_IN_REGS) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
             if (4 * s + q >= n_mels) db = 0.0f;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const float a = A_IN_REGS ? dcta[ct][s < KS ? s : 0] : T->dct_a[ct][s][lane];
+                const float a = A_IN_REGS ? dcta[ct][s < KS ? s : 0] : a_lds[(ct * KS + s) * 64 + lane];
                 acc[ct][par] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, db, acc[ct][par], 0, 0, 0);
             }
         };
@@ -621,7 +627,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 // shapes of BASELINE configs 4 and 5; other frame lengths below 512 take the run-time predicate (FLEN = 0).
 #define DSP_FOR_SHAPES(X) X(4, 10, 3) X(4, 10, 6) X(4, 16, 3) X(4, 16, 6) X(2, 20, 3) X(2, 20, 6)
 
-static size_t lds_bytes(bool tile, bool pool = false) { return (size_t)4 * (LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0) + (pool ? LDS_POOL_BYTES : 0)); }
+// S, L: DCT_SPLIT, DCT_LEN of the instantiation (shapes whose MFMA A operand does not fit registers keep it in LDS)
+template <int S, int L>
+static size_t lds_bytes(bool tile, bool pool = false)
+{
+    constexpr int KS = S == 2 ? L / 2 : L, CT = S == 2 ? 2 : 1;
+    return (size_t)4 * (LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0) + (pool ? LDS_POOL_BYTES : 0)) + (tile && CT * KS > 10 ? (size_t)CT * KS * 64 * 4 : 0);
+}
 
 template <int S, int L, int G>
 constexpr bool kHas400 = (S == 4 && L == 10 && G == 3) || (S == 2 && L == 20 && G == 3);
@@ -640,7 +652,7 @@ static void launch_flen(const Mfcc512Args &args, bool clips, dim3 g, dim3 b, siz
 template <int S, int L, int G, int IN, int TILE>
 static hipError_t launch_one(const Mfcc512Args &args, bool clips, int blocks, hipStream_t stream)
 {
-    const size_t lds = lds_bytes(TILE);
+    const size_t lds = lds_bytes<S, L>(TILE);
     const dim3 g(blocks), b(256);
     const int flen = flen_of<S, L, G>(args.frame_len);
     if (flen == 512) launch_flen<S, L, G, 512, IN, TILE>(args, clips, g, b, lds, stream);
@@ -654,10 +666,10 @@ hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_l
     if (args.frames_per_clip <= 0 || args.chunk != args.frames_per_clip || args.log_mode != 0 || args.in_kind != 0 || !args.pool.labels ||
         args.pool.svm.n_features != 2 * args.n_mfcc || args.pool.svm.n_features > 64)
         return hipErrorInvalidConfiguration;
-    const size_t lds = lds_bytes(true, true);
     const dim3 g(blocks), b(256);
 #define DSP_LAUNCH_POOL(S, L, G)                                                                                            \
     if (dct_split == S && dct_len == L && gather == G) {                                                                    \
+        const size_t lds = lds_bytes<S, L>(true, true);                                                                     \
         const int flen = flen_of<S, L, G>(args.frame_len);                                                                  \
         if (flen == 512) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 512, 0, 1, true, true>), g, b, lds, stream, args); \
         else if (flen == 400) {                                                                                             \
@@ -710,13 +722,13 @@ hipError_t launch_clip_floor(const float *frame_max, long n_clips, int frames_pe
     return hipGetLastError();
 }
 
-int mfcc512_lds_bytes_per_block(bool tile) { return (int)lds_bytes(tile); }
+int mfcc512_lds_bytes_per_block(bool tile) { return (int)lds_bytes<4, 10>(tile); }
 
 template <int S, int L, int G, int TILE>
 static int occupancy_one(bool full)
 {
     int n = 0;
-    const size_t lds = lds_bytes(TILE);
+    const size_t lds = lds_bytes<S, L>(TILE);
     hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, 512, 0, TILE, false>, 256, lds)
                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_wave_kernel<S, L, G, 0, 0, TILE, false>, 256, lds);
     return e == hipSuccess && n > 0 ? n : 4;

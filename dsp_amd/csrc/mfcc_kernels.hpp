@@ -57,8 +57,11 @@ int mfcc512_row_blocks_per_cu(int dct_split, int dct_len, int gather, bool full)
 hipError_t launch_mfcc1024(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream);
 int mfcc1024_blocks_per_cu(bool full);
 // register-resident wave-per-frame form (mfcc1024_wave_kernel.hip): tables->n_chunk_slots <= 3, chunk % 8 == 0
-hipError_t launch_mfcc1024_wave(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream);
-int mfcc1024_wave_blocks_per_cu(bool full);
+struct PrefilterScan;   // tables.hpp
+// scan != nullptr: independent 1024-sample frames are band-pass filtered (PrefilterScan, tables.hpp) inside the kernel
+hipError_t launch_mfcc1024_wave(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream,
+                                const PrefilterScan *scan = nullptr);
+int mfcc1024_wave_blocks_per_cu(bool full, bool prefilter = false);
 int mfcc512_lds_bytes_per_block(bool tile);
 int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full, bool tile);
 

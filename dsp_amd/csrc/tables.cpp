@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstring>
 
 namespace dsp {
@@ -79,6 +80,97 @@ std::vector<float> make_dct_ortho(int n_mfcc, int n_mels)
             d[(size_t)k * n_mels + m] = (float)(s1 * (double)std::cos(arg));
         }
     return d;
+}
+
+// ---- prefilter in parallel form -------------------------------------------------------------------------------------
+bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &out, std::string &why)
+{
+    typedef std::complex<double> cd;
+    // poles: roots of z^8 + a1 z^7 + ... + a8 (a0 = 1), Durand-Kerner from points on a spiral, then Newton polish
+    cd z[8];
+    for (int k = 0; k < 8; ++k) z[k] = std::pow(cd(0.4, 0.9), k);
+    auto poly = [&](cd x) { cd v = a[0]; for (int k = 1; k <= 8; ++k) v = v * x + a[k]; return v; };
+    for (int it = 0; it < 400; ++it)
+        for (int i = 0; i < 8; ++i) {
+            cd den = 1.0;
+            for (int j = 0; j < 8; ++j) if (j != i) den *= z[i] - z[j];
+            z[i] -= poly(z[i]) / den;
+        }
+    for (int i = 0; i < 8; ++i) {
+        if (!(std::abs(poly(z[i])) < 1e-10) || !(std::abs(z[i]) < 1.0)) { why = "prefilter: pole search failed or filter unstable"; return false; }
+    }
+    out.k0 = b[8] / a[8];
+    int ns = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (!(z[i].imag() > 1e-9)) continue;                       // one of each conjugate pair (Butterworth band-pass: no real poles)
+        if (ns == 4) { why = "prefilter: more than four pole pairs"; return false; }
+        const cd p = z[i];
+        cd B = 0.0, pk = 1.0;                                       // B(1/p)
+        for (int k = 0; k <= 8; ++k) { B += b[k] * pk; pk /= p; }
+        cd den = 1.0;
+        for (int j = 0; j < 8; ++j) if (j != i) den *= 1.0 - z[j] / p;
+        const cd r = B / den;                                       // residue of r / (1 - p z^-1)
+        out.b0[ns] = 2.0 * r.real();
+        out.b1[ns] = -2.0 * (r * std::conj(p)).real();
+        out.a1[ns] = -2.0 * p.real();
+        out.a2[ns] = std::norm(p);
+        ++ns;
+    }
+    if (ns != 4) { why = "prefilter: expected four conjugate pole pairs"; return false; }
+    for (int sct = 0; sct < 4; ++sct) {
+        double m[4] = {-out.a1[sct], -out.a2[sct], 1.0, 0.0}, pwr[4] = {1.0, 0.0, 0.0, 1.0};
+        auto mul = [](const double (&x)[4], const double (&y)[4], double (&o)[4]) {
+            const double t[4] = {x[0] * y[0] + x[1] * y[2], x[0] * y[1] + x[1] * y[3], x[2] * y[0] + x[3] * y[2], x[2] * y[1] + x[3] * y[3]};
+            for (int k = 0; k < 4; ++k) o[k] = t[k];
+        };
+        for (int k = 0; k < kScanChunk; ++k) mul(pwr, m, pwr);      // M^16
+        for (int d = 0; d < 6; ++d) {
+            for (int k = 0; k < 4; ++k) out.pw[d][sct][k] = pwr[k];
+            mul(pwr, pwr, pwr);
+        }
+    }
+    // self-check against the direct-form-II recurrence (classifier.c:420-446) on 1024 pseudo-random samples
+    double x[1024], yref[1024], y[1024], w[8] = {0};
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    for (int n = 0; n < 1024; ++n) { st = st * 6364136223846793005ull + 1442695040888963407ull; x[n] = (double)(st >> 11) / 9007199254740992.0 * 2.0 - 1.0; }
+    for (int n = 0; n < 1024; ++n) {
+        double w0 = x[n];
+        for (int j = 1; j < 9; ++j) w0 -= a[j] * w[j - 1];
+        double yy = b[0] * w0;
+        for (int j = 1; j < 9; ++j) yy += b[j] * w[j - 1];
+        for (int j = 7; j > 0; --j) w[j] = w[j - 1];
+        w[0] = w0;
+        yref[n] = yy;
+    }
+    for (int n = 0; n < 1024; ++n) y[n] = out.k0 * x[n];
+    for (int sct = 0; sct < 4; ++sct) {
+        double T[64][2];
+        for (int l = 0; l < 64; ++l) {
+            double w1 = 0, w2 = 0;
+            for (int i = 0; i < kScanChunk; ++i) { const double w0 = x[16 * l + i] - out.a1[sct] * w1 - out.a2[sct] * w2; w2 = w1; w1 = w0; }
+            T[l][0] = w1; T[l][1] = w2;
+        }
+        for (int d = 0; d < 6; ++d) {
+            const double *m = out.pw[d][sct];
+            for (int l = 63; l >= (1 << d); --l) {
+                const double *u = T[l - (1 << d)];
+                T[l][0] += m[0] * u[0] + m[1] * u[1];
+                T[l][1] += m[2] * u[0] + m[3] * u[1];
+            }
+        }
+        for (int l = 0; l < 64; ++l) {
+            double w1 = l ? T[l - 1][0] : 0.0, w2 = l ? T[l - 1][1] : 0.0;
+            for (int i = 0; i < kScanChunk; ++i) {
+                const double w0 = x[16 * l + i] - out.a1[sct] * w1 - out.a2[sct] * w2;
+                y[16 * l + i] += out.b0[sct] * w0 + out.b1[sct] * w1;
+                w2 = w1; w1 = w0;
+            }
+        }
+    }
+    double err = 0, top = 0;
+    for (int n = 0; n < 1024; ++n) { err = std::max(err, std::fabs(y[n] - yref[n])); top = std::max(top, std::fabs(yref[n])); }
+    if (!(err <= 1e-10 * top)) { why = "prefilter: the parallel form does not reproduce the direct form"; return false; }
+    return true;
 }
 
 static void unit(double turns, float &c, float &s)

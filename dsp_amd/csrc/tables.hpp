@@ -104,6 +104,23 @@ struct GenTables1024 {
 constexpr int kGenZeroSlot = kGenChunks * kLanes;   // partial slot that always reads 0
 bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::string &why);
 
+// ---- per-frame Butterworth prefilter as a wave-parallel scan (BASELINE config 3 inside the 1024-point kernel) ----------
+// The 8th-order filter H(z) = B(z^-1) / A(z^-1) (donut-classifier/classifier.c:342-401) in PARALLEL FORM: a direct term
+// plus four second-order sections, one per conjugate pole pair,
+//     H = k0 + sum_s (b0_s + b1_s z^-1) / (1 + a1_s z^-1 + a2_s z^-2),
+// so that the filter state splits into four independent 2-vectors and a frame can be filtered by 64 lanes at once: lane l
+// runs samples [16 l, 16 l + 16) from zero state, a Kogge-Stone scan over the lanes carries the section states across the
+// chunk boundaries (state_out = M_s^16 state_in + local; step d multiplies by pw[d][s] = M_s^(16 * 2^d), M_s = [[-a1, -a2],
+// [1, 0]]), and the lane reruns its chunk from its true initial state.  float64 throughout; equals the direct-form-II
+// recurrence to ~1e-13 (checked at plan creation on 1024 random samples), i.e. to the last bit or so of the float result.
+struct PrefilterScan {
+    double k0;
+    double b0[4], b1[4], a1[4], a2[4];
+    double pw[6][4][4];            // [step][section][m00, m01, m10, m11]
+};
+constexpr int kScanChunk = 16;     // samples per lane: 64 lanes x 16 = one 1024-sample frame
+bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &out, std::string &why);
+
 // Fills `t`; returns false (with a message) when the configuration does not
 // fit this kernel's layout.
 bool build_lane_tables_512(const dsp_mfcc_config &cfg, LaneTables512 &t, std::string &why);

@@ -347,3 +347,35 @@ def test_pcm16_ingestion_matches_float_path(dsp, torch_cuda, golden):
     avg = 0.5 * (st[..., 0].float() / 32768.0 + st[..., 1].float() / 32768.0)
     assert torch.equal(plan.clips_pcm16(st, 500, stereo_mode=1), plan.clips(avg.contiguous(), 500))
     assert plan.clips_pcm16(pcm[:, :398].contiguous(), 500).shape[1] == 0
+
+
+def test_config3_fused_prefilter_equals_the_two_pass_path(dsp, torch_cuda, monkeypatch):
+    """BASELINE config 3 in one pass: the Butterworth prefilter as a float64 parallel-form scan inside the 1024-point kernel
+    (no filtered copy in HBM) against the two-pass path (serial direct-form-II kernel, then MFCC) and the oracle.  The scan
+    equals the serial recurrence to ~1e-13 before the rounding to float, so the two paths differ by float rounding of a few
+    filtered samples at most."""
+    from oracle import oracle as O
+    torch = torch_cuda
+    over = dict(n_fft=1024, frame_length=1024, hop_length=1024, n_mels=128)
+    for pre in (2, 1):
+        plan = dsp.MfccPlan(dsp.default_config(prefilter=pre, **over))
+        n = 777
+        fr = S.uniform_pm1(1024 * n, 9000 + pre).reshape(n, 1024)
+        fr[1] = 0.0
+        fr[2] *= np.float32(1e-4)
+        fr[3] = S.chirp(1024, 3500.0, 7000.0)
+        fr[4, 1:] = 0.0                                            # an impulse: the filter's impulse response
+        x = torch.from_numpy(fr).cuda()
+        fused = plan.frames(x).cpu().numpy()
+        monkeypatch.setenv("DSP_AMD_PREFILTER_TWO_PASS", "1")
+        two = plan.frames(x).cpu().numpy()
+        monkeypatch.delenv("DSP_AMD_PREFILTER_TWO_PASS")
+        assert not fused[1].any() and not two[1].any()
+        gate(fused, two, f"config3 fused vs two-pass, prefilter {pre}")
+        assert np.abs(fused - two).max() <= 2e-3
+        ref = O.mfcc_frames(fr, O.default_cfg(prefilter=pre, **over), threads=4)
+        gate(fused, ref, f"config3 fused vs oracle, prefilter {pre}")
+        # unaligned input falls back to the two-pass path and gives the same numbers as that path
+        y = torch.empty(1024 * n + 2, device="cuda")[2:].view(n, 1024)
+        y.copy_(x)
+        assert np.array_equal(plan.frames(y).cpu().numpy(), two)
