@@ -53,11 +53,12 @@ bool valid_cfg(const dsp_mfcc_config &c, std::string &why)
     if (!(c.amin > 0)) { why = "amin must be positive"; return false; }
     if (c.log_mode != DSP_LOG_PER_FRAME_MAX && c.log_mode != DSP_LOG_GLOBAL_REF1) { why = "unknown log_mode"; return false; }
     if (c.log_mode == DSP_LOG_GLOBAL_REF1 && c.n_fft != 512) { why = "DSP_LOG_GLOBAL_REF1 is implemented for n_fft = 512"; return false; }
+    if (c.prefilter != DSP_PREFILTER_NONE && c.n_fft == 2048) { why = "the per-frame prefilter is implemented for n_fft = 512 and 1024"; return false; }
     if (c.frame_length > c.n_fft) { why = "frame_length must not exceed n_fft"; return false; }
     if (c.win_length < 0 || c.win_length > c.frame_length) { why = "win_length must be in [0, frame_length]"; return false; }
     if (c.prefilter != DSP_PREFILTER_NONE && c.prefilter != DSP_PREFILTER_BUTTER_1000_3000 &&
         c.prefilter != DSP_PREFILTER_BUTTER_3000_7500) { why = "unknown prefilter"; return false; }
-    if (c.n_fft != 512 && c.n_fft != 1024) { why = "n_fft must be 512 or 1024"; return false; }
+    if (c.n_fft != 512 && c.n_fft != 1024 && c.n_fft != 2048) { why = "n_fft must be 512, 1024 or 2048"; return false; }
     return true;
 }
 
@@ -75,6 +76,8 @@ struct dsp_mfcc_plan {
     dsp::LaneTables512 *d_tables = nullptr;
     dsp::RowTables512 *d_row_tables = nullptr;
     dsp::GenTables1024 *d_gen_tables = nullptr;   // n_fft = 1024
+    dsp::GenTables2048 *d_tables2048 = nullptr;   // n_fft = 2048
+    int resident_blocks_2048 = 2;
     int resident_blocks_gen = 3;
     int gen_slots = 0;                            // mel chunk slots per lane the 1024-point tables use (<= 3: wave kernel)
     int resident_blocks_gen_wave = 2;
@@ -195,13 +198,17 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
     auto *p = new dsp_mfcc_plan;
     p->cfg = *cfg;
     dsp::GenTables1024 *gen = nullptr;
-    if (cfg->n_fft == 1024) {
+    dsp::GenTables2048 *g2k = nullptr;
+    if (cfg->n_fft == 2048) {
+        g2k = new dsp::GenTables2048;
+        if (!dsp::build_gen_tables_2048(*cfg, *g2k, why)) { delete g2k; delete p; return fail(DSP_EINVAL, why); }
+    } else if (cfg->n_fft == 1024) {
         gen = new dsp::GenTables1024;
         if (!dsp::build_gen_tables_1024(*cfg, *gen, why)) { delete gen; delete p; return fail(DSP_EINVAL, why); }
     } else if (!dsp::build_lane_tables_512(*cfg, p->host, why)) { delete p; return fail(DSP_EINVAL, why); }
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { delete gen; delete p; return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback"); }
-    if (device < 0 || device >= n) { delete gen; delete p; return fail(DSP_EINVAL, "device index out of range"); }
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { delete gen; delete g2k; delete p; return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback"); }
+    if (device < 0 || device >= n) { delete gen; delete g2k; delete p; return fail(DSP_EINVAL, "device index out of range"); }
     p->device = device;
     hipError_t e = hipSetDevice(device);
     hipDeviceProp_t prop;
@@ -212,6 +219,11 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
         e = hipMalloc(&p->d_gen_tables, sizeof(dsp::GenTables1024));
         if (e == hipSuccess) e = hipMemcpy(p->d_gen_tables, gen, sizeof(*gen), hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess && g2k) {
+        e = hipMalloc(&p->d_tables2048, sizeof(dsp::GenTables2048));
+        if (e == hipSuccess) e = hipMemcpy(p->d_tables2048, g2k, sizeof(*g2k), hipMemcpyHostToDevice);
+    }
+    delete g2k;
     if (gen) p->gen_slots = gen->n_chunk_slots;
     delete gen;
     if (e == hipSuccess && cfg->n_fft == 1024 && cfg->prefilter != DSP_PREFILTER_NONE && cfg->frame_length == 1024 && p->gen_slots <= 3) {
@@ -238,7 +250,9 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
         return fail(DSP_EHIP, std::string("plan_create: ") + hipGetErrorString(e));
     }
     p->n_cu = prop.multiProcessorCount;
-    if (cfg->n_fft == 512) {
+    if (cfg->n_fft == 2048) {
+        p->resident_blocks_2048 = dsp::mfcc2048_blocks_per_cu();
+    } else if (cfg->n_fft == 512) {
         p->resident_blocks_frame = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
                                                               cfg->frame_length == 512, false);
         p->resident_blocks = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
@@ -265,6 +279,7 @@ void dsp_mfcc_plan_destroy(dsp_mfcc_plan *p)
     if (p->d_tables) hipFree(p->d_tables);
     if (p->d_row_tables) hipFree(p->d_row_tables);
     if (p->d_gen_tables) hipFree(p->d_gen_tables);
+    if (p->d_tables2048) hipFree(p->d_tables2048);
     if (p->d_scan) hipFree(p->d_scan);
     if (p->d_filtered) hipFree(p->d_filtered);
     if (p->d_frame_max) hipFree(p->d_frame_max);
@@ -315,6 +330,17 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
         return fail(DSP_EINVAL, "input must be 8-byte aligned (4 for mono int16) with an even clip stride");
     if (in_kind != 0 && (p->cfg.n_fft != 512 || p->kernel != DSP_KERNEL_WAVE || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX))
         return fail(DSP_EINVAL, "PCM16 ingestion runs on the 512-point wave-per-frame kernel, per-frame log mode");
+    if (p->cfg.n_fft == 2048) {
+        dsp::Mfcc512Args a{};
+        a.in = d_in; a.out = d_out; a.n_frames = n_frames; a.clip_stride = clip_stride; a.frames_per_clip = frames_per_clip;
+        a.hop = p->cfg.hop_length; a.frame_len = p->cfg.frame_length; a.chunk = p->chunk > 0 ? p->chunk : 8;
+        a.n_mels = p->cfg.n_mels; a.n_mfcc = p->cfg.n_mfcc; a.amin = p->cfg.amin; a.top_db = p->cfg.top_db;
+        const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks_2048;
+        const long chunks = (n_frames + a.chunk - 1) / a.chunk;
+        const long blocks = std::max(1L, std::min((long)p->n_cu * per_cu, (chunks + 3) / 4));
+        DSP_HIP(dsp::launch_mfcc2048(a, p->d_tables2048, (int)blocks, (hipStream_t)stream, false));
+        return DSP_OK;
+    }
     dsp::Mfcc512Args a;
     a.in = d_in;
     a.in_kind = in_kind;
@@ -908,8 +934,9 @@ int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signa
                               void *stream)
 {
     if (!p || !s || n_clips < 0) return fail(DSP_EINVAL, "bad argument");
-    if (p->cfg.n_fft != 512 || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX || p->cfg.prefilter != DSP_PREFILTER_NONE || p->kernel != DSP_KERNEL_WAVE)
-        return fail(DSP_EINVAL, "the fused clip -> label path runs on the 512-point wave-per-frame kernel, per-frame log mode");
+    if ((p->cfg.n_fft != 512 && p->cfg.n_fft != 2048) || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX || p->cfg.prefilter != DSP_PREFILTER_NONE ||
+        p->kernel != DSP_KERNEL_WAVE)
+        return fail(DSP_EINVAL, "the fused clip -> label path runs on the 512- and 2048-point wave-per-frame kernels, per-frame log mode");
     if (s->m.n_features != 2 * p->cfg.n_mfcc || s->m.n_features > 64) return fail(DSP_EINVAL, "SVM n_features must equal 2 * n_mfcc (<= 64)");
     const int t = dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
     if (n_clips == 0) return 0;
@@ -940,6 +967,12 @@ int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signa
     a.pool.decision = d_decision;
     a.pool.prob1 = d_prob1;
     a.pool.feat = d_feat;
+    if (p->cfg.n_fft == 2048) {      // scrubjay_infer.c's own framing (WIN_SIZE 2048, HOP_SIZE 1024): mfcc2048_kernel<POOL>
+        const int per_cu2 = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks_2048;
+        const long blocks2 = std::max(1L, std::min((long)p->n_cu * per_cu2, (n_clips + 3) / 4));
+        DSP_HIP(dsp::launch_mfcc2048(a, p->d_tables2048, (int)blocks2, (hipStream_t)stream, true));
+        return t;
+    }
     const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks;
     long blocks = std::max(1L, std::min((long)p->n_cu * per_cu, (n_clips + 3) / 4));
     DSP_HIP(dsp::launch_mfcc512_pool(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));

@@ -1,0 +1,271 @@
+// mfcc2048_kernel.hip -- the MFCC chain at n_fft = 2048: the framing of the file north_star names, cepstrum/scrubjay_infer.c
+// (:10-14: WIN_SIZE 2048, HOP_SIZE 1024, N_FILTERS 40, N_MFCC 20; pooling :36-66; SVM :105-141).  Same chain as the other
+// kernels (reference 2fa/audio/word/c/mfcc.c:142-221 with the constants as parameters), one 64-lane wavefront per frame:
+//
+//   load      16 x global_load_dwordx2 per lane: z[l + 64 a] = x[2n] + i x[2n+1] (zero padded past frame_length), x window / 2
+//   FFT       2048-point real FFT as a 1024-point complex radix-4 Stockham autosort, 5 stages, 4 butterflies per lane and
+//             stage through an 8 KB per-wave LDS image, twiddles from a block-shared LDS table
+//   untangle  bins k = l + 64 t (t < 8) with 1024 - k; power spectrum P[0..1024] to LDS
+//   mel       one lane per filter (two for n_mels > 64) walks its run of non-zero weights in ascending bins
+//   log       per-frame reference = max, amin, top_db (mfcc.c:169-206)
+//   DCT-II    two lanes per coefficient (<= 32 coefficients), halves of the log-mel vector each
+//   POOL      instead of storing the coefficients: per-clip mean | std in float64, frame order (scrubjay_infer.c:36-66), then
+//             Scaler -> RBF-SVM -> libsvm's label / probability (svm_kernels.hpp), one wavefront walks one clip
+//
+// Generality first: this shape exists so that the fused clip -> label path can run scrubjay_infer.c's own parameterisation;
+// the tuned kernels are the 512- and 1024-point ones.
+#include <hip/hip_runtime.h>
+
+#include "mfcc_device.hpp"
+#include "svm_kernels.hpp"
+#include "tables.hpp"
+
+namespace dsp {
+
+namespace {
+
+constexpr int Q_ZBUF = 0;                          // 1025 x float2 image (Z[1024] = Z[0]); later P[0..1024]
+constexpr int Q_LMEL = 1025 * 8 + 8;               // 128 log-mel values
+constexpr int Q_FEAT = Q_LMEL + 128 * 4;           // POOL: 64 standardised features
+constexpr int Q_WAVE_BYTES = Q_FEAT + 64 * 4;
+static_assert(Q_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
+constexpr int Q_W1024 = 4 * Q_WAVE_BYTES;          // block-shared: W1024^i, i < 1024
+constexpr int Q_W2048 = Q_W1024 + 1024 * 8;        // block-shared: W2048^k, k < 512
+constexpr int Q_BLOCK_BYTES = Q_W2048 + 512 * 8;
+
+}  // namespace
+
+template <bool CLIPS, bool POOL>
+__global__ __launch_bounds__(256) void mfcc2048_kernel(const Mfcc512Args args, const GenTables2048 *__restrict__ G)
+{
+    static_assert(!POOL || CLIPS, "pooling is per clip");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char *wl = smem + wib * Q_WAVE_BYTES;
+    float2 *zbuf = reinterpret_cast<float2 *>(wl + Q_ZBUF);
+    float *pbuf = reinterpret_cast<float *>(wl + Q_ZBUF);
+    float *lmel = reinterpret_cast<float *>(wl + Q_LMEL);
+    float *feat = reinterpret_cast<float *>(wl + Q_FEAT);
+    float2 *w1024 = reinterpret_cast<float2 *>(smem + Q_W1024);
+    float2 *w2048 = reinterpret_cast<float2 *>(smem + Q_W2048);
+    for (int i = threadIdx.x; i < 1024; i += 256) w1024[i] = make_float2(G->w1024[0][i], G->w1024[1][i]);
+    for (int i = threadIdx.x; i < 512; i += 256) w2048[i] = make_float2(G->w2048[0][i], G->w2048[1][i]);
+    __syncthreads();
+
+    const int n_mels = args.n_mels, n_mfcc = args.n_mfcc;
+    const long wave = (long)blockIdx.x * 4 + wib;
+    const long n_waves = (long)gridDim.x * 4;
+    const unsigned amin_u = __float_as_uint(args.amin);
+    const float neg_top_db = -args.top_db;
+    const int frame_len = args.frame_len;
+    (void)feat;
+
+    WaveCursor<CLIPS> cur;
+    cur.init(wave, n_waves, args.chunk, args.n_frames, args.frames_per_clip, CLIPS ? args.hop : frame_len, args.clip_stride);
+    if (!cur.valid()) return;
+
+    // POOL: lane 2 c keeps the running sums of coefficient c for the clip this wave is walking
+    double pool_s = 0.0, pool_q = 0.0;
+    int pool_t = 0;
+    (void)pool_s; (void)pool_q; (void)pool_t;
+
+    while (cur.valid()) {
+        const long f = cur.f, clip_f = cur.clip;
+        const bool last_of_chunk = cur.left == 0 || cur.remaining == 1;
+        (void)clip_f; (void)last_of_chunk;
+        const float *src = static_cast<const float *>(args.in) + cur.off;
+        cur.next();
+
+        // ---- load + window: v[a] = z[lane + 64 a] --------------------------------------------------------------------
+        c32 v[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const int i = 2 * (lane + 64 * a);
+            float x0 = 0.0f, x1 = 0.0f;
+            if (i + 1 < frame_len) {
+                const f2v x = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));
+                x0 = x.x; x1 = x.y;
+            } else if (i < frame_len) {
+                x0 = src[i];
+            }
+            v[a] = {x0 * G->win[2 * a][lane], x1 * G->win[2 * a + 1][lane]};
+        }
+
+        // ---- 1024-point complex FFT: radix-4 Stockham, 5 stages ----------------------------------------------------------
+        // stage s (Ns = 4^s), butterfly j = lane + 64 m: k = j % Ns; inputs x[j + 256 t] W_{4 Ns}^(t k); outputs y[(j - k) 4 + k + q Ns]
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int Ns = 1 << (2 * s);
+            if (s > 0) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float2 x = zbuf[lane + 64 * m + 256 * t];
+                        v[m + 4 * t] = {x.x, x.y};
+                    }
+                wave_lds_sync();
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int j = lane + 64 * m, k = j & (Ns - 1);
+                c32 u[4] = {v[m], v[m + 4], v[m + 8], v[m + 12]};
+                if (s > 0) {
+#pragma unroll
+                    for (int t = 1; t < 4; ++t) {
+                        const float2 w = w1024[(t * k * (256 / Ns)) & 1023];
+                        u[t] = cmul(u[t], c32{w.x, w.y});
+                    }
+                }
+                radix4(u);
+                const int j0 = (j - k) * 4 + k;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zbuf[j0 + q * Ns] = make_float2(u[q].x, u[q].y);
+            }
+            wave_lds_sync();
+        }
+        if (lane == 0) zbuf[1024] = zbuf[0];                 // natural order now; Z[1024] = Z[0] for the pairing below
+        wave_lds_sync();
+
+        // ---- untangle: bins k = l + 64 t (t < 8) with 1024 - k; bin 512 alone -------------------------------------------------
+        float P[16];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int k = lane + 64 * t;
+            const float2 a = zbuf[k], b = zbuf[1024 - k], w = w2048[k];
+            const c32 E = {a.x + b.x, a.y - b.y};
+            const c32 O = {a.x - b.x, a.y + b.y};
+            const c32 Tw = cmul(O, c32{w.x, w.y});
+            const float xr = E.x + Tw.y, xi = E.y - Tw.x;
+            const float mr = E.x - Tw.y, mi = E.y + Tw.x;
+            P[2 * t] = xr * xr + xi * xi;
+            P[2 * t + 1] = mr * mr + mi * mi;
+        }
+        const float2 zm = zbuf[512];
+        wave_lds_sync();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            pbuf[lane + 64 * t] = P[2 * t];
+            pbuf[1024 - lane - 64 * t] = P[2 * t + 1];
+        }
+        if (lane == 0) pbuf[512] = 4.0f * (zm.x * zm.x + zm.y * zm.y);
+        wave_lds_sync();
+
+        // ---- mel: lane m (and m + 64) walks filter m's run of weights in ascending bins (mfcc.c:158-164) --------------------
+        float e[2];
+        float emax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = lane + 64 * i;
+            float acc = 0.0f;
+            if (m < n_mels) {
+                const int lo = G->mel_lo[m], len = G->mel_len[m];
+                const float *w = G->mel_w + G->mel_off[m];
+                for (int k = 0; k < len; ++k) acc = fmaf(w[k], pbuf[lo + k], acc);
+            }
+            e[i] = acc;
+            emax = fmaxf(emax, acc);
+        }
+        // ---- 10 log10 with per-frame reference (mfcc.c:169-206), one log of the ratio --------------------------------------
+        const float ref = __uint_as_float(max(__float_as_uint(wave_max_nonneg(emax)), amin_u));
+        const float inv = __builtin_amdgcn_rcpf(ref);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float ec = __uint_as_float(max(__float_as_uint(e[i]), amin_u));
+            float db = 3.01029995663981195f * __builtin_amdgcn_logf(ec * inv);
+            db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f);
+            lmel[lane + 64 * i] = (lane + 64 * i < n_mels) ? db : 0.0f;
+        }
+        wave_lds_sync();
+
+        // ---- DCT-II: lane 2 c + h dots log-mels [64 h, 64 h + 64) with row c ---------------------------------------------------
+        float coef;
+        {
+            const int c = lane >> 1, h = lane & 1;
+            float acc = 0.0f;
+            if (c < n_mfcc) {
+                const float *row = &G->dct[c][64 * h];
+                const int cnt = n_mels - 64 * h < 64 ? n_mels - 64 * h : 64;
+                for (int m = 0; m < cnt; ++m) acc = fmaf(row[m], lmel[64 * h + m], acc);
+            }
+            acc += dpp<DPP_QUAD_1032>(acc);
+            coef = acc;
+            if (!POOL && h == 0 && c < n_mfcc) args.out[f * n_mfcc + c] = acc;
+        }
+        wave_lds_sync();
+
+        if (POOL) {
+            // scrubjay_infer.c:36-66: float64 sums in frame order (the clip's frames are consecutive on this wave)
+#pragma clang fp contract(off)
+            const int c = lane >> 1;
+            const double cv = (double)coef;
+            pool_s = pool_s + cv;
+            pool_q = pool_q + cv * cv;
+            ++pool_t;
+            if (last_of_chunk) {
+                const SvmModelDev &sm = args.pool.svm;
+                if ((lane & 1) == 0 && c < n_mfcc) {
+                    const double mean = pool_s / (double)pool_t;
+                    const double var = pool_q / (double)pool_t - mean * mean;
+                    const float f_mean = (float)mean, f_std = sqrtf((float)(var > 0 ? var : 0));
+                    if (args.pool.feat) {
+                        args.pool.feat[clip_f * 2L * n_mfcc + c] = f_mean;
+                        args.pool.feat[clip_f * 2L * n_mfcc + n_mfcc + c] = f_std;
+                    }
+                    feat[c] = (f_mean - sm.offset[c]) * sm.scale[c];
+                    feat[n_mfcc + c] = (f_std - sm.offset[n_mfcc + c]) * sm.scale[n_mfcc + c];
+                }
+                wave_lds_sync();
+                float term = 0.0f;                               // same arithmetic as svm_kernel (svm_kernels.hip)
+                for (int sidx = lane; sidx < sm.n_sv; sidx += 64) {
+                    const float *sv = sm.sv + (long)sidx * sm.n_features;
+                    float d2 = 0.0f;
+                    for (int j = 0; j < sm.n_features; ++j) {
+                        const float dd = feat[j] - sv[j];
+                        d2 = d2 + dd * dd;
+                    }
+                    term = term + sm.coef[sidx] * expf(-sm.gamma * d2);
+                }
+                for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o);
+                if (lane == 0) {
+                    const float score = term + sm.rho;
+                    int label;
+                    float p1;
+                    svm_binary_tail(score, sm.prob_a, sm.prob_b, label, p1);
+                    args.pool.labels[clip_f] = label;
+                    if (args.pool.decision) args.pool.decision[clip_f] = score;
+                    if (args.pool.prob1) args.pool.prob1[clip_f] = p1;
+                }
+                pool_s = 0.0; pool_q = 0.0; pool_t = 0;
+                wave_lds_sync();
+            }
+        }
+    }
+}
+
+hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables, int blocks, hipStream_t stream, bool pool)
+{
+    const bool clips = args.frames_per_clip > 0;
+    const dim3 g(blocks), b(256);
+    if (pool) {
+        if (!clips || args.chunk != args.frames_per_clip || !args.pool.labels || args.pool.svm.n_features != 2 * args.n_mfcc ||
+            args.pool.svm.n_features > 64)
+            return hipErrorInvalidConfiguration;
+        hipLaunchKernelGGL((mfcc2048_kernel<true, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+    } else if (clips) {
+        hipLaunchKernelGGL((mfcc2048_kernel<true, false>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+    } else {
+        hipLaunchKernelGGL((mfcc2048_kernel<false, false>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+    }
+    return hipGetLastError();
+}
+
+int mfcc2048_blocks_per_cu()
+{
+    int n = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<false, false>, 256, Q_BLOCK_BYTES);
+    return e == hipSuccess && n > 0 ? n : 2;
+}
+
+}  // namespace dsp

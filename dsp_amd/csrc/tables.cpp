@@ -82,6 +82,57 @@ std::vector<float> make_dct_ortho(int n_mfcc, int n_mels)
     return d;
 }
 
+static void unit(double turns, float &c, float &s)
+{
+    // exp(-2*pi*i*turns), evaluated in float64
+    c = (float)std::cos(-2.0 * kPi * turns);
+    s = (float)std::sin(-2.0 * kPi * turns);
+}
+
+bool build_gen_tables_2048(const dsp_mfcc_config &cfg, GenTables2048 &t, std::string &why)
+{
+    std::memset(&t, 0, sizeof(t));
+    const int n_fft = 2048, n_bins = 1025;
+    if (cfg.n_fft != n_fft) { why = "n_fft must be 2048 for this kernel"; return false; }
+    if (cfg.frame_length < 2 || cfg.frame_length > n_fft) { why = "frame_length must be in [2, n_fft]"; return false; }
+    if (cfg.n_mels < 1 || cfg.n_mels > k2048MaxMels) { why = "n_mels must be in [1, 128] for n_fft = 2048"; return false; }
+    if (cfg.n_mfcc < 1 || cfg.n_mfcc > k2048MaxMfcc) { why = "n_mfcc must be in [1, 32] for n_fft = 2048"; return false; }
+    if (cfg.log_mode != DSP_LOG_PER_FRAME_MAX) { why = "n_fft = 2048 runs the per-frame log mode"; return false; }
+    if (cfg.prefilter != DSP_PREFILTER_NONE) { why = "the per-frame prefilter is implemented for n_fft = 512 and 1024"; return false; }
+    t.n_mels = cfg.n_mels;
+    t.n_mfcc = cfg.n_mfcc;
+    std::vector<float> win = make_frame_window(cfg);
+    win.resize(n_fft, 0.0f);
+    for (int l = 0; l < kLanes; ++l)
+        for (int a = 0; a < 16; ++a) {
+            const int n = l + 64 * a;
+            t.win[2 * a][l] = 0.5f * win[2 * n];
+            t.win[2 * a + 1][l] = 0.5f * win[2 * n + 1];
+        }
+    for (int i = 0; i < 1024; ++i) unit((double)i / 1024.0, t.w1024[0][i], t.w1024[1][i]);
+    for (int k = 0; k < 512; ++k) unit((double)k / 2048.0, t.w2048[0][k], t.w2048[1][k]);
+    const std::vector<float> fb = make_mel_filterbank(cfg.sample_rate, n_fft, cfg.n_mels, cfg.fmin, cfg.fmax, cfg.mel_norm);
+    int off = 0;
+    for (int m = 0; m < cfg.n_mels; ++m) {
+        const float *row = &fb[(size_t)m * n_bins];
+        int first = -1, last = -1;
+        for (int k = 0; k < n_bins; ++k)
+            if (row[k] != 0.0f) { if (first < 0) first = k; last = k; }
+        t.mel_off[m] = off;
+        if (first < 0) { t.mel_lo[m] = 0; t.mel_len[m] = 0; continue; }
+        const int len = last - first + 1;
+        if (off + len > k2048MaxWeights) { why = "mel filterbank has too many non-zero weights for the 2048-point kernel"; return false; }
+        t.mel_lo[m] = first;
+        t.mel_len[m] = len;
+        for (int k = 0; k < len; ++k) t.mel_w[off + k] = row[first + k];       // ascending bins, the reference's summation order (mfcc.c:158-164)
+        off += len;
+    }
+    const std::vector<float> dct = make_dct_ortho(cfg.n_mfcc, cfg.n_mels);
+    for (int c = 0; c < cfg.n_mfcc; ++c)
+        for (int m = 0; m < cfg.n_mels; ++m) t.dct[c][m] = dct[(size_t)c * cfg.n_mels + m];
+    return true;
+}
+
 // ---- prefilter in parallel form -------------------------------------------------------------------------------------
 bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &out, std::string &why)
 {
@@ -173,12 +224,6 @@ bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &o
     return true;
 }
 
-static void unit(double turns, float &c, float &s)
-{
-    // exp(-2*pi*i*turns), evaluated in float64
-    c = (float)std::cos(-2.0 * kPi * turns);
-    s = (float)std::sin(-2.0 * kPi * turns);
-}
 
 bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::string &why)
 {

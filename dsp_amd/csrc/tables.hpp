@@ -104,6 +104,21 @@ struct GenTables1024 {
 constexpr int kGenZeroSlot = kGenChunks * kLanes;   // partial slot that always reads 0
 bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::string &why);
 
+// ---- n_fft = 2048 (the framing of cepstrum/scrubjay_infer.c:10-14: WIN_SIZE 2048, HOP_SIZE 1024, 40 filters, 20 coefficients)
+// Tables of mfcc2048_kernel.hip: window per lane, twiddle tables, the mel filterbank as one run of non-zero weights per filter
+// (CSR), the DCT rows.
+constexpr int k2048MaxMels = 128, k2048MaxMfcc = 32, k2048MaxWeights = 4096;
+struct GenTables2048 {
+    float win[32][kLanes];                 // x0.5 window for samples 2(l+64a), 2(l+64a)+1 at [2a], [2a+1], a < 16
+    float w1024[2][1024];                  // W1024^i (cos, sin): stage twiddles of the 1024-point complex FFT
+    float w2048[2][512];                   // W2048^k (cos, sin), k < 512: untangling the packed real transform
+    int32_t mel_lo[k2048MaxMels], mel_len[k2048MaxMels], mel_off[k2048MaxMels];   // filter m: bins [lo, lo+len), weights at mel_w[off ..]
+    float mel_w[k2048MaxWeights];
+    float dct[k2048MaxMfcc][k2048MaxMels]; // DCT-II rows
+    int32_t n_mels, n_mfcc;
+};
+bool build_gen_tables_2048(const dsp_mfcc_config &cfg, GenTables2048 &t, std::string &why);
+
 // ---- per-frame Butterworth prefilter as a wave-parallel scan (BASELINE config 3 inside the 1024-point kernel) ----------
 // The 8th-order filter H(z) = B(z^-1) / A(z^-1) (donut-classifier/classifier.c:342-401) in PARALLEL FORM: a direct term
 // plus four second-order sections, one per conjugate pole pair,

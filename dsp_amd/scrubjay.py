@@ -69,11 +69,20 @@ def mfcc_stats(mfcc):
     return feat
 
 
+def scrubjay_infer_config(sample_rate: int = 16000):
+    """The framing cepstrum/scrubjay_infer.c itself uses (:10-14): WIN_SIZE 2048, HOP_SIZE 1024, N_FILTERS 40, N_MFCC 20 at the
+    file's sample rate, mel band up to Nyquist.  (aubio's own filterbank / scaling details are not vendored: unpinned.)"""
+    return default_config(sample_rate=sample_rate, n_fft=2048, frame_length=2048, hop_length=1024, n_mels=40, n_mfcc=20,
+                          fmin=0.0, fmax=sample_rate / 2.0)
+
+
 class ScrubJay:
     """clips -> label / probability, the scrubjay_infer.c main loop (:158-177) for a batch in HBM."""
 
-    def __init__(self, svm_attrs: dict, device: int = 0, n_mfcc: int = 20):
-        self.plan = MfccPlan(default_config(n_mfcc=n_mfcc), device)
+    def __init__(self, svm_attrs: dict, device: int = 0, n_mfcc: int = 20, config=None):
+        """config: an MfccConfig (its n_mfcc must be half the SVM's feature count), e.g. scrubjay_infer_config();
+        default: the reference's 512-point keyword front end with n_mfcc coefficients (BASELINE config 5)."""
+        self.plan = MfccPlan(config if config is not None else default_config(n_mfcc=n_mfcc), device)
         self.svm = SvmModel(svm_attrs, device)
 
     def __call__(self, clips, max_frames: int = 1 << 20, fused: bool = True):

@@ -73,7 +73,7 @@ enum { DSP_PREFILTER_NONE = 0, DSP_PREFILTER_BUTTER_1000_3000 = 1, DSP_PREFILTER
  * turned into a POD; dsp_mfcc_default_config() fills in the reference values. */
 typedef struct dsp_mfcc_config {
     int sample_rate;  /* 16000 */
-    int n_fft;        /* 512   (supported: 512 and 1024, one wavefront per frame) */
+    int n_fft;        /* 512   (supported: 512, 1024, 2048; one wavefront per frame)  */
     int frame_length; /* 400   (<= n_fft) */
     int hop_length;   /* 160 */
     int n_mels;       /* 40 */
@@ -225,15 +225,19 @@ int dsp_svm_create(int device, int n_features, int n_sv, const float *offset, co
                    const float *support_vectors, const float *coefficients, float gamma, float rho,
                    float prob_a, float prob_b, dsp_svm **out);
 void dsp_svm_destroy(dsp_svm *svm);
-/* labels (0/1), decision values and P(label 1) for n_clips feature rows; HBM pointers,
- * d_decision / d_prob1 may be NULL.                                               */
+/* labels, decision values and P(label 1) for n_clips feature rows; HBM pointers, d_decision / d_prob1 may be NULL.
+ * libsvm's rules (sklearn's SVC is libsvm; pinned by tests/golden/svm_libsvm_ref.npz): decision = sum_i coef_i K(x, sv_i) +
+ * rho; label = the pairwise vote, decision > 0 -> class 0 else class 1 (what .predict returns in cepstrum/run.py, and ONNX
+ * Runtime's output_label in SVC mode); P(label 1) from svm_predict_probability (Platt pair -> multiclass_probability's
+ * iteration, which is NOT the plain sigmoid: exactly 0.5 in a dead zone around decision = 0).                      */
 int dsp_svm_predict_device(dsp_svm *svm, const float *d_feat, long n_clips, int *d_labels, float *d_decision,
                            float *d_prob1, void *stream);
 
 /* BASELINE config 5 in ONE kernel: clip -> MFCC(n_mfcc) -> mean | std -> Scaler -> RBF-SVM -> label, the MFCC
  * matrix never leaves the chip (one wavefront walks one clip; pooling in the kernel's tile epilogue).  The plan's
  * 2 * n_mfcc must equal the SVM's n_features (<= 64); equal results to dsp_mfcc_clips_device +
- * dsp_mfcc_stats_device + dsp_svm_predict_device.  d_decision, d_prob1, d_feat ([n_clips][2 n_mfcc]) may be NULL. */
+ * dsp_mfcc_stats_device + dsp_svm_predict_device.  Plans with n_fft = 512 (BASELINE config 5) or n_fft = 2048 (the framing
+ * of scrubjay_infer.c:10-14 itself: 2048 / 1024 / 40 filters / 20 coefficients).  d_decision, d_prob1, d_feat ([n_clips][2 n_mfcc]) may be NULL. */
 int dsp_scrubjay_fused_device(dsp_mfcc_plan *plan, dsp_svm *svm, const float *d_signal, long n_clips,
                               int samples_per_clip, long clip_stride, int max_frames, int *d_labels,
                               float *d_decision, float *d_prob1, float *d_feat, void *stream);

@@ -161,3 +161,59 @@ def test_fused_kernel_equals_the_three_kernel_path(golden):
     a = sj(wide[:, :16000].contiguous(), 50, fused=False)
     b = sj(wide[:, :16000], 50, fused=True)
     assert torch.equal(a[3], b[3]) and torch.equal(a[0], b[0])
+
+
+def test_n_fft_2048_scrubjay_infer_framing(golden):
+    """The parameterisation of cepstrum/scrubjay_infer.c itself (:10-14: WIN_SIZE 2048, HOP_SIZE 1024, 40 filters, 20
+    coefficients): the 2048-point MFCC kernel against the oracle at that shape (clips, independent frames, a short frame
+    length, another sample rate / 128 mels), and the fused clip -> label kernel against the oracle chain and the three-kernel
+    path.  (aubio's filterbank and scaling are not vendored: what is pinned is the chain's arithmetic at this framing.)"""
+    import torch
+    import dsp_amd
+    from dsp_amd import scrubjay
+    from oracle import oracle as O
+    from tests.conftest import gate
+    m = golden("scrubjay_svm.npz")
+    for sr, extra in ((16000, {}), (44100, {}), (16000, dict(n_mels=128, n_mfcc=32, frame_length=1600, hop_length=800))):
+        cfg = scrubjay.scrubjay_infer_config(sr)
+        over = dict(sample_rate=sr, n_fft=2048, frame_length=2048, hop_length=1024, n_mels=40, n_mfcc=20, fmin=0.0, fmax=sr / 2.0)
+        over.update(extra)
+        for k, v in extra.items():
+            setattr(cfg, k, v)
+        plan = dsp_amd.MfccPlan(cfg)
+        ocfg = O.default_cfg(**over)
+        x = np.stack([S.uniform_pm1(24000, 60), S.chirp(24000, 300.0, 7000.0), S.uniform_pm1(24000, 61) * np.float32(0.01)])
+        x[2, 6000:] = 0.0
+        out = plan.clips(torch.from_numpy(x).cuda(), 500).cpu().numpy()
+        for i in range(3):
+            ref = O.compute_mfcc(x[i], 500, ocfg)
+            assert out[i].shape == ref.shape
+            gate(out[i], ref, f"n_fft 2048 sr {sr} {extra}/clip{i}")
+        if not extra:
+            fr = S.uniform_pm1(2048 * 70, 62).reshape(70, 2048)
+            fr[3] = 0.0
+            fplan = dsp_amd.MfccPlan(dsp_amd.default_config(**dict(over, hop_length=2048)))
+            got = fplan.frames(torch.from_numpy(fr).cuda()).cpu().numpy()
+            gate(got, O.mfcc_frames(fr, O.default_cfg(**dict(over, hop_length=2048)), threads=4), f"n_fft 2048 frames sr {sr}")
+            assert not got[3].any()
+    # fused: clip -> MFCC(2048/1024/40/20) -> mean | std -> SVM
+    sj = scrubjay.ScrubJay({k: m[k] for k in m.files}, config=scrubjay.scrubjay_infer_config(16000))
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    clips = torch.rand((300, 16000), device="cuda", generator=gen) * 2 - 1
+    clips[::3] *= 0.01
+    clips[4] = 0.0
+    a = sj(clips, fused=False)
+    b = sj(clips, fused=True)
+    assert torch.equal(a[3], b[3]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[0], b[0])
+    ocfg = O.default_cfg(n_fft=2048, frame_length=2048, hop_length=1024, n_mels=40, n_mfcc=20)
+    model = _model(m)
+    for i in (0, 3, 4, 299):
+        omfcc = O.compute_mfcc(clips[i].cpu().numpy(), 1 << 20, ocfg)
+        assert omfcc.shape == (14, 20)
+        ofeat = O.mfcc_stats(omfcc)
+        feat = b[3][i].cpu().numpy()
+        assert np.all(np.abs(feat - ofeat) <= 1e-4 * np.abs(omfcc).max() + (3e-4 if np.abs(omfcc).max() < 3.0 else 0.0))
+        lab, odec, op1 = O.svm_predict(model, feat)
+        assert abs(float(b[1][i]) - odec) <= 2e-5 * max(1.0, abs(odec)) and _prob_close(float(b[2][i]), op1)[0]
+        if abs(odec) > 1e-5:
+            assert int(b[0][i]) == lab
