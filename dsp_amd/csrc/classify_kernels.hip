@@ -409,6 +409,7 @@ hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, cons
 //   wave 2: taps 1000-3000 Hz one tile behind (segment means, energy gate)
 // HBM traffic: x once + 71 x (32 + 32 + 4 + 4) B per 1 s clip.
 // ---------------------------------------------------------------------------------
+template <bool EVEN_B>
 __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride,
                                                         const IirCoef c_bp, const IirCoef c_mp, float *__restrict__ ck_bp,
                                                         float *__restrict__ ck_mp, float *__restrict__ means_mp,
@@ -517,8 +518,12 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
             const float *vin = vbuf[(s - 1) & 1];
             auto taps = [&](float v) {                               // classifier.cpp:207-216
                 float o = c.b[0] * v;
+                // EVEN_B: b[1] = b[3] = b[5] = b[7] = 0 exactly (a Butterworth band-pass numerator is (1 - z^-2)^4 scaled: both
+                // literal tables).  Their products are +-0 for finite data and o + (+-0) == o, so skipping them changes at most
+                // the sign of an exact zero -- which no PSD value, hence no output of classify(), can see.
 #pragma unroll
-                for (int j = 1; j <= 8; ++j) o = o + c.b[j] * d[j - 1];
+                for (int j = 1; j <= 8; ++j)
+                    if (!EVEN_B || j % 2 == 0) o = o + c.b[j] * d[j - 1];
 #pragma unroll
                 for (int j = 7; j > 0; --j) d[j] = d[j - 1];
                 d[0] = v;
@@ -577,6 +582,8 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
     }
 }
 
+static bool even_taps_only(const IirCoef &c) { return c.b[1] == 0.0f && c.b[3] == 0.0f && c.b[5] == 0.0f && c.b[7] == 0.0f; }
+
 hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
                             float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream)
 {
@@ -589,8 +596,12 @@ hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, co
     }
     const int blocks = (int)((n_clips + 63) / 64);
     const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
-    hipLaunchKernelGGL(iir2_ckpt_kernel, dim3(blocks), dim3(192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, means_mp, want_mp,
-                       tables, vec_ok);
+    if (even_taps_only(c_mp))
+        hipLaunchKernelGGL(iir2_ckpt_kernel<true>, dim3(blocks), dim3(192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, means_mp, want_mp,
+                           tables, vec_ok);
+    else
+        hipLaunchKernelGGL(iir2_ckpt_kernel<false>, dim3(blocks), dim3(192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, means_mp, want_mp,
+                           tables, vec_ok);
     return hipGetLastError();
 }
 
@@ -935,7 +946,7 @@ struct SpecLane {                             // per-lane constants of the 256-p
     }
 };
 
-template <int OUT>
+template <int OUT, bool EVEN_B>
 __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void spec_from_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride, const IirCoef c,
                                                              const float *__restrict__ ck, const float *__restrict__ means,
                                                              const int *__restrict__ wantlist, const int *__restrict__ hits,
@@ -1048,7 +1059,8 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                 for (int i = 0; i < IIR_BURST; ++i) {                           // classifier.cpp:207-216
                     float o = c.b[0] * vr[i];
 #pragma unroll
-                    for (int j = 1; j <= 8; ++j) o = o + c.b[j] * d[j - 1];
+                    for (int j = 1; j <= 8; ++j)
+                        if (!EVEN_B || j % 2 == 0) o = o + c.b[j] * d[j - 1];       // EVEN_B: see iir2_ckpt_kernel
 #pragma unroll
                     for (int j = 7; j > 0; --j) d[j] = d[j - 1];
                     d[0] = vr[i];
@@ -1127,11 +1139,19 @@ hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long strid
     if (flags) {
         hipError_t e = hipMemsetAsync(out, 0, (size_t)total * sizeof(int), stream);      // frames not on the list are not loud
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(spec_from_ckpt_kernel<SPEC_FLAGS>, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wantlist,
-                           (const int *)nullptr, tables, out, T, vec_ok);
+        if (even_taps_only(c))
+            hipLaunchKernelGGL((spec_from_ckpt_kernel<SPEC_FLAGS, true>), grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wantlist,
+                               (const int *)nullptr, tables, out, T, vec_ok);
+        else
+            hipLaunchKernelGGL((spec_from_ckpt_kernel<SPEC_FLAGS, false>), grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wantlist,
+                               (const int *)nullptr, tables, out, T, vec_ok);
     } else {
-        hipLaunchKernelGGL(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR>, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means,
-                           (const int *)nullptr, hits, tables, out, T, vec_ok);
+        if (even_taps_only(c))
+            hipLaunchKernelGGL((spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, true>), grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means,
+                               (const int *)nullptr, hits, tables, out, T, vec_ok);
+        else
+            hipLaunchKernelGGL((spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, false>), grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means,
+                               (const int *)nullptr, hits, tables, out, T, vec_ok);
     }
     return hipGetLastError();
 }
@@ -1307,60 +1327,85 @@ hipError_t launch_spec_threshold(SpecTables *tables, float threshold_db, hipStre
 //                              midpoints, written to the clip's ClassifyTrace record; label 0 when there are none
 //   classify_bands_kernel      (band-pass spectrogram, clips with midpoints only)  dB map, normalisation, the three
 //                              band sums per midpoint in the reference's order, the rule
+constexpr int kMidClipsPerWave = 4;       // clips one wavefront walks: one atomic on the work-list counter per 16 clips, not per clip
 __global__ __launch_bounds__(256) void classify_midpoints_kernel(const int *__restrict__ loud, long n_clips, int T, int fs,
                                                                  int *__restrict__ labels, ClassifyTrace *__restrict__ trace,
                                                                  int *__restrict__ hits, int full_records)
 {
-    // a wavefront per clip; loud[clip][T] are the time bins with a cell above 70 dB (spectrogram_kernel<SPEC_FLAGS>)
+    // a wavefront per clip, kMidClipsPerWave clips in turn; loud[clip][T] are the time bins with a cell above the threshold
+    // (spec_from_ckpt_kernel<SPEC_FLAGS>).  Clips with midpoints go on the band kernels' work list: collected per block and
+    // appended with ONE atomic (12 288 single-word atomics from as many wavefronts took 0.14 ms: the word saturates at
+    // ~88 adds per microsecond).
     __shared__ float blob_all[4][1024];
+    __shared__ int hit_list[4][kMidClipsPerWave];
+    __shared__ int hit_count[4], hit_base;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long clip = (long)blockIdx.x * 4 + wib;
-    if (clip >= n_clips) return;
     float *blob = blob_all[wib];
-    // blob times of the flagged bins, in order (ballot ranks), then the greedy clustering on one lane
-    int nb = 0;
-    for (int j0 = 0; j0 < T; j0 += 64) {
-        const int j = j0 + lane;
-        const bool flag = j < T && loud[clip * T + j] != 0;
-        const unsigned long long m = __ballot(flag);
-        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        if (flag) blob[nb + rank] = ((float)(j * kSpecHop + kSpecSeg / 2)) / (float)fs;
-        nb += __popcll(m);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    int count = 0;
-    if (lane == 0) {
-        // greedy clustering, classifier.cpp:522-574
-        const float tol = 0.05f, min_dur = 0.15f;
-        int i0 = 0;
-        while (i0 < nb) {
-            int i1 = i0;
-            while (i1 + 1 < nb && (blob[i1 + 1] - blob[i1]) <= tol) ++i1;
-            const float dur = blob[i1] - blob[i0];
-            if (dur >= min_dur) {
-                float sm = 0.0f;
-                for (int k = i0; k <= i1; ++k) sm = sm + blob[k];
-                if (count < kMaxMidpoints) trace[clip].midpoints[count] = sm / (float)(i1 - i0 + 1);
-                ++count;
-            }
-            i0 = i1 + 1;
+    int n_hits = 0;                                         // wave-uniform
+    const long first = ((long)blockIdx.x * 4 + wib) * kMidClipsPerWave;
+    for (int ci = 0; ci < kMidClipsPerWave; ++ci) {
+        const long clip = first + ci;
+        if (clip >= n_clips) break;
+        // blob times of the flagged bins, in order (ballot ranks), then the greedy clustering on one lane
+        int nb = 0;
+        for (int j0 = 0; j0 < T; j0 += 64) {
+            const int j = j0 + lane;
+            const bool flag = j < T && loud[clip * T + j] != 0;
+            const unsigned long long m = __ballot(flag);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            if (flag) blob[nb + rank] = ((float)(j * kSpecHop + kSpecSeg / 2)) / (float)fs;
+            nb += __popcll(m);
         }
-        if (count > kMaxMidpoints) count = kMaxMidpoints;
-        trace[clip].n_midpoints = count;
-        if (count == 0) labels[clip] = 0;                   // classifier.cpp:93-114: no midpoint can fire the rule
-        else hits[1 + atomicAdd(hits, 1)] = (int)clip;      // work list of the band kernels, any order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int count = 0;
+        if (lane == 0) {
+            // greedy clustering, classifier.cpp:522-574
+            const float tol = 0.05f, min_dur = 0.15f;
+            int i0 = 0;
+            while (i0 < nb) {
+                int i1 = i0;
+                while (i1 + 1 < nb && (blob[i1 + 1] - blob[i1]) <= tol) ++i1;
+                const float dur = blob[i1] - blob[i0];
+                if (dur >= min_dur) {
+                    float sm = 0.0f;
+                    for (int k = i0; k <= i1; ++k) sm = sm + blob[k];
+                    if (count < kMaxMidpoints) trace[clip].midpoints[count] = sm / (float)(i1 - i0 + 1);
+                    ++count;
+                }
+                i0 = i1 + 1;
+            }
+            if (count > kMaxMidpoints) count = kMaxMidpoints;
+            trace[clip].n_midpoints = count;
+            if (count == 0) labels[clip] = 0;               // classifier.cpp:93-114: no midpoint can fire the rule
+            else hit_list[wib][n_hits] = (int)clip;
+        }
+        count = __builtin_amdgcn_readfirstlane(count);
+        n_hits += count > 0 ? 1 : 0;
+        if (full_records) {
+            // a whole record per clip: unused midpoints and the band sums the rule never reaches (no midpoints, or after the
+            // first hit) read as 0.  midpoints[64] and sums[64][3] are 256 consecutive floats.
+            static_assert(kMaxMidpoints == 64 && sizeof(ClassifyTrace) == 4 + 4 * 256, "record layout");
+            float *rec = trace[clip].midpoints;
+            for (int i = lane; i < 4 * kMaxMidpoints; i += 64)
+                if (i >= count) rec[i] = 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next clip reuses blob
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (!full_records) return;          // nobody reads the records of this batch (labels only): 1 KB per clip not written
-    count = __builtin_amdgcn_readfirstlane(count);
-    // a whole record per clip: unused midpoints and the band sums the rule never reaches (no midpoints, or after the
-    // first hit) read as 0.  midpoints[64] and sums[64][3] are 256 consecutive floats.
-    static_assert(kMaxMidpoints == 64 && sizeof(ClassifyTrace) == 4 + 4 * 256, "record layout");
-    float *rec = trace[clip].midpoints;
-    for (int i = lane; i < 4 * kMaxMidpoints; i += 64)
-        if (i >= count) rec[i] = 0.0f;
+    if (lane == 0) hit_count[wib] = n_hits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int total = hit_count[0] + hit_count[1] + hit_count[2] + hit_count[3];
+        hit_base = total ? atomicAdd(hits, total) : 0;      // work list of the band kernels, any order
+    }
+    __syncthreads();
+    int off = hit_base;
+    for (int w = 0; w < wib; ++w) off += hit_count[w];
+    if (lane < n_hits) hits[1 + off + lane] = hit_list[wib][lane];
 }
 
 // USE_LDS: the map fits the LDS budget (129 x T <= kTailLdsCells): the PSD cells of the clip are read ONCE into
@@ -1505,7 +1550,7 @@ hipError_t launch_classify_midpoints(const int *loud, long n_clips, int n, int f
     if (T <= 0 || T > 1024 || !trace || !hits) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(hits, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(classify_midpoints_kernel, dim3((unsigned)((n_clips + 3) / 4)), dim3(256), 0, stream, loud, n_clips, T, fs, labels, trace, hits, full_records ? 1 : 0);
+    hipLaunchKernelGGL(classify_midpoints_kernel, dim3((unsigned)((n_clips + 4 * kMidClipsPerWave - 1) / (4 * kMidClipsPerWave))), dim3(256), 0, stream, loud, n_clips, T, fs, labels, trace, hits, full_records ? 1 : 0);
     return hipGetLastError();
 }
 
