@@ -34,7 +34,16 @@ def _hipcc() -> str:
 
 
 def is_stale() -> bool:
+    """True when the library on disk was not built from the sources in the tree: by the hash the build left next to it
+    (mtimes do not survive a copy of the tree to another machine), with the mtime comparison as a second opinion.  The
+    authoritative check is made by lib.load() AFTER loading: the hash compiled into the binary (dsp_version())."""
     if not os.path.exists(LIB):
+        return True
+    try:
+        with open(LIB + ".hash") as f:
+            if f.read().strip() != source_hash():
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
@@ -74,8 +83,11 @@ def _build_locked(verbose: bool) -> str:
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     try:
+        h = source_hash()
         subprocess.check_call(cmd, cwd=CSRC)
         os.replace(tmp, LIB)
+        with open(LIB + ".hash", "w") as f:
+            f.write(h + "\n")
     finally:
         if os.path.exists(tmp):
             os.remove(tmp)
