@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void mfcc1024_kernel(const Mfcc512Args args, c
         for (int a = 0; a < 8; ++a) {
             const int i = 2 * (lane + 64 * a);
             if (FULL || i + 1 < frame_len) {
-                const f2v x = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));
+                const f2v x = args.frames_per_clip > 0 ? *reinterpret_cast<const f2v *>(src + i)      // clips re-read samples: cacheable
+                                                       : __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));
                 z[a] = {x.x, x.y};
             } else if (i < frame_len) {
                 z[a] = {src[i], 0.0f};

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void mfcc2048_kernel(const Mfcc512Args args, c
             const int i = 2 * (lane + 64 * a);
             float x0 = 0.0f, x1 = 0.0f;
             if (i + 1 < frame_len) {
-                const f2v x = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));
+                const f2v x = CLIPS ? *reinterpret_cast<const f2v *>(src + i) : __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));   // clips re-read samples: cacheable
                 x0 = x.x; x1 = x.y;
             } else if (i < frame_len) {
                 x0 = src[i];

@@ -57,7 +57,13 @@ namespace {
 //   3 int16 stereo, channel average  x = 0.5 (L/32768 + R/32768)  (main_test.c:205-217)
 // The power-of-two scale is folded into the window (exact), so a lane only converts int -> float.
 // `off` is the frame's first sample (per channel).
-template <int FLEN, int IN>
+// STREAM: frames lie back to back and every sample is read exactly once -> nontemporal loads (nothing is displaced in L2).
+// Clip mode reads every sample 2.5 times (frames of 400 every 160): those loads must stay cacheable, or the re-reads go
+// out to the fabric again (measured with nontemporal loads: 1.96 x the algorithmic bytes; FETCH_SIZE, profiles/r02b).
+template <typename V>
+__device__ __forceinline__ V ld_frame(const V *p, bool stream) { return stream ? __builtin_nontemporal_load(p) : *p; }
+
+template <int FLEN, int IN, bool STREAM>
 __device__ __forceinline__ void load_frame(const void *__restrict__ base, long off, int lane, int frame_len, c32 (&z)[4])
 {
 #pragma unroll
@@ -69,8 +75,7 @@ __device__ __forceinline__ void load_frame(const void *__restrict__ base, long o
         if (IN == 0) {
             const float *src = static_cast<const float *>(base) + off;
             if (both) {
-                // streamed once: nontemporal keeps the frames from displacing anything in L2
-                const f2v v = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));
+                const f2v v = ld_frame(reinterpret_cast<const f2v *>(src + i), STREAM);
                 z[a] = {v.x, v.y};
             } else if (one) {
                 z[a] = {src[i], 0.0f};
@@ -82,14 +87,14 @@ __device__ __forceinline__ void load_frame(const void *__restrict__ base, long o
             // is consumed (unpack_pcm16): 4 VGPRs per frame in flight instead of 8
             const short *src = static_cast<const short *>(base) + off;
             int v = 0;
-            if (both) v = __builtin_nontemporal_load(reinterpret_cast<const int *>(src + i));         // samples i, i+1
+            if (both) v = ld_frame(reinterpret_cast<const int *>(src + i), STREAM);                  // samples i, i+1
             else if (one) v = (int)(unsigned short)src[i];
             z[a] = {__int_as_float(v), 0.0f};
         } else {
             // interleaved stereo: the ring keeps the two raw L|R dwords, unpack_pcm16 converts at consumption
             const short *src = static_cast<const short *>(base) + 2 * off;
             i2v v = {0, 0};
-            if (both) v = __builtin_nontemporal_load(reinterpret_cast<const i2v *>(src + 2 * i));      // L0 R0 | L1 R1
+            if (both) v = ld_frame(reinterpret_cast<const i2v *>(src + 2 * i), STREAM);               // L0 R0 | L1 R1
             else if (one) v.x = *reinterpret_cast<const int *>(src + 2 * i);
             z[a] = {__int_as_float(v.x), __int_as_float(v.y)};
         }
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
     bool lastq[DSP_PREFETCH];           // POOL: the frame closes its chunk (= its clip)
     auto refill = [&](int d) {
         if (pre.valid()) {
-            load_frame<FLEN, IN>(args.in, pre.off, lane, frame_len, ring[d]);
+            load_frame<FLEN, IN, !CLIPS>(args.in, pre.off, lane, frame_len, ring[d]);
             fq[d] = pre.f; cq[d] = pre.clip; lastq[d] = pre.left == 0 || pre.remaining == 1;
             pre.next();
         } else {

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void mfcc512_row_kernel(const Mfcc512Args args
         for (int k = 0; k < 16; ++k) {
             const int i = 2 * (j + 16 * k);
             if (row_ok && (FULL || i + 1 < frame_len)) {
-                const f2v x = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));
+                const f2v x = args.frames_per_clip > 0 ? *reinterpret_cast<const f2v *>(src + i)      // clips re-read samples: cacheable
+                                                       : __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));
                 v[k] = {x.x, x.y};
             } else if (row_ok && i < frame_len) {
                 v[k] = {src[i], 0.0f};
