@@ -37,14 +37,18 @@ def butter_bandpass_filter(data: np.ndarray, b, a) -> np.ndarray:
 
 
 def compute_spectrogram(signal: np.ndarray, fs: int = 16000):
-    """-> (frequencies[129], times[T], Sxx[129][T]) float32 (classifier.cpp:221-368)."""
-    signal = np.ascontiguousarray(signal, np.float32)
+    """-> (frequencies[129], times[T], Sxx[129][T]).  float32 input: the fp32 firmware arithmetic, bit-identical to
+    classifier.cpp:221-368; float64 input: the float64 pipeline of donut-classifier/classifier.c:448-592."""
+    signal = np.asarray(signal)
+    dt = np.float64 if signal.dtype == np.float64 else np.float32
+    signal = np.ascontiguousarray(signal, dt)
     t_max = max(1, (signal.size - 256) // 224 + 1) if signal.size >= 256 else 1
-    freqs = np.empty(129, np.float32)
-    times = np.empty(t_max, np.float32)
-    sxx = np.empty((129, t_max), np.float32)
-    t = _lib.check(_lib.load().dsp_compute_spectrogram_f32(signal.ctypes.data, signal.size, int(fs), freqs.ctypes.data,
-                                                            times.ctypes.data, sxx.ctypes.data), "dsp_compute_spectrogram_f32")
+    freqs = np.empty(129, dt)
+    times = np.empty(t_max, dt)
+    sxx = np.empty((129, t_max), dt)
+    fn = _lib.load().dsp_compute_spectrogram_f64 if dt == np.float64 else _lib.load().dsp_compute_spectrogram_f32
+    t = _lib.check(fn(signal.ctypes.data, signal.size, int(fs), freqs.ctypes.data, times.ctypes.data, sxx.ctypes.data),
+                   "dsp_compute_spectrogram")
     return freqs, times[:t], sxx.reshape(-1)[: 129 * t].reshape(129, t)
 
 

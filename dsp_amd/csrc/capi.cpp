@@ -747,6 +747,31 @@ int dsp_compute_spectrogram_f32(const float *signal, int n, int fs, float *frequ
     return T;
 }
 
+int dsp_compute_spectrogram_f64(const double *signal, int n, int fs, double *frequencies, double *times, double *sxx)
+{
+    if (!signal || !sxx || n < 0 || fs <= 0) return fail(DSP_EINVAL, "bad argument");
+    const int T = spec_bins(n);
+    if (frequencies)
+        for (int k = 0; k < dsp::kSpecBins; ++k) frequencies[k] = (double)k * fs / dsp::kSpecSeg;                      // classifier.c:468-471
+    if (times)
+        for (int t = 0; t < T; ++t) times[t] = (double)(t * dsp::kSpecHop + dsp::kSpecSeg / 2) / fs;                    // :474-478
+    if (T == 0) return 0;
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    int rc = cls_init();
+    if (rc < 0) return rc;
+    DSP_HIP(hipSetDevice(g_cls.device));
+    double *dx = nullptr, *ds = nullptr;
+    DSP_HIP(hipMalloc(&dx, (size_t)n * sizeof(double)));
+    const size_t sb = (size_t)dsp::kSpecBins * T * sizeof(double);
+    if (hipMalloc(&ds, sb) != hipSuccess) { hipFree(dx); return fail(DSP_ENOMEM, "hipMalloc"); }
+    hipError_t e = hipMemcpy(dx, signal, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dsp::launch_spectrogram_f64(dx, 1, n, n, fs, ds, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(sxx, ds, sb, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(ds);
+    if (e != hipSuccess) return fail(DSP_EHIP, hipGetErrorString(e));
+    return T;
+}
+
 int dsp_sum_intense_f32(float lower, float upper, float half_range, const float *frequencies, int freq_bins,
                         const float *times, int time_bins, const float *db, float midpoint, float *out)
 {

@@ -1156,6 +1156,68 @@ hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long strid
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------
+// a10 in float64: compute_spectrogram of donut-classifier/classifier.c:448-592 (the file north_star names for the IIR keeps
+// its whole pipeline in double and transforms with FFTW's r2c).  FFTW is unvendored, so there is no operation order to replay:
+// a block per frame evaluates the 129 bins of the 256-point DFT directly in float64 (129 x 256 multiply-adds, twiddles from
+// sincospi) -- the same mathematical transform, checked by tolerance against scipy.signal.spectrogram and the reference-held dump _blobtimes.txt (tests).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spectrogram_f64_kernel(const double *__restrict__ y, long n_clips, int n, long stride, int fs,
+                                                              double *__restrict__ sxx, int T)
+{
+    __shared__ double seg[kSpecSeg], cs[kSpecSeg], sn[kSpecSeg], red[kSpecSeg];
+    const int tid = threadIdx.x;
+    const long clip = blockIdx.x / T;
+    const int t = (int)(blockIdx.x - clip * T);
+    if (clip >= n_clips) return;
+    const double x = y[clip * stride + (long)t * kSpecHop + tid];
+    double s_, c_;
+    sincospi(2.0 * (double)tid / (double)kSpecSeg, &s_, &c_);
+    cs[tid] = c_; sn[tid] = s_;
+    // periodic Tukey(0.25): the 257-point symmetric formula without its last point (classifier.c:484-521)
+    const double alpha = 0.25, M = (double)(kSpecSeg + 1), pi = 3.14159265358979323846;
+    const int width = (int)floor(alpha * (M - 1.0) / 2.0);
+    double w;
+    if (tid <= width) w = 0.5 * (1.0 + cos(pi * (-1.0 + 2.0 * tid / (alpha * (M - 1.0)))));
+    else if (tid <= (int)(M - width - 2)) w = 1.0;
+    else w = 0.5 * (1.0 + cos(pi * (-2.0 / alpha + 1.0 + 2.0 * tid / (alpha * (M - 1.0)))));
+    auto block_sum = [&](double v) {
+        red[tid] = v;
+        __syncthreads();
+        for (int o = kSpecSeg / 2; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    const double mean = block_sum(x) / (double)kSpecSeg;               // classifier.c:551-561 detrend
+    const double U = block_sum(w * w) * (double)fs;                     // :524-530
+    seg[tid] = (x - mean) * w;
+    __syncthreads();
+    if (tid < kSpecBins) {
+        double sr = 0.0, si = 0.0;
+        for (int i = 0; i < kSpecSeg; ++i) {
+            const int ph = (tid * i) & (kSpecSeg - 1);
+            sr += seg[i] * cs[ph];
+            si -= seg[i] * sn[ph];
+        }
+        double p = (sr * sr + si * si) / U;                             // :574-586
+        if (tid >= 1 && tid < kSpecBins - 1) p *= 2.0;
+        sxx[(clip * kSpecBins + tid) * (long)T + t] = p;
+    }
+}
+
+hipError_t launch_spectrogram_f64(const double *y, long n_clips, int n, long stride, int fs, double *sxx, hipStream_t stream)
+{
+    const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
+    if (n_clips <= 0 || T <= 0) return hipSuccess;
+    if (n_clips * T >= (1L << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(spectrogram_f64_kernel, dim3((unsigned)(n_clips * T)), dim3(256), 0, stream, y, n_clips, n, stride, fs, sxx, T);
+    return hipGetLastError();
+}
+
 hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stride, const SpecTables *tables,
                                   float *sxx, hipStream_t stream, const float *means, const int *hits, bool frame_major)
 {

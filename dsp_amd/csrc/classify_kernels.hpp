@@ -74,6 +74,10 @@ hipError_t launch_spectrogram_f32(const float *y, long n_clips, int n, long stri
                                   bool frame_major = false);
 
 
+// float64 twin (donut-classifier/classifier.c:448-592): sxx[c][129][T] in double, direct DFT per frame (tolerance parity: FFTW
+// is unvendored)
+hipError_t launch_spectrogram_f64(const double *y, long n_clips, int n, long stride, int fs, double *sxx, hipStream_t stream);
+
 // The 1000-3000 Hz spectrogram reduced to what find_midpoints reads from it (classifier.cpp:457-518): loud[c][T] = 1 for
 // the time bins with a cell above 70 dB.  The map itself is not written.
 hipError_t launch_spectrogram_flags(const float *y, long n_clips, int n, long stride, const SpecTables *tables, int *loud,

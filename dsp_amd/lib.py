@@ -75,7 +75,7 @@ PREFILTER_NONE, PREFILTER_BUTTER_1000_3000, PREFILTER_BUTTER_3000_7500 = 0, 1, 2
 SYMBOLS = [
     "compute_mfcc", "dsp_classify",
     "dsp_classify_default_config", "dsp_classify_batch_host_cfg", "dsp_classify_batch_device_cfg", "dsp_sum_intense_f32",
-    "dsp_butter_bandpass_filter_f32", "dsp_butter_bandpass_filter_f64", "dsp_compute_spectrogram_f32",
+    "dsp_butter_bandpass_filter_f32", "dsp_butter_bandpass_filter_f64", "dsp_compute_spectrogram_f32", "dsp_compute_spectrogram_f64",
     "dsp_classify_batch_host", "dsp_classify_batch_device", "dsp_find_midpoints",
     "dsp_mfcc_stats_device", "dsp_svm_create", "dsp_svm_destroy", "dsp_svm_predict_device",
     "dsp_mfcc_default_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
@@ -148,6 +148,7 @@ def load() -> C.CDLL:
     L.dsp_butter_bandpass_filter_f32.argtypes = [vp, C.c_long, ip, C.c_long, vp, vp, vp]; L.dsp_butter_bandpass_filter_f32.restype = ip
     L.dsp_butter_bandpass_filter_f64.argtypes = [vp, C.c_long, ip, C.c_long, vp, vp, vp]; L.dsp_butter_bandpass_filter_f64.restype = ip
     L.dsp_compute_spectrogram_f32.argtypes = [vp, ip, ip, vp, vp, vp]; L.dsp_compute_spectrogram_f32.restype = ip
+    L.dsp_compute_spectrogram_f64.argtypes = [vp, ip, ip, vp, vp, vp]; L.dsp_compute_spectrogram_f64.restype = ip
     L.dsp_classify_batch_host.argtypes = [vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_batch_host.restype = ip
     L.dsp_find_midpoints.argtypes = [vp, ip, ip, vp, ip]; L.dsp_find_midpoints.restype = ip
     L.dsp_classify_batch_device.argtypes = [vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_batch_device.restype = ip

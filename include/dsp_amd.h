@@ -163,6 +163,10 @@ int dsp_butter_bandpass_filter_f64(const double *data, long n_clips, int n, long
  * Host pointers; frequencies / times may be NULL.                                 */
 int dsp_compute_spectrogram_f32(const float *signal, int signal_length, int fs,
                                 float *frequencies, float *times, float *sxx);
+/* The float64 twin, compute_spectrogram of donut-classifier/classifier.c:448-592 (FFTW r2c there; here a float64 DFT per
+ * frame, the same transform -- parity by tolerance, FFTW is unvendored).  Same flat layout in double.                  */
+int dsp_compute_spectrogram_f64(const double *signal, int signal_length, int fs,
+                                double *frequencies, double *times, double *sxx);
 
 /* Per-clip trace of classify() for parity tests: midpoints (classifier.cpp:433-598) and
  * the three band sums per midpoint (classifier.cpp:99-101).                       */

@@ -240,3 +240,29 @@ def test_clips_longer_than_the_trace_can_describe_are_rejected(dsp):
     assert dsp.classify_batch(np.zeros((1, n_ok), np.float32))[0] == 0
     with pytest.raises(dsp.DspError, match="too long"):
         dsp.classify_batch(np.zeros((1, n_ok + 224), np.float32))
+
+
+def test_float64_spectrogram_vs_oracle_scipy_and_blobtimes(dsp, golden):
+    """compute_spectrogram of donut-classifier/classifier.c:448-592 in float64 on the GPU: against the oracle and
+    scipy.signal.spectrogram (1e-10), and through the reference's own known-answer dump _blobtimes.txt (filter in float64 on
+    the GPU, spectrogram in float64 on the GPU, 45 dB mask: the 61 blob times)."""
+    from oracle import oracle as O
+    from scipy import signal as ss
+    x = S.uniform_pm1(5000, 3).astype(np.float64)
+    f, t, sxx = dsp.compute_spectrogram(x, 16000)
+    assert sxx.dtype == np.float64
+    fo, to, so = O.spectrogram_f64(x, 16000)
+    f2, t2, s2 = ss.spectrogram(x, fs=16000)
+    assert np.allclose(f, fo) and np.allclose(t, to) and np.allclose(f, f2) and np.allclose(t, t2)
+    assert np.allclose(sxx, so, rtol=1e-10, atol=1e-20) and np.allclose(sxx, s2, rtol=1e-9, atol=1e-18)
+    k = golden("blobtimes_kat.npz")
+    fs = int(k["fs"])
+    pcm = k["pcm"].astype(np.float64) / 32768.0
+    y = dsp.butter_bandpass_filter(pcm, k["b"], k["a"])
+    _, tt, sx = dsp.compute_spectrogram(y, fs)
+    with np.errstate(divide="ignore"):
+        db = 10 * np.log10(sx / 1e-12)
+    mine = tt[(db > float(k["threshold_db"])).any(axis=0)]
+    ref = k["blobtimes"]
+    ref = ref[ref <= tt[-1] + 1e-9]
+    assert ref.size >= 10 and mine.size == ref.size and np.abs(mine - ref).max() <= 1e-6
