@@ -83,6 +83,7 @@ __device__ __forceinline__ void prefilter_scan(const float (&x)[kScanChunk], flo
         const bool on = lane >= (1 << d);
 #pragma unroll
         for (int sc = 0; sc < 4; ++sc) {
+            if (d >= S->steps[sc]) continue;          // wave-uniform: this section's older chunks are damped below 1e-14
             const double u0 = shfl_up_f64(t0[sc], from), u1 = shfl_up_f64(t1[sc], from);
             const double *m = S->pw[d][sc];
             const double n0 = t0[sc] + m[0] * u0 + m[1] * u1, n1 = t1[sc] + m[2] * u0 + m[3] * u1;

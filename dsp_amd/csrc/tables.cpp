@@ -165,6 +165,11 @@ bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &o
         out.b1[ns] = -2.0 * (r * std::conj(p)).real();
         out.a1[ns] = -2.0 * p.real();
         out.a2[ns] = std::norm(p);
+        {   // smallest D with |p|^(16 * 2^D) < 1e-14
+            int D = 0;
+            while (D < 6 && std::pow(std::abs(p), 16.0 * (double)(1 << D)) >= 1e-14) ++D;
+            out.steps[ns] = D;
+        }
         ++ns;
     }
     if (ns != 4) { why = "prefilter: expected four conjugate pole pairs"; return false; }
@@ -201,7 +206,7 @@ bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &o
             for (int i = 0; i < kScanChunk; ++i) { const double w0 = x[16 * l + i] - out.a1[sct] * w1 - out.a2[sct] * w2; w2 = w1; w1 = w0; }
             T[l][0] = w1; T[l][1] = w2;
         }
-        for (int d = 0; d < 6; ++d) {
+        for (int d = 0; d < out.steps[sct]; ++d) {
             const double *m = out.pw[d][sct];
             for (int l = 63; l >= (1 << d); --l) {
                 const double *u = T[l - (1 << d)];

@@ -132,6 +132,10 @@ struct PrefilterScan {
     double k0;
     double b0[4], b1[4], a1[4], a2[4];
     double pw[6][4][4];            // [step][section][m00, m01, m10, m11]
+    // Scan steps section s needs: after `steps[s]` steps the scan covers 2^steps[s] chunks back, and what lies further back
+    // reaches the state damped by |pole_s|^(16 * 2^steps[s]) < 1e-14 (the pole radii of the two literal filters are
+    // 0.27 .. 0.93: 1 .. 5 steps instead of 6 for every section).
+    int32_t steps[4];
 };
 constexpr int kScanChunk = 16;     // samples per lane: 64 lanes x 16 = one 1024-sample frame
 bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &out, std::string &why);
