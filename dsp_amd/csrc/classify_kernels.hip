@@ -861,21 +861,25 @@ __global__ __launch_bounds__(256) void spectrogram_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------
-// a10 from checkpoints: the spectrogram of segments that were never written to HBM.  A 256-thread block takes 64 frame
+// a10 from checkpoints: the spectrogram of segments that were never written to HBM.  A 512-thread block takes 60 frame
 // slots ((clip, time bin) pairs); for the wanted ones it
 //   L  loads the segments' 256 input samples into its LDS rows (all waves, coalesced 1 KB rows);
 //   R  recomputes the recurrence v over the segment's 256 samples, lane per frame (wave 0), from the delay line
 //      iir2_ckpt_kernel stored at the segment start: classifier.cpp:199-205 on the same x with the same state;
-//   T  applies the output taps y[n] = b0 v[n] + sum b[j] v[n-j] (classifier.cpp:207-216): no feedback, so the four waves
-//      take a quarter of every segment each, and y overwrites v in place;
+//   T  applies the output taps y[n] = b0 v[n] + sum b[j] v[n-j] (classifier.cpp:207-216): no feedback, so the eight waves
+//      take an eighth of every segment each, and y overwrites v in place;
 //   M  (3000-7500 Hz map only) sums each segment in order for its mean (classifier.cpp:329-333), lane per frame;
-//   F  runs the 256-point PlainFFT of each wanted frame, a wave per frame, 16 frames per wave, exactly as
+//   F  runs the 256-point PlainFFT of each wanted frame, a wave per frame, 7 or 8 frames per wave, exactly as
 //      spectrogram_kernel does, reading the samples from the block's LDS rows.
 // OUT = SPEC_FLAGS: slot = clip * T + t over all clips, wanted = gate != 0, output one flag per slot (0 for the others);
 // OUT = SPEC_FRAME_MAJOR: slots walk the work list `hits`, every frame is wanted, output [time][bin] PSD rows.
 // ---------------------------------------------------------------------------------
-constexpr int RC_THREADS = 256, RC_WAVES = RC_THREADS / 64;
-static_assert((kSpecSeg / RC_WAVES) % IIR_BURST == 0 && 64 % RC_WAVES == 0, "taps and frames split evenly over the waves");
+// 512 threads and 60 frame slots per block: 60 rows + 8 FFT buffers = 80.5 KB, so TWO blocks of eight waves fit a CU's 160 KB
+// (64 slots would be 84.7 KB: one block per CU).  The recompute is lane-per-frame on one wave (~9 us whatever the lane
+// count), so what a CU delivers is frames in flight / block latency: 2 x 60 frames over (1 + 9 + 1 + 1 + 3.4) us instead of
+// 2 x 64 over (2 + 9 + 2 + 1 + 7) us with four waves per block.
+constexpr int RC_THREADS = 512, RC_WAVES = RC_THREADS / 64, RC_FRAMES = 60;
+static_assert((kSpecSeg / RC_WAVES) % IIR_BURST == 0 && RC_FRAMES <= 64, "taps split evenly over the waves; a frame per lane");
 constexpr int RC_ROW = 8 + kSpecSeg + 1;      // v[-8..-1] | 256 samples | pad: odd stride, lane l <-> row l is conflict free
 
 struct SpecLane {                             // per-lane constants of the 256-point FFT (see spectrogram_kernel)
@@ -953,7 +957,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                                                              const SpecTables *__restrict__ tab, float *__restrict__ out, int T, int vec_ok)
 {
     static_assert(OUT == SPEC_FLAGS || OUT == SPEC_FRAME_MAJOR, "flags or [time][bin]");
-    __shared__ float rows[64 * RC_ROW];
+    __shared__ float rows[RC_FRAMES * RC_ROW];
     __shared__ float2 fftbuf[RC_WAVES][kSpecSeg];
     __shared__ float smean[64];
     __shared__ int sflag[64];
@@ -962,11 +966,11 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     // frame slots of this launch: SPEC_FLAGS walks the work list of gated-in frames (wantlist[0] = count, then clip * T + t),
     // SPEC_FRAME_MAJOR every time bin of the clips on `hits` (hits[0] = count, then clip numbers)
     const long total = OUT == SPEC_FLAGS ? (long)wantlist[0] : (long)hits[0] * T;
-    const long gid0 = (long)blockIdx.x * 64;
+    const long gid0 = (long)blockIdx.x * RC_FRAMES;
     if (gid0 >= total) return;
     // every wave's lane l describes frame slot gid0 + l
     const long gid = gid0 + lane;
-    const bool want = gid < total;
+    const bool want = lane < RC_FRAMES && gid < total;
     long clip = 0;
     int t = 0;
     if (want) {
@@ -981,18 +985,20 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         }
     }
     const unsigned long long todo = __ballot(want);
-    float *row = rows + lane * RC_ROW;
+    float *row = rows + (lane < RC_FRAMES ? lane : 0) * RC_ROW;
 
     // ---- L: the wanted segments of x into the rows.  Every load of the block is issued before the first LDS store (16
     // float4 per thread in flight): loads inside the recurrence loop would each pay an HBM round trip that the serial
     // arithmetic cannot cover.  One wave-instruction = one row = 1 KB contiguous.
     {
-        constexpr int PER_ROW = kSpecSeg / 4, NL = 64 * PER_ROW / RC_THREADS;
+        constexpr int PER_ROW = kSpecSeg / 4, NL = (RC_FRAMES * PER_ROW + RC_THREADS - 1) / RC_THREADS;
+        static_assert(PER_ROW == 64, "one wave-instruction loads one row");
         float4 v4[NL];
         const unsigned clip_lo = (unsigned)clip, clip_hi = (unsigned)((unsigned long long)clip >> 32);
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int e = threadIdx.x + RC_THREADS * i, r = e / PER_ROW, c4 = (e % PER_ROW) * 4;      // r is wave-uniform
+            if (r >= RC_FRAMES) { v4[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
             const long rclip = (long)(((unsigned long long)__builtin_amdgcn_readlane(clip_hi, r) << 32) | __builtin_amdgcn_readlane(clip_lo, r));
             const float *xs = x + rclip * stride + (long)__builtin_amdgcn_readlane(t, r) * kSpecHop + c4;     // unwanted slots: clip 0, t 0
             if (vec_ok) v4[i] = *reinterpret_cast<const float4 *>(xs);
@@ -1001,6 +1007,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int e = threadIdx.x + RC_THREADS * i, r = e / PER_ROW, c4 = (e % PER_ROW) * 4;
+            if (r >= RC_FRAMES) continue;
             float *dst = rows + r * RC_ROW + 8 + c4;
             dst[0] = v4[i].x; dst[1] = v4[i].y; dst[2] = v4[i].z; dst[3] = v4[i].w;
         }
@@ -1102,7 +1109,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     float2 *buf = fftbuf[wib];
     const unsigned clip_lo = (unsigned)clip, clip_hi = (unsigned)((unsigned long long)clip >> 32);
 #pragma unroll 1
-    for (int f = (64 / RC_WAVES) * wib; f < (64 / RC_WAVES) * (wib + 1); ++f) {
+    for (int f = wib; f < RC_FRAMES; f += RC_WAVES) {
         if (!((todo >> f) & 1)) continue;
         const float *fr = rows + f * RC_ROW + 8;
         float cur[4];
@@ -1135,7 +1142,7 @@ hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long strid
     if (n_clips <= 0 || T <= 0) return hipSuccess;
     const long total = n_clips * T;                       // the bound: blocks past the list's count exit at once
     const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
-    const dim3 grid((unsigned)((total + 63) / 64));
+    const dim3 grid((unsigned)((total + RC_FRAMES - 1) / RC_FRAMES));
     if (flags) {
         hipError_t e = hipMemsetAsync(out, 0, (size_t)total * sizeof(int), stream);      // frames not on the list are not loud
         if (e != hipSuccess) return e;
