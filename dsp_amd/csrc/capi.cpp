@@ -772,6 +772,16 @@ int dsp_compute_spectrogram_f64(const double *signal, int n, int fs, double *fre
     return T;
 }
 
+#ifdef DSP_RC_STAMPS
+namespace dsp { hipError_t read_rc_stamps(unsigned long long *host, int count); }
+int dsp_debug_rc_stamps(unsigned long long *out, int count)     // diagnostic builds only (tools/rc_stamps.py)
+{
+    DSP_HIP(hipDeviceSynchronize());
+    DSP_HIP(dsp::read_rc_stamps(out, count));
+    return DSP_OK;
+}
+#endif
+
 int dsp_sum_intense_f32(float lower, float upper, float half_range, const float *frequencies, int freq_bins,
                         const float *times, int time_bins, const float *db, float midpoint, float *out)
 {

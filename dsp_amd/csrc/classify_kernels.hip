@@ -950,6 +950,19 @@ struct SpecLane {                             // per-lane constants of the 256-p
     }
 };
 
+// Diagnostic build only (-DDSP_RC_STAMPS, never shipped): s_memtime at the phase boundaries of the first 2048 blocks, written to a
+// buffer of their own that no kernel reads (cdna_hip_programming.md 7, in-kernel stamps); tools/rc_stamps.py prints the medians.
+#ifdef DSP_RC_STAMPS
+__device__ unsigned long long g_rc_stamps[8 * 2048];
+#define RC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_rc_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+hipError_t read_rc_stamps(unsigned long long *host, int count)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rc_stamps), sizeof(unsigned long long) * (size_t)count);
+}
+#else
+#define RC_STAMP(k) do { } while (0)
+#endif
+
 template <int OUT, bool EVEN_B>
 __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void spec_from_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride, const IirCoef c,
                                                              const float *__restrict__ ck, const float *__restrict__ means,
@@ -985,6 +998,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         }
     }
     const unsigned long long todo = __ballot(want);
+    RC_STAMP(0);
     float *row = rows + (lane < RC_FRAMES ? lane : 0) * RC_ROW;
 
     // ---- L: the wanted segments of x into the rows.  Every load of the block is issued before the first LDS store (16
@@ -1013,6 +1027,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         }
     }
     __syncthreads();
+    RC_STAMP(1);
 
     // ---- R: v over the segment, from the stored delay line; v replaces x in the row
     if (wib == 0) {
@@ -1047,6 +1062,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         }
     }
     __syncthreads();
+    RC_STAMP(2);
 
     // ---- T: output taps, wave w takes samples [RC_TQ w, RC_TQ (w + 1)) of every wanted frame; y replaces v
     {
@@ -1079,6 +1095,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         }
     }
     __syncthreads();
+    RC_STAMP(3);
 
     // ---- M: segment means (sequential sums, classifier.cpp:329-333)
     if (wib == 0 && want) {
@@ -1100,6 +1117,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         smean[lane] = mean;
     }
     __syncthreads();
+    RC_STAMP(4);
 
     // ---- F: one frame at a time per wave
     SpecLane K;
@@ -1129,6 +1147,10 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
             if (lane == 0) o[128] = p2;
         }
     }
+#ifdef DSP_RC_STAMPS
+    __syncthreads();
+    RC_STAMP(5);
+#endif
     if (OUT == SPEC_FLAGS) {
         __syncthreads();
         if (wib == 0 && want) reinterpret_cast<int *>(out)[clip * T + t] = sflag[lane];      // the rest of loud[] was zeroed by the launcher
