@@ -19,6 +19,10 @@
 #include "svm_kernels.hpp"
 #include "tables.hpp"
 
+#ifdef DSP_RC_STAMPS
+namespace dsp { hipError_t read_rc_stamps(unsigned long long *host, int count); }      // classify_kernels.hip, diagnostic builds
+#endif
+
 namespace {
 
 thread_local std::string g_err;
@@ -773,7 +777,6 @@ int dsp_compute_spectrogram_f64(const double *signal, int n, int fs, double *fre
 }
 
 #ifdef DSP_RC_STAMPS
-namespace dsp { hipError_t read_rc_stamps(unsigned long long *host, int count); }
 int dsp_debug_rc_stamps(unsigned long long *out, int count)     // diagnostic builds only (tools/rc_stamps.py)
 {
     DSP_HIP(hipDeviceSynchronize());
