@@ -777,7 +777,7 @@ int dsp_compute_spectrogram_f64(const double *signal, int n, int fs, double *fre
 }
 
 #ifdef DSP_RC_STAMPS
-int dsp_debug_rc_stamps(unsigned long long *out, int count)     // diagnostic builds only (tools/rc_stamps.py)
+__attribute__((visibility("default"))) int dsp_debug_rc_stamps(unsigned long long *out, int count)     // diagnostic builds only (tools/rc_stamps.py)
 {
     DSP_HIP(hipDeviceSynchronize());
     DSP_HIP(dsp::read_rc_stamps(out, count));
