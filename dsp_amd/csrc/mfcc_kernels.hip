@@ -18,10 +18,13 @@
 //   power     |X[k]|^2, k = 0..256                                     mfcc.c:151-155
 //   mel       sparse HTK triangles: <= 12 bins per lane + 3-way gather  mfcc.c:158-164
 //   log       per-frame ref = max, amin, top_db (v_log_f32)            mfcc.c:169-206
-//   DCT-II    4 lanes per coefficient, quad DPP reduce                 mfcc.c:210-216
+//   DCT-II    default (TILE): once per 16-frame tile as v_mfma_f32_16x16x4_f32,          mfcc.c:210-216
+//             D[coef][frame] += A[coef][mel] B[mel][frame] in full fp32 -- the one dense
+//             product the chain contains; per-frame form (clip-global log mode): 4 lanes
+//             per coefficient + quad DPP reduce
 //   store     n_mfcc floats per frame                                  mfcc.c:219-221
 //
-// No MFMA: a 512-point FFT and a 494-non-zero mel product are not dense
+// The FFT and the 494-non-zero mel product stay on the VALU: they are not dense
 // contractions.  The bound is HBM (2048 B in + 52 B out per frame).
 #include <hip/hip_runtime.h>
 
