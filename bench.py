@@ -301,11 +301,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    # BENCH_REHEARSAL=1 (one-GPU boxes): every rank on cuda:0 and the gloo backend, to exercise the N > 1 control flow (self
+    # launch, barriers, pipelined gather, max over ranks) where no second GPU exists.  The line says so; its numbers mean nothing.
+    rehearsal = world > 1 and os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import dsp_amd
 
@@ -395,6 +403,8 @@ def main():
         line["step_calls"] = args.warmup + args.steps if args.settle <= 0 else None      # tools/traffic.py divides by this
         if c4:
             line["config4"] = c4
+        if rehearsal:
+            line["rehearsal"] = f"gloo backend, {world} ranks sharing cuda:0 -- control-flow check only, not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(600_000)
         print(json.dumps(line), flush=True)
