@@ -1558,19 +1558,6 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
         return v;
     };
     __shared__ float2 pend_buf[4][64];                       // per wavefront: (cell index, s) waiting for its log10
-    // Only cells inside a band-sum window are ever read back (sum_intense: 500 .. 7000 Hz = bins 8 .. 112, and +-0.18 s around
-    // a midpoint): time bins further than 0.21 s (the widest half range + two columns) from every midpoint, and bins outside
-    // 7 .. 113, get NaN without a log10 -- a superset of the union of the windows, so no summed cell changes.
-    __shared__ unsigned char tneed[1024];
-    if (USE_LDS) {
-        for (int t = tid; t < T; t += 256) {
-            const float tm = ((float)(t * kSpecHop + kSpecSeg / 2)) / (float)fs;
-            bool need = false;
-            for (int k = 0; k < n_mids; ++k) need = need || fabsf(tm - mids[k]) <= 0.21f;
-            tneed[t] = need ? 1 : 0;
-        }
-        __syncthreads();
-    }
     if (USE_LDS) {
         // Cells outside the widened band are NaN at once.  The others (7-18 % of a map) are queued per wavefront and
         // evaluated up to 64 at a time, so a float64 log10 is paid per ~64 candidates and not per 64 cells.
@@ -1593,8 +1580,7 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
         for (int k = 0; k < kTailPerThread; ++k) {
             const int idx = tid + 256 * k;
             const float sv = idx < cells ? map_lds[idx] : 0.0f;       // this thread's own store above
-            const int ct = idx / kSpecBins, cb = idx - ct * kSpecBins;
-            const bool cand = idx < cells && sv >= s_lo && sv <= s_hi && cb >= 7 && cb <= 113 && tneed[ct < T ? ct : 0] != 0;
+            const bool cand = idx < cells && sv >= s_lo && sv <= s_hi;
             if (idx < cells && !cand) map_lds[idx] = NAN;
             const unsigned long long m = __ballot(cand);
             if (m == 0) continue;
