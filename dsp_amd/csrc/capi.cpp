@@ -20,7 +20,7 @@
 #include "tables.hpp"
 
 #ifdef DSP_RC_STAMPS
-namespace dsp { hipError_t read_rc_stamps(unsigned long long *host, int count); }      // classify_kernels.hip, diagnostic builds
+namespace dsp { hipError_t read_rc_stamps(unsigned long long *host, int count); hipError_t read_bd_stamps(unsigned long long *host, int count); }      // classify_kernels.hip, diagnostic builds
 #endif
 
 namespace {
@@ -781,6 +781,12 @@ __attribute__((visibility("default"))) int dsp_debug_rc_stamps(unsigned long lon
 {
     DSP_HIP(hipDeviceSynchronize());
     DSP_HIP(dsp::read_rc_stamps(out, count));
+    return DSP_OK;
+}
+__attribute__((visibility("default"))) int dsp_debug_bd_stamps(unsigned long long *out, int count)
+{
+    DSP_HIP(hipDeviceSynchronize());
+    DSP_HIP(dsp::read_bd_stamps(out, count));
     return DSP_OK;
 }
 #endif

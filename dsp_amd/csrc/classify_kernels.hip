@@ -955,12 +955,19 @@ struct SpecLane {                             // per-lane constants of the 256-p
 #ifdef DSP_RC_STAMPS
 __device__ unsigned long long g_rc_stamps[8 * 2048];
 #define RC_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_rc_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_bd_stamps[8 * 2048];
+#define BD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_bd_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+hipError_t read_bd_stamps(unsigned long long *host, int count)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bd_stamps), sizeof(unsigned long long) * (size_t)count);
+}
 hipError_t read_rc_stamps(unsigned long long *host, int count)
 {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rc_stamps), sizeof(unsigned long long) * (size_t)count);
 }
 #else
 #define RC_STAMP(k) do { } while (0)
+#define BD_STAMP(k) do { } while (0)
 #endif
 
 template <int OUT, bool EVEN_B>
@@ -1514,6 +1521,7 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
     const int cells = kSpecBins * T;
     float *bp_g = sxx_bp + clip * (long)cells;
     if (tid < n_mids) mids[tid] = trace[clip].midpoints[tid];
+    BD_STAMP(0);
 
     // ---- band-pass map: dB, clip min/max, normalise, keep (0.65, 0.80)  classifier.cpp:35-80
     // to_db is monotone in the PSD value s, so the clip's dB minimum / maximum are to_db of the smallest / largest
@@ -1541,6 +1549,7 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
     smx = wave_maxf(smx);
     if ((tid & 63) == 0) { red_mn[tid >> 6] = smn; red_mx[tid >> 6] = smx; }
     __syncthreads();
+    BD_STAMP(1);
     smn = fminf(fminf(red_mn[0], red_mn[1]), fminf(red_mn[2], red_mn[3]));      // min / max are order-independent
     smx = fmaxf(fmaxf(red_mx[0], red_mx[1]), fmaxf(red_mx[2], red_mx[3]));
     // the reference starts its running min / max from +-DBL_MAX stored in floats = +-inf
@@ -1596,6 +1605,7 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
     }
     const float *bp = USE_LDS ? map_lds : bp_g;
     __syncthreads();
+    BD_STAMP(2);
     // classifier.cpp:93-114: per midpoint the three band sums, one wavefront each (the fourth idles), then the rule
     __shared__ float band[3];
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1613,6 +1623,7 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
         __syncthreads();
         if (hit) break;                                      // uniform: every thread read the same three sums
     }
+    BD_STAMP(3);
     if (tid == 0) labels[clip] = hit;
 }
 

@@ -32,3 +32,13 @@ print("ticks of s_memtime (100 MHz constant clock on gfx950: 1 tick = 10 ns), me
 for i, nm in enumerate(names):
     print(f"  {nm:28s} {np.median(d[:, i]):9.0f} {np.percentile(d[:, i], 90):9.0f}")
 print(f"  {'block total':28s} {np.median(st[:, 5] - st[:, 0]):9.0f}")
+
+buf2 = np.zeros(8 * 2048, np.uint64)
+L.dsp_debug_bd_stamps.argtypes = [C.c_void_p, C.c_int]
+assert L.dsp_debug_bd_stamps(buf2.ctypes.data, buf2.size) == 0
+st = buf2.reshape(2048, 8).astype(np.int64)
+d = np.diff(st[:, :4], axis=1)
+print("classify_bands_kernel, last clip of each of the first 2048 blocks (shader cycles, median / p90)")
+for i, nm in enumerate(["PSD load + min/max", "candidates + float64 log10", "band sums per midpoint + rule"]):
+    print(f"  {nm:32s} {np.median(d[:, i]):9.0f} {np.percentile(d[:, i], 90):9.0f}")
+print(f"  {'clip total':32s} {np.median(st[:, 3] - st[:, 0]):9.0f}")
