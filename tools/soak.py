@@ -33,7 +33,11 @@ def main():
     cases.append(("fused config 5", lambda: torch.cat([t.float().reshape(clips.shape[0], -1) for t in sj(clips, 500, fused=True)], 1)))
     x1024 = torch.rand((50_000, 1024), device="cuda", generator=gen) * 2 - 1
     p3 = dsp_amd.MfccPlan(dsp_amd.default_config(n_fft=1024, frame_length=1024, hop_length=1024, n_mels=128, prefilter=2))
-    cases.append(("config 3 (IIR + 1024)", lambda: p3.frames(x1024)))
+    cases.append(("config 3 (fused scan + 1024)", lambda: p3.frames(x1024)))
+    from dsp_amd.scrubjay import scrubjay_infer_config
+    sj2k = ScrubJay(attrs, config=scrubjay_infer_config(16000))
+    cases.append(("fused 2048/1024/40/20", lambda: torch.cat([t.float().reshape(clips.shape[0], -1) for t in sj2k(clips, 500, fused=True)], 1)))
+    mic = dsp_amd.classify_config(dsp_amd.CLASSIFY_MICROPHONE)
     cl = (torch.rand((4096, 16000), device="cuda", generator=gen) * 2 - 1) * 0.05
     # a third of the clips carry call-like patterns (midpoints; some fire the rule): the work list between the midpoints
     # and the band kernels is filled with atomics in any order, the results must not depend on it
@@ -52,7 +56,11 @@ def main():
     def cls():
         dsp_amd.classify_device(cl, lab)
         return lab.clone()
+    def cls_mic():
+        dsp_amd.classify_device(cl, lab, config=mic)
+        return lab.clone()
     cases.append(("classify", cls))
+    cases.append(("classify (microphone thresholds)", cls_mic))
     cases.append(("classify + trace (host)", cls_trace))
     bad = 0
     for name, fn in cases:
@@ -64,7 +72,7 @@ def main():
                 if not torch.equal(out, ref):
                     mism += 1
         torch.cuda.synchronize()
-        print(f"{name:24s} {n_launch} launches, mismatching checks: {mism}", flush=True)
+        print(f"{name:34s} {n_launch} launches, mismatching checks: {mism}", flush=True)
         bad += mism
     sys.exit(1 if bad else 0)
 
