@@ -266,3 +266,21 @@ def test_float64_spectrogram_vs_oracle_scipy_and_blobtimes(dsp, golden):
     ref = k["blobtimes"]
     ref = ref[ref <= tt[-1] + 1e-9]
     assert ref.size >= 10 and mine.size == ref.size and np.abs(mine - ref).max() <= 1e-6
+
+
+def test_device_batch_with_unaligned_rows(dsp, golden):
+    """Rows that are not 16-byte aligned (odd stride, base one float into a buffer): the checkpoint kernel and the recompute
+    kernel take their scalar-load paths; labels must equal the aligned batch's."""
+    import torch
+    g = golden("classifier_ref.npz")
+    base = np.stack([g[f"{n}__input"] for n in CASES])
+    want = np.array([int(g[f"{n}__label"]) for n in CASES], np.int32)
+    reps = 11
+    clips = torch.from_numpy(np.tile(base, (reps, 1))).cuda()
+    buf = torch.zeros((clips.shape[0], 16003), device="cuda")
+    view = buf[:, 1:16001]
+    view.copy_(clips)
+    assert view.stride(0) == 16003 and view.data_ptr() % 16 != 0
+    assert np.array_equal(dsp.classify_device(view).cpu().numpy(), np.tile(want, reps))
+    assert np.array_equal(dsp.classify_device(view, config=dsp.CLASSIFY_MICROPHONE).cpu().numpy(),
+                          dsp.classify_device(clips, config=dsp.CLASSIFY_MICROPHONE).cpu().numpy())
