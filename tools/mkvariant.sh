@@ -1,13 +1,10 @@
 #!/bin/bash
-# tools/mkvariant.sh NAME [extra hipcc flags...] -> variants/NAME.so (A/B builds for tools/ab.py)
+# tools/mkvariant.sh NAME [extra hipcc flags...] -> variants/NAME.so (A/B builds for tools/ab.py), same sources and flags as
+# dsp_amd/build.py plus the extra ones
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 mkdir -p "$ROOT/variants"
-cd "$ROOT/dsp_amd/csrc"
-LOG=$(mktemp)
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -Wno-unused-value \
-    -Rpass-analysis=kernel-resource-usage "$@" -o "$ROOT/variants/$NAME.so" capi.cpp capi_consumers.cpp tables.cpp mfcc_kernels.hip mfcc_row_kernel.hip mfcc1024_kernel.hip mfcc1024_wave_kernel.hip classify_kernels.hip svm_kernels.hip consumer_kernels.hip > "$LOG" 2>&1 || { grep -E "error" "$LOG" | head; rm -f "$LOG"; exit 1; }
-# resource usage of the default instantiation (reference shape, float input, tile epilogue)
-grep -A12 "Function Name: _ZN3dsp19mfcc512_wave_kernelILi4ELi10ELi3ELi512ELi0ELi1ELb0ELb0EE" "$LOG" | grep -E "VGPRs:|Occupancy \[|ScratchSize" | head -3
-rm -f "$LOG"
+cd "$ROOT"
+DSP_AMD_LIB="$ROOT/variants/$NAME.so" DSP_AMD_EXTRA_FLAGS="$*" python -m dsp_amd.build 2>&1 | grep -E "error|_ZN3dsp19mfcc512_wave_kernelILi4ELi10ELi3ELi512ELi0ELi1ELb0ELb0EE" -A 12 | grep -E "error|VGPRs:|Occupancy \[|ScratchSize" | head -4
+ls -la "$ROOT/variants/$NAME.so" | cut -c1-80
