@@ -22,6 +22,17 @@
 #include "mfcc_device.hpp"
 #include "tables.hpp"
 
+// Wave priority per phase of a frame (s_setprio, rising as the frame progresses; see mfcc_kernels.hip).  Schemes: 0 = none,
+// 1 = stages A, B at 0, C at 1, untangling at 2, mel + tile at 3,  2 = B at 1, C at 2,  3 = A, B at 1, C at 2, untangling at 3.
+// The float64 prefilter scan of the PRE variant always runs at 0.  Measured (tools/ab.py, 1 M x 1024 frames, interleaved):
+// plain kernel 1.132 -> 1.109 ms with scheme 1 (2, 3: no gain); PRE kernel (config 3) 2.99 -> 2.93 / 2.91 / 2.85 ms with 1 / 2 / 3.
+#ifndef DSP_P1024
+#define DSP_P1024 1
+#endif
+#ifndef DSP_P1024_PRE
+#define DSP_P1024_PRE 3
+#endif
+
 namespace dsp {
 
 namespace {
@@ -126,6 +137,7 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
                                                             const PrefilterScan *__restrict__ S = nullptr)
 {
     static_assert(!PRE || (FULL && !CLIPS), "the fused prefilter runs on independent 1024-sample frames");
+    constexpr int SCH = PRE ? DSP_P1024_PRE : DSP_P1024;       // wave-priority scheme
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
     while (true) {
         const long f = f_next;
         c32 v[8];
+        if (SCH) __builtin_amdgcn_s_setprio(0);
         if (PRE) {
             float xs[kScanChunk], ys[kScanChunk];
 #pragma unroll
@@ -280,6 +293,7 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
         if (more) { f_next = pre.f; load_frame8(pre.off, nxt); pre.next(); }
 
         // ---- stage A: radix-8 over a, twiddle W512^(l q) -----------------------------------------------------------
+        if (SCH == 3) __builtin_amdgcn_s_setprio(1);
         radix8w(v);
 #pragma unroll
         for (int q = 1; q < 8; ++q) v[q] = cmul(v[q], tw1[q - 1]);
@@ -295,6 +309,7 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
         }
         wave_lds_sync();
         // ---- stage B: radix-8 over l_hi, twiddle W64^(l_lo p) -----------------------------------------------------
+        if (SCH == 2) __builtin_amdgcn_s_setprio(1);
         radix8w(v);
 #pragma unroll
         for (int p = 1; p < 8; ++p) v[p] = cmul(v[p], tw2[p - 1]);
@@ -312,7 +327,11 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
         }
         wave_lds_sync();
         // ---- stage C: radix-8 over l_lo: v[r] = Z[lane + 64 r] / 2 ------------------------------------------------
+        if (SCH == 1) __builtin_amdgcn_s_setprio(1);
+        if (SCH >= 2) __builtin_amdgcn_s_setprio(2);
         radix8w(v);
+        if (SCH == 1) __builtin_amdgcn_s_setprio(2);
+        if (SCH == 3) __builtin_amdgcn_s_setprio(3);
 
         // ---- untangle + power: pairs (k, 512 - k), k = lane + 64 t, t = 0..3 ----------------------------------------
         float P[8];
@@ -341,6 +360,7 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
             pbuf[512 - lane - 64 * t] = P[2 * t + 1];
         }
         if (self_paired) pbuf[256] = p256;
+        if (SCH) __builtin_amdgcn_s_setprio(3);
         wave_lds_sync();
 
         // ---- sparse mel: two chunk slots per lane, weights in registers ---------------------------------------------

@@ -48,6 +48,30 @@
 #ifndef DSP_PREFETCH
 #define DSP_PREFETCH 2
 #endif
+// Wave priority (s_setprio 0..3) rises as a frame progresses: window + refill and the first two butterflies 0, third butterfly
+// + exchange 3 at 1, last butterfly .. power at 2, mel + tile at 3.  The SIMD's arbiter then serves the wave closest to
+// finishing its frame first ("finish what you started"): fewer frames sit half-done in the LDS queues at any time.  Measured
+// on MI355X (tools/ab.py, interleaved, 1 M frames): 0.446 -> 0.408 ms; equal priorities per phase in any other order gain
+// less (FFT high 0.424, mel + tile high 0.434, falling priorities 0.421).  Results are bit-identical (scheduling only).
+#ifndef DSP_PRIO_LOAD
+#define DSP_PRIO_LOAD 0
+#endif
+#ifndef DSP_PRIO_FFT
+#define DSP_PRIO_FFT 0
+#endif
+#ifndef DSP_PRIO_FFT2
+#define DSP_PRIO_FFT2 1
+#endif
+#ifndef DSP_PRIO_UNT
+#define DSP_PRIO_UNT 2
+#endif
+#ifndef DSP_PRIO_MEL
+#define DSP_PRIO_MEL 3
+#endif
+#ifndef DSP_PRIO_TILE
+#define DSP_PRIO_TILE 3
+#endif
+#define DSP_SETPRIO(from, to) do { if ((from) != (to)) __builtin_amdgcn_s_setprio(to); } while (0)
 
 namespace dsp {
 
@@ -415,6 +439,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         const bool last_f = lastq[rd];      // POOL: f closes its clip
         (void)clip_f; (void)last_f;
         c32 s[4];
+        DSP_SETPRIO(DSP_PRIO_TILE, DSP_PRIO_LOAD);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const c32 x = IN == 0 ? nxt[a] : unpack_pcm16<IN>(nxt[a]);
@@ -436,6 +461,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 #endif
 
         // ---- 256-point complex FFT, radix-4 DIF --------------------------------
+        DSP_SETPRIO(DSP_PRIO_LOAD, DSP_PRIO_FFT);
         radix4(s);                                             // digit a (bits 7:6)
 #pragma unroll
         for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw1[q - 1]);
@@ -479,6 +505,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         swap_lane4(s[0].x, s[1].x); swap_lane4(s[0].y, s[1].y);
         swap_lane4(s[2].x, s[3].x); swap_lane4(s[2].y, s[3].y);
 #endif
+        DSP_SETPRIO(DSP_PRIO_FFT, DSP_PRIO_FFT2);
         radix4(s);                                             // digit c (bits 3:2)
 #pragma unroll
         for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw3[q - 1]);
@@ -504,6 +531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         // ---- last butterfly, packed-real untangling, power spectrum ----------------
         // the lane with bins kap, kap+64 pairs them with 256-kap and 192-kap; both live
         // in the partner lane (slots 3 and 2).  Lane 0 (kap = 0) pairs inside itself.
+        DSP_SETPRIO(DSP_PRIO_FFT2, DSP_PRIO_UNT);
         radix4(s);                                             // digit d: s[t] = Z[64 t + kap] / 2
         c32 b, d;
 #if DSP_UNT_LDS
@@ -543,6 +571,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         pbuf[192 - kap] = P[3];
         pbuf[256 - kap] = P[1];
         if (self_paired) pbuf[128] = p128;
+        DSP_SETPRIO(DSP_PRIO_UNT, DSP_PRIO_MEL);
         wave_lds_sync();
 
         // ---- sparse mel filterbank -------------------------------------------
@@ -559,6 +588,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         for (int g = 1; g < GATHER; ++g) e += part[gat[g]];
         if (lane >= n_mels) e = 0.0f;
 
+        DSP_SETPRIO(DSP_PRIO_MEL, DSP_PRIO_TILE);
         if (TILE) {
             if ((slot & 7) == 0) { if (slot == 0) fb0 = f; else fb1 = f; }
             etile[16 * lane + (slot ^ (lane >> 2))] = e;

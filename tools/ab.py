@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--rounds", type=int, default=15)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--frame-length", type=int, default=512)
+    ap.add_argument("--n-fft", type=int, default=512)
+    ap.add_argument("--n-mels", type=int, default=40)
+    ap.add_argument("--prefilter", type=int, default=0, help="dsp_mfcc_config.prefilter (2 = 3000-7500 Hz Butterworth per frame: BASELINE config 3)")
     args = ap.parse_args()
     import torch
     from dsp_amd.lib import MfccConfig
@@ -44,6 +47,9 @@ def main():
         L.dsp_mfcc_default_config(C.byref(cfg))
         cfg.frame_length = fl
         cfg.hop_length = fl
+        cfg.n_fft = args.n_fft
+        cfg.n_mels = args.n_mels
+        cfg.prefilter = args.prefilter
         h = C.c_void_p()
         L.dsp_last_error.restype = C.c_char_p
         rc = L.dsp_mfcc_plan_create(C.byref(cfg), 0, C.byref(h))
