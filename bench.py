@@ -125,18 +125,20 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         units, unit, bytes_per = n, "frames/s", FRAME * 2 + 52
         what = f"{n} x 512-sample int16 mono frames (PCM16 ingestion in the kernel's load, SURVEY 8f-1), otherwise configs[1]"
         kernel = "mfcc512_wave_kernel<IN=1>"
-    elif args.workload == "config5":
+    elif args.workload in ("config5", "config5_2048"):
         import numpy as np
-        from dsp_amd.scrubjay import ScrubJay
+        from dsp_amd.scrubjay import ScrubJay, scrubjay_infer_config
         n = args.clips or 125_000                              # 1 M clips over 8 GPUs
         clips = torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1
         attrs = dict(np.load(os.path.join(ROOT, "tests", "golden", "scrubjay_svm.npz")))
-        sj = ScrubJay(attrs, local)
+        own = args.workload == "config5_2048"                  # scrubjay_infer.c:10-14's own framing: WIN_SIZE 2048, HOP_SIZE 1024
+        sj = ScrubJay(attrs, local, config=scrubjay_infer_config(16000)) if own else ScrubJay(attrs, local)
         step = lambda: sj(clips, 500, fused=True)              # noqa: E731
         units, unit, bytes_per = n, "clips/s", 64_000 + 8      # label + probability out
         what = (f"BASELINE configs[4] per-GPU share ({n} clips): 1 s 16 kHz fp32 clip -> MFCC(20) -> mean|std -> Scaler -> RBF-SVM "
-                "(scrubjay_svm.onnx attributes) fused in ONE kernel, one wavefront per clip; the MFCC matrix never reaches HBM")
-        kernel = "mfcc512_wave_kernel<POOL>"
+                "(scrubjay_svm.onnx attributes) fused in ONE kernel, one wavefront per clip; the MFCC matrix never reaches HBM"
+                + ("; framing of scrubjay_infer.c itself (n_fft 2048, hop 1024, 40 mel, 20 coefficients: 14 frames per clip)" if own else ""))
+        kernel = "mfcc2048_kernel<POOL>" if own else "mfcc512_wave_kernel<POOL>"
     elif args.workload == "config3":
         n = args.clips or 1_000_000
         frames = torch.rand((n, 1024), device=dev, generator=gen) * 2 - 1
@@ -146,7 +148,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         units, unit, bytes_per = n, "frames/s", 4096 + 52      # 4 148 B per frame
         what = (f"BASELINE configs[2] at {n} frames: float64 Butterworth 3000-7500 Hz per 1024-sample frame from zero state "
                 "-> Hann(1024) -> 1024-pt FFT -> 128 HTK mel -> dB -> 13 coeffs")
-        kernel = "iir_kernel<double,float> + mfcc1024_wave_kernel"
+        kernel = "mfcc1024_wave_kernel<PRE> (float64 prefilter scan fused in)"
     elif args.workload == "clips":
         n = args.clips or 12_500
         clips = torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1
@@ -170,7 +172,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         units, unit, bytes_per = n, "clips/s", 64_000 + 4
         what = (f"{n} x 1 s 16 kHz fp32 clips (25 % with a call-like burst pattern, label 1) through classify() "
                 "(2 x IIR, 2 x spectrogram, rule), bit-exact with the reference")
-        kernel = "iir2_split_kernel + spectrogram_kernel<flags> + classify_midpoints_kernel + spectrogram_kernel<frame-major> + classify_bands_kernel"
+        kernel = "iir2_ckpt_kernel + spec_from_ckpt_kernel<flags> + classify_midpoints_kernel + spec_from_ckpt_kernel<[time][bin]> + classify_bands_kernel"
     settle(step, torch, args.settle)
     for _ in range(max(1, args.warmup // 4)):
         step()
@@ -269,7 +271,7 @@ def main():
                          "steps end before the GPU's clocks have ramped (first launches after idle run 0.6 ms); reported in config")
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="all-gather the per-rank features every step (RCCL)")
-    ap.add_argument("--workload", choices=["frames", "clips", "classify", "config3", "config5", "pcm16"], default="frames",
+    ap.add_argument("--workload", choices=["frames", "clips", "classify", "config3", "config5", "config5_2048", "pcm16"], default="frames",
                     help="frames = BASELINE configs[1] (the headline metric, default); clips = configs[3] per-GPU share "
                          "(12 500 x 1 s clips, reference framing 400/160); classify = the donut classifier on 1 s clips")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step for --workload clips / classify")

@@ -81,7 +81,7 @@ struct dsp_mfcc_plan {
     dsp::RowTables512 *d_row_tables = nullptr;
     dsp::GenTables1024 *d_gen_tables = nullptr;   // n_fft = 1024
     dsp::GenTables2048 *d_tables2048 = nullptr;   // n_fft = 2048
-    int resident_blocks_2048 = 2;
+    int resident_blocks_2048 = 2, resident_blocks_2048_pool = 2;
     int resident_blocks_gen = 3;
     int gen_slots = 0;                            // mel chunk slots per lane the 1024-point tables use (<= 3: wave kernel)
     int resident_blocks_gen_wave = 2;
@@ -255,7 +255,8 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
     }
     p->n_cu = prop.multiProcessorCount;
     if (cfg->n_fft == 2048) {
-        p->resident_blocks_2048 = dsp::mfcc2048_blocks_per_cu();
+        p->resident_blocks_2048 = dsp::mfcc2048_blocks_per_cu(cfg->n_mels, false);
+        p->resident_blocks_2048_pool = dsp::mfcc2048_blocks_per_cu(cfg->n_mels, true);
     } else if (cfg->n_fft == 512) {
         p->resident_blocks_frame = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
                                                               cfg->frame_length == 512, false);
@@ -1012,7 +1013,7 @@ int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signa
     a.pool.prob1 = d_prob1;
     a.pool.feat = d_feat;
     if (p->cfg.n_fft == 2048) {      // scrubjay_infer.c's own framing (WIN_SIZE 2048, HOP_SIZE 1024): mfcc2048_kernel<POOL>
-        const int per_cu2 = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks_2048;
+        const int per_cu2 = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks_2048_pool;
         const long blocks2 = std::max(1L, std::min((long)p->n_cu * per_cu2, (n_clips + 3) / 4));
         DSP_HIP(dsp::launch_mfcc2048(a, p->d_tables2048, (int)blocks2, (hipStream_t)stream, true));
         return t;

@@ -27,11 +27,13 @@ namespace {
 constexpr int Q_ZBUF = 0;                          // 1025 x float2 image (Z[1024] = Z[0]); later P[0..1024]
 constexpr int Q_LMEL = 1025 * 8 + 8;               // 128 log-mel values
 constexpr int Q_FEAT = Q_LMEL + 128 * 4;           // POOL: 64 standardised features
-constexpr int Q_WAVE_BYTES = Q_FEAT + 64 * 4;
+constexpr int Q_PART = Q_FEAT + 64 * 4;            // partial sums of the mel segments (192) + the slot that reads 0
+constexpr int Q_WAVE_BYTES = Q_PART + 196 * 4;
 static_assert(Q_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
 constexpr int Q_W1024 = 4 * Q_WAVE_BYTES;          // block-shared: W1024^i, i < 1024
 constexpr int Q_W2048 = Q_W1024 + 1024 * 8;        // block-shared: W2048^k, k < 512
-constexpr int Q_BLOCK_BYTES = Q_W2048 + 512 * 8;
+constexpr int Q_DCT = Q_W2048 + 512 * 8;           // block-shared: dct_t[i][lane], i < ceil(n_mels / 2)
+constexpr int Q_BLOCK_BYTES = Q_DCT;               // + 256 B per DCT row, added by the launcher
 
 }  // namespace
 
@@ -49,11 +51,35 @@ __global__ __launch_bounds__(256) void mfcc2048_kernel(const Mfcc512Args args, c
     float *feat = reinterpret_cast<float *>(wl + Q_FEAT);
     float2 *w1024 = reinterpret_cast<float2 *>(smem + Q_W1024);
     float2 *w2048 = reinterpret_cast<float2 *>(smem + Q_W2048);
+    float *part = reinterpret_cast<float *>(wl + Q_PART);
+    float *dct_t = reinterpret_cast<float *>(smem + Q_DCT);
+    const int n_mels = args.n_mels, n_mfcc = args.n_mfcc;
+    const int half = (n_mels + 1) / 2;                   // log-mels per DCT lane
     for (int i = threadIdx.x; i < 1024; i += 256) w1024[i] = make_float2(G->w1024[0][i], G->w1024[1][i]);
     for (int i = threadIdx.x; i < 512; i += 256) w2048[i] = make_float2(G->w2048[0][i], G->w2048[1][i]);
+    for (int i = threadIdx.x; i < half * 64; i += 256) dct_t[i] = (&G->dct_t[0][0])[i];
+    if (lane == 0) part[k2048SegZero] = 0.0f;
     __syncthreads();
 
-    const int n_mels = args.n_mels, n_mfcc = args.n_mfcc;
+    // mel segments: this lane's three 16-bin windows and their weights stay in registers; filters lane and lane + 64 add
+    // their partial sums [s0, s0 + cnt)
+    const bool seg_ok = G->seg_ok != 0;
+    int seg_k0[k2048SegSlots];
+    float seg_w[k2048SegSlots][k2048SegTaps];
+    int mel_s0[2], mel_cnt[2];
+#pragma unroll
+    for (int c = 0; c < k2048SegSlots; ++c) {
+        seg_k0[c] = G->seg_k0[c][lane];
+#pragma unroll
+        for (int i = 0; i < k2048SegTaps; ++i) seg_w[c][i] = G->seg_w[c][i][lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = lane + 64 * i;
+        mel_s0[i] = m < n_mels ? G->mel_s0[m] : 0;
+        mel_cnt[i] = m < n_mels ? G->mel_cnt[m] : 0;
+    }
+
     const long wave = (long)blockIdx.x * 4 + wib;
     const long n_waves = (long)gridDim.x * 4;
     const unsigned amin_u = __float_as_uint(args.amin);
@@ -153,19 +179,41 @@ __global__ __launch_bounds__(256) void mfcc2048_kernel(const Mfcc512Args args, c
         wave_lds_sync();
 
         // ---- mel: lane m (and m + 64) walks filter m's run of weights in ascending bins (mfcc.c:158-164) --------------------
-        float e[2];
+        float e[2] = {0.0f, 0.0f};
         float emax = 0.0f;
+        if (seg_ok) {
+            // every lane dots its three windows (ascending bins), the filter's lane adds the pieces in ascending order
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = lane + 64 * i;
-            float acc = 0.0f;
-            if (m < n_mels) {
-                const int lo = G->mel_lo[m], len = G->mel_len[m];
-                const float *w = G->mel_w + G->mel_off[m];
-                for (int k = 0; k < len; ++k) acc = fmaf(w[k], pbuf[lo + k], acc);
+            for (int c = 0; c < k2048SegSlots; ++c) {
+                const float *rd = pbuf + seg_k0[c];
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < k2048SegTaps; ++i) acc = fmaf(seg_w[c][i], rd[i], acc);
+                part[c * 64 + lane] = acc;
             }
-            e[i] = acc;
-            emax = fmaxf(emax, acc);
+            wave_lds_sync();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && n_mels <= 64) break;
+                float acc = 0.0f;
+#pragma unroll
+                for (int g = 0; g < k2048MaxGather; ++g) acc += part[g < mel_cnt[i] ? mel_s0[i] + g : k2048SegZero];
+                e[i] = acc;
+                emax = fmaxf(emax, acc);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = lane + 64 * i;
+                float acc = 0.0f;
+                if (m < n_mels) {
+                    const int lo = G->mel_lo[m], len = G->mel_len[m];
+                    const float *w = G->mel_w + G->mel_off[m];
+                    for (int k = 0; k < len; ++k) acc = fmaf(w[k], pbuf[lo + k], acc);
+                }
+                e[i] = acc;
+                emax = fmaxf(emax, acc);
+            }
         }
         // ---- 10 log10 with per-frame reference (mfcc.c:169-206), one log of the ratio --------------------------------------
         const float ref = __uint_as_float(max(__float_as_uint(wave_max_nonneg(emax)), amin_u));
@@ -175,20 +223,18 @@ __global__ __launch_bounds__(256) void mfcc2048_kernel(const Mfcc512Args args, c
             const float ec = __uint_as_float(max(__float_as_uint(e[i]), amin_u));
             float db = 3.01029995663981195f * __builtin_amdgcn_logf(ec * inv);
             db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f);
-            lmel[lane + 64 * i] = (lane + 64 * i < n_mels) ? db : 0.0f;
+            lmel[lane + 64 * i] = (lane + 64 * i < n_mels) ? db : 0.0f;          // 128 slots: the DCT may read up to 2 half <= n_mels + 1
         }
         wave_lds_sync();
 
-        // ---- DCT-II: lane 2 c + h dots log-mels [64 h, 64 h + 64) with row c ---------------------------------------------------
+        // ---- DCT-II: lane 2 c + h dots log-mels [h half, h half + half) with its column of the LDS copy of dct_t -------------
         float coef;
         {
             const int c = lane >> 1, h = lane & 1;
+            const float *lm = lmel + h * half;
             float acc = 0.0f;
-            if (c < n_mfcc) {
-                const float *row = &G->dct[c][64 * h];
-                const int cnt = n_mels - 64 * h < 64 ? n_mels - 64 * h : 64;
-                for (int m = 0; m < cnt; ++m) acc = fmaf(row[m], lmel[64 * h + m], acc);
-            }
+#pragma unroll 4
+            for (int m = 0; m < half; ++m) acc = fmaf(dct_t[m * 64 + lane], lm[m], acc);     // rows past n_mels / n_mfcc hold 0
             acc += dpp<DPP_QUAD_1032>(acc);
             coef = acc;
             if (!POOL && h == 0 && c < n_mfcc) args.out[f * n_mfcc + c] = acc;
@@ -244,10 +290,13 @@ __global__ __launch_bounds__(256) void mfcc2048_kernel(const Mfcc512Args args, c
     }
 }
 
+static size_t lds_bytes_2048(int n_mels) { return (size_t)Q_BLOCK_BYTES + (size_t)((n_mels + 1) / 2) * 256; }
+
 hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables, int blocks, hipStream_t stream, bool pool)
 {
     const bool clips = args.frames_per_clip > 0;
     const dim3 g(blocks), b(256);
+    const size_t Q_BLOCK_BYTES = lds_bytes_2048(args.n_mels);
     if (pool) {
         if (!clips || args.chunk != args.frames_per_clip || !args.pool.labels || args.pool.svm.n_features != 2 * args.n_mfcc ||
             args.pool.svm.n_features > 64)
@@ -261,10 +310,11 @@ hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables,
     return hipGetLastError();
 }
 
-int mfcc2048_blocks_per_cu()
+int mfcc2048_blocks_per_cu(int n_mels, bool pool)
 {
     int n = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<false, false>, 256, Q_BLOCK_BYTES);
+    hipError_t e = pool ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<true, true>, 256, lds_bytes_2048(n_mels))
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<false, false>, 256, lds_bytes_2048(n_mels));
     return e == hipSuccess && n > 0 ? n : 2;
 }
 

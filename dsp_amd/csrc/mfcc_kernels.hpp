@@ -66,7 +66,7 @@ int mfcc512_lds_bytes_per_block(bool tile);
 // n_fft = 2048 (mfcc2048_kernel.hip); pool: the fused clip -> label form (args.chunk == args.frames_per_clip, args.pool set)
 struct GenTables2048;
 hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables, int blocks, hipStream_t stream, bool pool);
-int mfcc2048_blocks_per_cu();
+int mfcc2048_blocks_per_cu(int n_mels, bool pool);
 int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full, bool tile);
 
 }  // namespace dsp

@@ -130,6 +130,34 @@ bool build_gen_tables_2048(const dsp_mfcc_config &cfg, GenTables2048 &t, std::st
     const std::vector<float> dct = make_dct_ortho(cfg.n_mfcc, cfg.n_mels);
     for (int c = 0; c < cfg.n_mfcc; ++c)
         for (int m = 0; m < cfg.n_mels; ++m) t.dct[c][m] = dct[(size_t)c * cfg.n_mels + m];
+    const int half = (cfg.n_mels + 1) / 2;
+    for (int l = 0; l < kLanes; ++l) {
+        const int c = l >> 1, h = l & 1;
+        for (int i = 0; i < half; ++i) {
+            const int m = h * half + i;
+            t.dct_t[i][l] = (c < cfg.n_mfcc && m < cfg.n_mels) ? t.dct[c][m] : 0.0f;
+        }
+    }
+    // segments: filter m's run [lo, lo + len) in pieces of <= 16 bins, numbered consecutively
+    int n_seg = 0;
+    bool ok = true;
+    for (int m = 0; m < cfg.n_mels && ok; ++m) {
+        const int len = t.mel_len[m], pieces = (len + k2048SegTaps - 1) / k2048SegTaps;
+        t.mel_s0[m] = n_seg;
+        t.mel_cnt[m] = pieces;
+        if (pieces > k2048MaxGather || n_seg + pieces > k2048SegSlots * kLanes) { ok = false; break; }
+        for (int g = 0; g < pieces; ++g, ++n_seg) {
+            const int first = t.mel_lo[m] + g * k2048SegTaps, cnt = std::min(k2048SegTaps, len - g * k2048SegTaps);
+            const int k0 = std::min(first, n_bins - k2048SegTaps);            // the 16-bin window stays inside P[0 .. 1024]
+            const int slot = n_seg / kLanes, lane = n_seg % kLanes;
+            t.seg_k0[slot][lane] = k0;
+            for (int j = 0; j < k2048SegTaps; ++j) {
+                const int kk = k0 + j;
+                t.seg_w[slot][j][lane] = (kk >= first && kk < first + cnt) ? fb[(size_t)m * n_bins + kk] : 0.0f;
+            }
+        }
+    }
+    t.seg_ok = ok ? 1 : 0;
     return true;
 }
 

@@ -108,6 +108,8 @@ bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::st
 // Tables of mfcc2048_kernel.hip: window per lane, twiddle tables, the mel filterbank as one run of non-zero weights per filter
 // (CSR), the DCT rows.
 constexpr int k2048MaxMels = 128, k2048MaxMfcc = 32, k2048MaxWeights = 4096;
+constexpr int k2048SegTaps = 16, k2048SegSlots = 3, k2048MaxGather = 12;   // mel product in segments of <= 16 bins, <= 12 per filter
+constexpr int k2048SegZero = k2048SegSlots * kLanes;                       // partial slot that always reads 0
 struct GenTables2048 {
     float win[32][kLanes];                 // x0.5 window for samples 2(l+64a), 2(l+64a)+1 at [2a], [2a+1], a < 16
     float w1024[2][1024];                  // W1024^i (cos, sin): stage twiddles of the 1024-point complex FFT
@@ -116,6 +118,16 @@ struct GenTables2048 {
     float mel_w[k2048MaxWeights];
     float dct[k2048MaxMfcc][k2048MaxMels]; // DCT-II rows
     int32_t n_mels, n_mfcc;
+    // the same filterbank cut into segments of <= 16 consecutive bins, one per (slot, lane): lane l of slot s dots
+    // P[seg_k0 .. seg_k0 + 16) with seg_w; filter m then adds its partial sums [mel_s0, mel_s0 + mel_cnt) in ascending order.
+    // seg_ok = 0 when the bank does not fit 192 segments / 12 per filter: the kernel walks the CSR rows above instead.
+    int32_t seg_ok;
+    int32_t seg_k0[k2048SegSlots][kLanes];
+    float seg_w[k2048SegSlots][k2048SegTaps][kLanes];
+    int32_t mel_s0[k2048MaxMels], mel_cnt[k2048MaxMels];
+    // DCT rows as the kernel's lanes read them: lane 2 c + h dots log-mels [h half, h half + half), half = ceil(n_mels / 2),
+    // with dct_t[i][lane] = D[c][h half + i] (0 past the row / past n_mfcc)
+    float dct_t[(k2048MaxMels + 1) / 2][kLanes];
 };
 bool build_gen_tables_2048(const dsp_mfcc_config &cfg, GenTables2048 &t, std::string &why);
 
