@@ -24,8 +24,35 @@ namespace dsp {
 
 namespace {
 
-constexpr int Q_ZBUF = 0;                          // 1025 x float2 image (Z[1024] = Z[0]); later P[0..1024]
-constexpr int Q_LMEL = 1025 * 8 + 8;               // 128 log-mel values
+constexpr int Q_ZBUF = 0;                          // 1025 x float2 image (Z[1024] = Z[0]), one float2 of padding every 16; later P[0..1024]
+constexpr int Q_LMEL = 1092 * 8;                   // 128 log-mel values
+__device__ __forceinline__ constexpr int ZI(int i) { return i + (i >> 4); }           // padded index into the image
+
+// forward 16-point DFT in place as 4 x 4 (input t = 4 t1 + t2): position p = 4 q1 + q2 ends up holding X[q1 + 4 q2] = X[r16_out(p)]
+__device__ __forceinline__ constexpr int r16_out(int p) { return (p >> 2) + 4 * (p & 3); }
+__device__ __forceinline__ void radix16(c32 (&v)[16])
+{
+#pragma unroll
+    for (int t2 = 0; t2 < 4; ++t2) {                // DFT over t1 for each t2 -> A[t2][q1] at v[4 q1 + t2]
+        c32 u[4] = {v[t2], v[4 + t2], v[8 + t2], v[12 + t2]};
+        radix4(u);
+#pragma unroll
+        for (int q1 = 0; q1 < 4; ++q1) v[4 * q1 + t2] = u[q1];
+    }
+    // W16^(t2 q1) = exp(-2 pi i t2 q1 / 16)
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+    constexpr c32 W1 = {C1, -S1}, W2 = {R2, -R2}, W3 = {S1, -C1}, W6 = {-R2, -R2}, W9 = {-C1, S1};
+    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], W1); v[4 * 1 + 2] = cmul(v[4 * 1 + 2], W2); v[4 * 1 + 3] = cmul(v[4 * 1 + 3], W3);
+    v[4 * 2 + 1] = cmul(v[4 * 2 + 1], W2); v[4 * 2 + 2] = cmul_mi(v[4 * 2 + 2]);   v[4 * 2 + 3] = cmul(v[4 * 2 + 3], W6);
+    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], W3); v[4 * 3 + 2] = cmul(v[4 * 3 + 2], W6); v[4 * 3 + 3] = cmul(v[4 * 3 + 3], W9);
+#pragma unroll
+    for (int q1 = 0; q1 < 4; ++q1) {                // DFT over t2 for each q1 -> X[q1 + 4 q2] at v[4 q1 + q2]
+        c32 u[4] = {v[4 * q1], v[4 * q1 + 1], v[4 * q1 + 2], v[4 * q1 + 3]};
+        radix4(u);
+#pragma unroll
+        for (int q2 = 0; q2 < 4; ++q2) v[4 * q1 + q2] = u[q2];
+    }
+}
 constexpr int Q_FEAT = Q_LMEL + 128 * 4;           // POOL: 64 standardised features
 constexpr int Q_PART = Q_FEAT + 64 * 4;            // partial sums of the mel segments (192) + the slot that reads 0
 constexpr int Q_WAVE_BYTES = Q_PART + 196 * 4;
@@ -38,7 +65,7 @@ constexpr int Q_BLOCK_BYTES = Q_DCT;               // + 256 B per DCT row, added
 }  // namespace
 
 template <bool CLIPS, bool POOL>
-__global__ __launch_bounds__(256) void mfcc2048_kernel(const Mfcc512Args args, const GenTables2048 *__restrict__ G)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mfcc2048_kernel(const Mfcc512Args args, const GenTables2048 *__restrict__ G)
 {
     static_assert(!POOL || CLIPS, "pooling is per clip");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,40 +145,59 @@ __global__ __launch_bounds__(256) void mfcc2048_kernel(const Mfcc512Args args, c
             v[a] = {x0 * G->win[2 * a][lane], x1 * G->win[2 * a + 1][lane]};
         }
 
-        // ---- 1024-point complex FFT: radix-4 Stockham, 5 stages ----------------------------------------------------------
-        // stage s (Ns = 4^s), butterfly j = lane + 64 m: k = j % Ns; inputs x[j + 256 t] W_{4 Ns}^(t k); outputs y[(j - k) 4 + k + q Ns]
+        // ---- 1024-point complex FFT: Stockham autosort as 16 x 16 x 4, three passes through the wave's LDS image -------------
+        // pass with Ns points done, butterfly j: k = j % Ns, inputs x[j + (1024 / R) t] W_{R Ns}^(t k), outputs y[(j - k) R + k + q Ns].
+        // The image is padded by one float2 every 16 (ZI): the stride-16 stores of the radix-16 passes would otherwise all land in
+        // one bank pair.
+        {
+            // pass 0: R = 16, Ns = 1: butterfly j = lane takes the 16 points this lane loaded, no twiddles
+            radix16(v);
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {
-            const int Ns = 1 << (2 * s);
-            if (s > 0) {
+            for (int p = 0; p < 16; ++p) zbuf[ZI(16 * lane + r16_out(p))] = make_float2(v[p].x, v[p].y);
+            wave_lds_sync();
+            // pass 1: R = 16, Ns = 16: k = lane % 16, twiddles W_256^(t k) = W_1024^(4 t k)
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float2 x = zbuf[lane + 64 * m + 256 * t];
-                        v[m + 4 * t] = {x.x, x.y};
-                    }
-                wave_lds_sync();
+            for (int t = 0; t < 16; ++t) {
+                const float2 x = zbuf[ZI(lane + 64 * t)];
+                v[t] = {x.x, x.y};
             }
+            wave_lds_sync();
+            const int k = lane & 15;
+#pragma unroll
+            for (int t = 1; t < 16; ++t) {
+                const float2 w = w1024[4 * t * k];
+                v[t] = cmul(v[t], c32{w.x, w.y});
+            }
+            radix16(v);
+            const int base = 16 * (lane - k) + k;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) zbuf[ZI(base + 16 * r16_out(p))] = make_float2(v[p].x, v[p].y);
+            wave_lds_sync();
+            // pass 2: R = 4, Ns = 256: four butterflies per lane, j = lane + 64 m = k, outputs y[j + 256 q]: natural order
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float2 x = zbuf[ZI(lane + 64 * m + 256 * t)];
+                    v[m + 4 * t] = {x.x, x.y};
+                }
+            wave_lds_sync();
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int j = lane + 64 * m, k = j & (Ns - 1);
+                const int j = lane + 64 * m;
                 c32 u[4] = {v[m], v[m + 4], v[m + 8], v[m + 12]};
-                if (s > 0) {
 #pragma unroll
-                    for (int t = 1; t < 4; ++t) {
-                        const float2 w = w1024[(t * k * (256 / Ns)) & 1023];
-                        u[t] = cmul(u[t], c32{w.x, w.y});
-                    }
+                for (int t = 1; t < 4; ++t) {
+                    const float2 w = w1024[(t * j) & 1023];
+                    u[t] = cmul(u[t], c32{w.x, w.y});
                 }
                 radix4(u);
-                const int j0 = (j - k) * 4 + k;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) zbuf[j0 + q * Ns] = make_float2(u[q].x, u[q].y);
+                for (int q = 0; q < 4; ++q) zbuf[ZI(j + 256 * q)] = make_float2(u[q].x, u[q].y);
             }
             wave_lds_sync();
         }
-        if (lane == 0) zbuf[1024] = zbuf[0];                 // natural order now; Z[1024] = Z[0] for the pairing below
+        if (lane == 0) zbuf[ZI(1024)] = zbuf[ZI(0)];         // natural order now; Z[1024] = Z[0] for the pairing below
         wave_lds_sync();
 
         // ---- untangle: bins k = l + 64 t (t < 8) with 1024 - k; bin 512 alone -------------------------------------------------
@@ -159,7 +205,7 @@ __global__ __launch_bounds__(256) void mfcc2048_kernel(const Mfcc512Args args, c
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int k = lane + 64 * t;
-            const float2 a = zbuf[k], b = zbuf[1024 - k], w = w2048[k];
+            const float2 a = zbuf[ZI(k)], b = zbuf[ZI(1024 - k)], w = w2048[k];
             const c32 E = {a.x + b.x, a.y - b.y};
             const c32 O = {a.x - b.x, a.y + b.y};
             const c32 Tw = cmul(O, c32{w.x, w.y});
@@ -168,7 +214,7 @@ __global__ __launch_bounds__(256) void mfcc2048_kernel(const Mfcc512Args args, c
             P[2 * t] = xr * xr + xi * xi;
             P[2 * t + 1] = mr * mr + mi * mi;
         }
-        const float2 zm = zbuf[512];
+        const float2 zm = zbuf[ZI(512)];
         wave_lds_sync();
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
