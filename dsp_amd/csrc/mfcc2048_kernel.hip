@@ -3,17 +3,21 @@
 // kernels (reference 2fa/audio/word/c/mfcc.c:142-221 with the constants as parameters), one 64-lane wavefront per frame:
 //
 //   load      16 x global_load_dwordx2 per lane: z[l + 64 a] = x[2n] + i x[2n+1] (zero padded past frame_length), x window / 2
-//   FFT       2048-point real FFT as a 1024-point complex radix-4 Stockham autosort, 5 stages, 4 butterflies per lane and
-//             stage through an 8 KB per-wave LDS image, twiddles from a block-shared LDS table
+//   FFT       2048-point real FFT as a 1024-point complex Stockham autosort in three passes, 16 x 16 x 4 (a radix-16 butterfly
+//             per lane, then four radix-4 ones), through an 8.5 KB padded per-wave LDS image, twiddles from a block-shared LDS table
 //   untangle  bins k = l + 64 t (t < 8) with 1024 - k; power spectrum P[0..1024] to LDS
-//   mel       one lane per filter (two for n_mels > 64) walks its run of non-zero weights in ascending bins
+//   mel       every lane dots three 16-bin segments of the filters' runs (weights in registers), the filter's lane adds its
+//             segments in ascending order; banks that do not fit 192 segments fall back to one lane per filter (CSR walk)
 //   log       per-frame reference = max, amin, top_db (mfcc.c:169-206)
-//   DCT-II    two lanes per coefficient (<= 32 coefficients), halves of the log-mel vector each
+//   DCT-II    two lanes per coefficient (<= 32 coefficients), halves of the log-mel vector each, rows from a block-shared LDS copy
 //   POOL      instead of storing the coefficients: per-clip mean | std in float64, frame order (scrubjay_infer.c:36-66), then
 //             Scaler -> RBF-SVM -> libsvm's label / probability (svm_kernels.hpp), one wavefront walks one clip
 //
-// Generality first: this shape exists so that the fused clip -> label path can run scrubjay_infer.c's own parameterisation;
-// the tuned kernels are the 512- and 1024-point ones.
+// This shape exists so that the fused clip -> label path can run scrubjay_infer.c's own parameterisation.  Round 2 tuned the
+// obvious: the mel product in 16-bin segments on all 64 lanes with the weights in registers (a lane-per-filter walk of up to
+// 135 weights from global memory took 30 % of the kernel), the DCT rows from LDS, three 16 x 16 x 4 passes instead of five
+// radix-4 ones: 10.4 -> 5.75 ms per 125 000 one-second clips (fused), 1.14 -> 0.82 ms per 250 000 plain frames.  Rising wave
+// priorities (mfcc_kernels.hip) were tried here too and lose 1.5 % at two waves per SIMD.
 #include <hip/hip_runtime.h>
 
 #include "mfcc_device.hpp"
@@ -59,7 +63,8 @@ constexpr int Q_WAVE_BYTES = Q_PART + 196 * 4;
 static_assert(Q_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
 constexpr int Q_W1024 = 4 * Q_WAVE_BYTES;          // block-shared: W1024^i, i < 1024
 constexpr int Q_W2048 = Q_W1024 + 1024 * 8;        // block-shared: W2048^k, k < 512
-constexpr int Q_DCT = Q_W2048 + 512 * 8;           // block-shared: dct_t[i][lane], i < ceil(n_mels / 2)
+constexpr int Q_WIN = Q_W2048 + 512 * 8;           // block-shared: window pairs (win[2a][l], win[2a+1][l]) at [a][l]
+constexpr int Q_DCT = Q_WIN + 16 * 64 * 8;         // block-shared: dct_t[i][lane], i < ceil(n_mels / 2)
 constexpr int Q_BLOCK_BYTES = Q_DCT;               // + 256 B per DCT row, added by the launcher
 
 }  // namespace
@@ -80,11 +85,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     float2 *w2048 = reinterpret_cast<float2 *>(smem + Q_W2048);
     float *part = reinterpret_cast<float *>(wl + Q_PART);
     float *dct_t = reinterpret_cast<float *>(smem + Q_DCT);
+    float2 *win2 = reinterpret_cast<float2 *>(smem + Q_WIN);
     const int n_mels = args.n_mels, n_mfcc = args.n_mfcc;
     const int half = (n_mels + 1) / 2;                   // log-mels per DCT lane
     for (int i = threadIdx.x; i < 1024; i += 256) w1024[i] = make_float2(G->w1024[0][i], G->w1024[1][i]);
     for (int i = threadIdx.x; i < 512; i += 256) w2048[i] = make_float2(G->w2048[0][i], G->w2048[1][i]);
     for (int i = threadIdx.x; i < half * 64; i += 256) dct_t[i] = (&G->dct_t[0][0])[i];
+    // the window through LDS pays in the fused clip kernel (+4 %) and costs the plain one dearly (0.82 -> 1.34 ms per 250 000
+    // frames, measured): it stays a global (L1) read there
+    constexpr bool WIN_LDS = POOL;
+    if (WIN_LDS)
+        for (int i = threadIdx.x; i < 16 * 64; i += 256) win2[i] = make_float2(G->win[2 * (i >> 6)][i & 63], G->win[2 * (i >> 6) + 1][i & 63]);
     if (lane == 0) part[k2048SegZero] = 0.0f;
     __syncthreads();
 
@@ -142,7 +153,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             } else if (i < frame_len) {
                 x0 = src[i];
             }
-            v[a] = {x0 * G->win[2 * a][lane], x1 * G->win[2 * a + 1][lane]};
+            if (WIN_LDS) {
+                const float2 w = win2[64 * a + lane];
+                v[a] = {x0 * w.x, x1 * w.y};
+            } else {
+                v[a] = {x0 * G->win[2 * a][lane], x1 * G->win[2 * a + 1][lane]};
+            }
         }
 
         // ---- 1024-point complex FFT: Stockham autosort as 16 x 16 x 4, three passes through the wave's LDS image -------------
