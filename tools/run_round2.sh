@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/round_$TAG; mkdir -p $OUT
 cd $R
 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; tail -5 $OUT/tests.log
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-300 $OUT/bench.json
-for w in clips config3 config5 classify pcm16; do
+for w in clips config3 config5 config5_2048 classify pcm16; do
     python bench.py --workload $w --no-cpu-baseline --steps 50 >> $OUT/side_workloads.jsonl 2>> $OUT/side.err
 done
 cut -c1-120 $OUT/side_workloads.jsonl
