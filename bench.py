@@ -367,7 +367,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    c4 = None if args.no_config4 else config4(args, torch, dist, dsp_amd, dev, local, rank, world, sync)
+    # the headline above is measured; a failure in the secondary config-4 leg must not cost the line
+    c4 = None
+    if not args.no_config4:
+        try:
+            c4 = config4(args, torch, dist, dsp_amd, dev, local, rank, world, sync)
+        except Exception as exc:  # noqa: BLE001
+            c4 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     if rank == 0:
         total_frames = world * n * args.steps
