@@ -62,3 +62,34 @@ def test_random_configurations_match_the_oracle(n_fft):
             gate(out[i], ref, f"fuzz n_fft {n_fft} #{it} clip{i} {over}")
         ran += 1
     assert ran >= 7, f"only {ran} of {ran + refused} random configurations ran"
+
+
+def test_random_clip_lengths_through_classify_match_the_oracle():
+    """classify() on batches of random length (odd lengths, lengths that are no multiple of the 32-sample tiles or the 224-sample
+    spectrogram hop, 0.1 s .. 2.4 s) built from shifted pieces of the call-like patterns over noise: labels, midpoints and band
+    sums against the oracle, bit exact."""
+    import dsp_amd
+    from oracle import oracle as O
+    rng = np.random.default_rng(4104)
+    c = S.classify_cases()
+    calls = [c["scrub_a"], c["scrub_b"], c["jay_like"], c["burst_2k"]]
+    with_mids = hits = 0
+    for it in range(12):
+        n = int(rng.integers(1600, 38400))
+        clips = np.empty((6, n), np.float32)
+        for i in range(6):
+            x = rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-3.0, -1.0)
+            call = np.tile(calls[int(rng.integers(0, 4))], 3)[int(rng.integers(0, 16000)):][:n].astype(np.float64)
+            if i % 3 != 2:
+                x[:call.size] += call * 10.0 ** rng.uniform(-1.0, 0.2)
+            clips[i] = x.astype(np.float32)
+        labels, trace = dsp_amd.classify_batch(clips, with_trace=True)
+        for x, lab, (mids, sums) in zip(clips, labels, trace):
+            olab, _, osums = O.classify(x)
+            omids = O.find_midpoints(x)
+            assert lab == olab, (it, n)
+            assert np.array_equal(mids, omids), (it, n)
+            assert np.array_equal(sums, osums), (it, n)
+            with_mids += len(omids) > 0
+            hits += int(olab)
+    assert with_mids >= 12 and hits >= 3, (with_mids, hits)      # the draws exercise the midpoint and the rule paths
