@@ -66,18 +66,21 @@ class GatherPipeline:
     order of issue relative to the next batch's kernels changes.  Every rank contributes exactly rows_per_rank rows
     (all_gather needs equal counts: pad the short last shard, see gather_features)."""
 
-    def __init__(self, rows_per_rank: int, row_shape, dtype, device, group=None, depth: int = 2):
+    def __init__(self, rows_per_rank: int, row_shape, dtype, device, group=None, depth: int = 2, always_collective: bool = False):
+        """always_collective: issue the all-gather even in a one-rank group (a copy through the backend): lets a one-GPU box
+        exercise the RCCL path itself -- communicator, the backend's stream, Work.wait() -- which world == 1 otherwise skips."""
         import torch
         import torch.distributed as dist
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (always_collective and dist.is_initialized())
         self.depth = depth
         shape = (rows_per_rank,) + tuple(row_shape)
         self.local = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
         # world == 1: nothing to gather, the local block IS the result
-        self.gathered = [torch.empty((self.world * rows_per_rank,) + tuple(row_shape), dtype=dtype, device=device) if self.world > 1
+        self.gathered = [torch.empty((self.world * rows_per_rank,) + tuple(row_shape), dtype=dtype, device=device) if self.collective
                          else self.local[i] for i in range(depth)]
         self.work = [None] * depth
         self.k = 0
@@ -89,7 +92,7 @@ class GatherPipeline:
         slot = self.k % self.depth
         self._wait(slot)                                   # the gather that last read local[slot] / wrote gathered[slot]
         compute(self.local[slot])
-        if self.world > 1:
+        if self.collective:
             self.work[slot] = dist.all_gather_into_tensor(self.gathered[slot], self.local[slot], group=self.group, async_op=True)
         self.k += 1
         return slot

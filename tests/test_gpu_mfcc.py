@@ -6,6 +6,8 @@ Gate (tests/conftest.py gate()): the PURE |gpu - ref| <= 1e-4 * max(|ref|, ||ref
 of 3e-4 is granted only to named low-level cases, for frames with ||ref||_inf < 3 (where the reference's own noise
 exceeds the pure gate).  Every comparison's worst ratio goes to gpurun_out/gate_report.json.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -379,3 +381,43 @@ def test_config3_fused_prefilter_equals_the_two_pass_path(dsp, torch_cuda, monke
         y = torch.empty(1024 * n + 2, device="cuda")[2:].view(n, 1024)
         y.copy_(x)
         assert np.array_equal(plan.frames(y).cpu().numpy(), two)
+
+
+def test_gather_pipeline_through_rccl_on_one_rank():
+    """The pipelined all-gather of BASELINE config 4 through the real backend ("nccl" = RCCL) in a one-rank group: what a
+    one-GPU box can check of the N > 1 path beyond the gloo tests -- communicator creation, the collective on the backend's
+    stream behind the MFCC kernel of the same batch, Work.wait() as a stream dependency, slot reuse at depth 2.  Runs in a
+    child process (one process group per process)."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, socket
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.getcwd())
+import dsp_amd
+from dsp_amd.dist import GatherPipeline
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+plan = dsp_amd.MfccPlan(dsp_amd.default_config())
+gen = torch.Generator(device="cuda").manual_seed(5)
+batches = [torch.rand((64, 16000), device="cuda", generator=gen) * 2 - 1 for _ in range(5)]
+want = [plan.clips(b, 500).clone() for b in batches]
+pipe = GatherPipeline(64, (98, 13), torch.float32, torch.device("cuda", 0), always_collective=True)
+assert pipe.collective and pipe.gathered[0] is not pipe.local[0]
+slots, got = [], []
+for k, b in enumerate(batches):
+    slots.append(pipe.submit(lambda block, b=b: plan.clips(b, 500, block)))
+    if k >= 1:                                   # consume batch k - 1 while batch k's gather is in flight
+        got.append(pipe.result(slots[k - 1]).clone())
+got.append(pipe.result(slots[-1]).clone())
+pipe.drain()
+torch.cuda.synchronize()
+for g, w in zip(got, want):
+    assert torch.equal(g, w)
+dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    assert "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
