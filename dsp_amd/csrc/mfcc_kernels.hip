@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
     float dctw[(DCT_LEN + 3) & ~3];
     // the MFMA A operand stays in registers for the reference's shape (10 VGPRs); larger shapes read it from a block-shared
     // LDS copy (once per 16 frames; a global re-read sat latency-exposed in the rolled k loop) to stay within 128 VGPRs
-    constexpr bool A_IN_REGS = CT * KS <= 10;
+    constexpr bool A_IN_REGS = CT * KS <= 10 && !POOL;      // POOL: the pooling epilogue needs the ten registers (no spills)
     float dcta[CT][KS];
     float *a_lds = reinterpret_cast<float *>(smem + 4 * WAVE_BYTES);
     (void)a_lds;
@@ -670,7 +670,7 @@ template <int S, int L>
 static size_t lds_bytes(bool tile, bool pool = false)
 {
     constexpr int KS = S == 2 ? L / 2 : L, CT = S == 2 ? 2 : 1;
-    return (size_t)4 * (LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0) + (pool ? LDS_POOL_BYTES : 0)) + (tile && CT * KS > 10 ? (size_t)CT * KS * 64 * 4 : 0);
+    return (size_t)4 * (LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0) + (pool ? LDS_POOL_BYTES : 0)) + (tile && (CT * KS > 10 || pool) ? (size_t)CT * KS * 64 * 4 : 0);
 }
 
 template <int S, int L, int G>

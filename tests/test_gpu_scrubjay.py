@@ -217,3 +217,37 @@ def test_n_fft_2048_scrubjay_infer_framing(golden):
         assert abs(float(b[1][i]) - odec) <= 2e-5 * max(1.0, abs(odec)) and _prob_close(float(b[2][i]), op1)[0]
         if abs(odec) > 1e-5:
             assert int(b[0][i]) == lab
+
+
+@pytest.mark.parametrize("n_mfcc,n_mels,fmax", [(13, 40, 8000.0), (16, 64, 3000.0), (8, 24, 8000.0)])
+def test_fused_kernel_at_other_coefficient_counts(n_mfcc, n_mels, fmax):
+    """The fused clip -> label kernel is instantiated per DCT shape; shapes with at most 16 coefficients take other
+    instantiations (one coefficient tile) than config 5's 20.  A synthetic RBF model of 2 n_mfcc features: fused equals the
+    three-kernel path bit for bit, and the pooled features equal the oracle's mfcc_stats of the oracle-gated MFCC."""
+    import torch
+    import dsp_amd
+    from dsp_amd import scrubjay
+    from oracle import oracle as O
+    from tests.conftest import gate
+    rng = np.random.default_rng(100 + n_mfcc)
+    nf, nsv = 2 * n_mfcc, 37
+    attrs = dict(offset=rng.normal(0, 5, nf).astype(np.float32), scale=(1.0 / rng.uniform(2, 20, nf)).astype(np.float32),
+                 sv=rng.normal(0, 1, (nsv, nf)).astype(np.float32), coef=rng.normal(0, 1, nsv).astype(np.float32),
+                 kernel_params=np.array([0.03, 0.0, 3.0], np.float32), rho=np.array([0.1], np.float32),
+                 prob_a=np.array([-2.0], np.float32), prob_b=np.array([0.05], np.float32), vectors_per_class=np.array([20, 17], np.int64))
+    cfg = dsp_amd.default_config(n_mfcc=n_mfcc, n_mels=n_mels, fmax=fmax)       # 64 filters fit the 64 chunk lanes only below ~3 kHz
+    sj = scrubjay.ScrubJay(attrs, config=cfg)
+    gen = torch.Generator(device="cuda").manual_seed(23 + n_mfcc)
+    clips = torch.rand((70, 16000), device="cuda", generator=gen) * 2 - 1
+    clips[::4] *= 0.003
+    clips[5] = 0.0
+    a = sj(clips, fused=False)
+    b = sj(clips, fused=True)
+    for i in range(4):
+        assert torch.equal(a[i], b[i]), i
+    ocfg = O.default_cfg(n_mfcc=n_mfcc, n_mels=n_mels, fmax=fmax)
+    x = clips[:3].cpu().numpy()
+    feats = b[3].cpu().numpy()
+    for i in range(3):
+        ref = O.mfcc_stats(O.compute_mfcc(x[i], 500, ocfg))
+        gate(feats[i][None, :], ref[None, :], f"fused n_mfcc {n_mfcc} / {n_mels} mel pooled features clip{i}")
