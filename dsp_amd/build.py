@@ -8,7 +8,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.environ.get("DSP_AMD_LIB") or os.path.join(PKG, "libdsp_amd.so")
-SOURCES = ["capi.cpp", "capi_consumers.cpp", "capi_classifier_cxx.cpp", "tables.cpp", "mfcc_kernels.hip", "mfcc_row_kernel.hip", "mfcc1024_kernel.hip", "mfcc1024_wave_kernel.hip", "mfcc2048_kernel.hip", "classify_kernels.hip",
+SOURCES = ["capi.cpp", "capi_consumers.cpp", "capi_classifier_cxx.cpp", "tables.cpp", "mfcc_kernels.hip", "mfcc_row_kernel.hip", "mfcc512_pair_kernel.hip", "mfcc1024_kernel.hip", "mfcc1024_wave_kernel.hip", "mfcc2048_kernel.hip", "classify_kernels.hip",
            "svm_kernels.hip", "consumer_kernels.hip"]
 HEADERS = ["exports.map", "tables.hpp", "mfcc_kernels.hpp", "mfcc_device.hpp", "classify_kernels.hpp", "svm_kernels.hpp", "consumer_kernels.hpp", "capi_util.hpp",
            os.path.join("..", "..", "include", "dsp_amd.h"), os.path.join("..", "..", "include", "dsp_amd_classifier.h")]

@@ -81,6 +81,8 @@ struct dsp_mfcc_plan {
     dsp::RowTables512 *d_row_tables = nullptr;
     dsp::GenTables1024 *d_gen_tables = nullptr;   // n_fft = 1024
     dsp::GenTables2048 *d_tables2048 = nullptr;   // n_fft = 2048
+    dsp::PairExtra512 *d_pair = nullptr;          // n_fft = 512: extra constants of the two-frames-per-wave kernel (DSP_KERNEL_PAIR)
+    int resident_blocks_pair = 3;
     int resident_blocks_2048 = 2, resident_blocks_2048_pool = 2;
     int resident_blocks_gen = 3;
     int gen_slots = 0;                            // mel chunk slots per lane the 1024-point tables use (<= 3: wave kernel)
@@ -247,9 +249,16 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
         e = hipMemcpy(p->d_row_tables, rt, sizeof(*rt), hipMemcpyHostToDevice);
         delete rt;
     }
+    if (e == hipSuccess && cfg->n_fft == 512) {
+        dsp::PairExtra512 px;
+        dsp::build_pair_extra_512(px);
+        e = hipMalloc(&p->d_pair, sizeof(px));
+        if (e == hipSuccess) e = hipMemcpy(p->d_pair, &px, sizeof(px), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         if (p->d_tables) hipFree(p->d_tables);
         if (p->d_row_tables) hipFree(p->d_row_tables);
+        if (p->d_pair) hipFree(p->d_pair);
         delete p;
         return fail(DSP_EHIP, std::string("plan_create: ") + hipGetErrorString(e));
     }
@@ -264,6 +273,7 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
                                                         cfg->frame_length == 512, true);
         p->resident_blocks_row = dsp::mfcc512_row_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
                                                                 cfg->frame_length == 512);
+        p->resident_blocks_pair = dsp::mfcc512_pair_blocks_per_cu();
     } else {
         p->resident_blocks_gen = dsp::mfcc1024_blocks_per_cu(cfg->frame_length == 1024);
         p->resident_blocks_gen_wave = dsp::mfcc1024_wave_blocks_per_cu(cfg->frame_length == 1024);
@@ -271,7 +281,7 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
     }
     if (const char *k = std::getenv("DSP_AMD_KERNEL")) {
         const int id = std::atoi(k);
-        p->kernel = id == 1 ? DSP_KERNEL_ROW : (id == 2 ? DSP_KERNEL_WAVE_FRAME : DSP_KERNEL_WAVE);
+        p->kernel = id == 1 ? DSP_KERNEL_ROW : (id == 2 ? DSP_KERNEL_WAVE_FRAME : (id == 3 ? DSP_KERNEL_PAIR : DSP_KERNEL_WAVE));
     }
     *out = p;
     return DSP_OK;
@@ -285,6 +295,7 @@ void dsp_mfcc_plan_destroy(dsp_mfcc_plan *p)
     if (p->d_row_tables) hipFree(p->d_row_tables);
     if (p->d_gen_tables) hipFree(p->d_gen_tables);
     if (p->d_tables2048) hipFree(p->d_tables2048);
+    if (p->d_pair) hipFree(p->d_pair);
     if (p->d_scan) hipFree(p->d_scan);
     if (p->d_filtered) hipFree(p->d_filtered);
     if (p->d_frame_max) hipFree(p->d_frame_max);
@@ -303,7 +314,7 @@ int dsp_mfcc_plan_config(const dsp_mfcc_plan *p, dsp_mfcc_config *cfg)
 
 int dsp_mfcc_plan_set_kernel(dsp_mfcc_plan *p, int kernel)
 {
-    if (!p || (kernel != DSP_KERNEL_WAVE && kernel != DSP_KERNEL_ROW && kernel != DSP_KERNEL_WAVE_FRAME)) return fail(DSP_EINVAL, "bad kernel id");
+    if (!p || (kernel != DSP_KERNEL_WAVE && kernel != DSP_KERNEL_ROW && kernel != DSP_KERNEL_WAVE_FRAME && kernel != DSP_KERNEL_PAIR)) return fail(DSP_EINVAL, "bad kernel id");
     p->kernel = kernel;
     return DSP_OK;
 }
@@ -358,13 +369,16 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     a.frame_len = p->cfg.frame_length;
     const bool gen = p->cfg.n_fft == 1024;
     const bool row = !gen && p->kernel == DSP_KERNEL_ROW;
+    // two frames per wavefront step (experiment): the reference shape on independent full frames only, else the default form
+    const bool pair = !gen && p->kernel == DSP_KERNEL_PAIR && p->d_pair && in_kind == 0 && frames_per_clip == 0 && p->cfg.frame_length == 512 &&
+                      p->cfg.log_mode == DSP_LOG_PER_FRAME_MAX && p->host.dct_split == 4 && p->host.dct_len == 10 && p->host.mel_gather == 3;
     // 16-frame tile epilogue: per-frame log mode on the wave-per-frame kernel
-    const bool tile = !gen && p->kernel == DSP_KERNEL_WAVE && p->cfg.log_mode == DSP_LOG_PER_FRAME_MAX;
+    const bool tile = !gen && (p->kernel == DSP_KERNEL_WAVE || p->kernel == DSP_KERNEL_PAIR) && p->cfg.log_mode == DSP_LOG_PER_FRAME_MAX;
     // 1024-point: the register-resident wave kernel when the filterbank fits two chunk slots per lane (DSP_KERNEL_ROW selects
     // the general Stockham kernel for A/B)
     const bool gen_wave = gen && p->gen_slots <= 3 && p->kernel != DSP_KERNEL_ROW;
-    const int nf = gen ? (gen_wave ? 8 : 1) : (row ? 4 : (tile ? 8 : 1));
-    a.chunk = p->chunk > 0 ? p->chunk : 8;
+    const int nf = gen ? (gen_wave ? 8 : 1) : (pair ? 16 : (row ? 4 : (tile ? 8 : 1)));
+    a.chunk = p->chunk > 0 ? p->chunk : (pair ? 16 : 8);
     a.chunk = ((a.chunk + nf - 1) / nf) * nf;   // whole items (tile: half-tiles of 8 frames) per chunk
     a.n_mels = p->cfg.n_mels;
     a.n_mfcc = p->cfg.n_mfcc;
@@ -378,7 +392,7 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     // never more blocks than there are chunks of work
     const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu
                        : (gen ? (gen_wave ? (fused_prefilter ? p->resident_blocks_gen_pre : p->resident_blocks_gen_wave) : p->resident_blocks_gen)
-                              : (row ? p->resident_blocks_row : (tile ? p->resident_blocks : p->resident_blocks_frame)));
+                              : (pair ? p->resident_blocks_pair : (row ? p->resident_blocks_row : (tile ? p->resident_blocks : p->resident_blocks_frame))));
     long blocks = (long)p->n_cu * per_cu;
     const long chunks = (n_frames + a.chunk - 1) / a.chunk;
     blocks = std::max(1L, std::min(blocks, (chunks + 3) / 4));
@@ -407,6 +421,8 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
         DSP_HIP(dsp::launch_mfcc1024_wave(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream, fused_prefilter ? p->d_scan : nullptr));
     else if (gen)
         DSP_HIP(dsp::launch_mfcc1024(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream));
+    else if (pair)
+        DSP_HIP(dsp::launch_mfcc512_pair(a, p->d_pair, (int)blocks, (hipStream_t)stream));
     else if (row)
         DSP_HIP(dsp::launch_mfcc512_row(a, p->d_row_tables, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks,
                                         (hipStream_t)stream));

@@ -65,6 +65,10 @@ int mfcc1024_wave_blocks_per_cu(bool full, bool prefilter = false);
 int mfcc512_lds_bytes_per_block(bool tile);
 // n_fft = 2048 (mfcc2048_kernel.hip); pool: the fused clip -> label form (args.chunk == args.frames_per_clip, args.pool set)
 struct GenTables2048;
+struct PairExtra512;
+// two frames per wavefront step, reference shape, independent 512-sample frames (mfcc512_pair_kernel.hip; DSP_KERNEL_PAIR)
+hipError_t launch_mfcc512_pair(const Mfcc512Args &args, const PairExtra512 *extra, int blocks, hipStream_t stream);
+int mfcc512_pair_blocks_per_cu();
 hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables, int blocks, hipStream_t stream, bool pool);
 int mfcc2048_blocks_per_cu(int n_mels, bool pool);
 int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full, bool tile);

@@ -374,6 +374,18 @@ bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::st
     return true;
 }
 
+void build_pair_extra_512(PairExtra512 &t)
+{
+    std::memset(&t, 0, sizeof(t));
+    for (int l = 0; l < kLanes; ++l) {
+        const int f = (l >> 2) & 1, j = (l & 3) + 4 * (l >> 3);
+        for (int p = 1; p < 8; ++p) unit((double)((l % 8) * p) / 64.0, t.tw2[2 * (p - 1)][l], t.tw2[2 * (p - 1) + 1][l]);
+        for (int tt = 0; tt < 4; ++tt) unit((double)(j + 32 * tt) / 512.0, t.twp[2 * tt][l], t.twp[2 * tt + 1][l]);
+        const int jp = (32 - j) & 31;
+        t.partner[l] = (jp & 3) | (f << 2) | ((jp >> 2) << 3);
+    }
+}
+
 void build_row_tables_512(const dsp_mfcc_config &cfg, RowTables512 &t)
 {
     std::memset(&t, 0, sizeof(t));

@@ -69,6 +69,17 @@ struct LaneTables512 {
     float dct_a[2][kDctSteps][kLanes];
 };
 
+// ---- extra per-lane constants of the two-frames-per-wave kernel (mfcc512_pair_kernel.hip) ------------------------------------
+// Two 512-sample frames ride the radix-8 pipeline of the 1024-point kernel as eight independent 64-point transforms: slots
+// q = q' + 4 f (f = frame, q' = output of the frame's first radix-4 butterfly).  Lane l ends with bins j + 32 r (r = 0..7) of
+// frame f = (l >> 2) & 1, j = (l & 3) + 4 (l >> 3).
+struct PairExtra512 {
+    float tw2[14][kLanes];      // W64^((l % 8) p), p = 1..7 (cos, sin): after the second stage
+    float twp[8][kLanes];       // W512^(j + 32 t), t = 0..3: untangling the packed real transform
+    int32_t partner[kLanes];    // lane of the same frame that holds bins (32 - j) + 32 r
+};
+void build_pair_extra_512(PairExtra512 &t);
+
 // ---- per-lane layout of the FFT front end of the row-per-frame kernel -------------
 // (4 frames per wave: lane = 16 g + j, row g = frame, 16 complex points per lane; the
 // tail -- mel, log, DCT -- reuses LaneTables512).

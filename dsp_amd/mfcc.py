@@ -72,7 +72,8 @@ class MfccPlan:
             pass
 
     def set_kernel(self, kernel: int):
-        """0 = one wavefront per frame, 1 = one 16-lane row per frame (4 frames per wavefront)."""
+        """0 = one wavefront per frame (default), 1 = one 16-lane row per frame (4 frames per wavefront), 2 = wave per frame with the
+        per-frame epilogue, 3 = two frames per wavefront step (reference shape, independent full frames; an experiment)."""
         _lib.check(self._L.dsp_mfcc_plan_set_kernel(self._h, int(kernel)), "dsp_mfcc_plan_set_kernel")
 
     def set_launch(self, blocks_per_cu: int = 0, frames_per_chunk: int = 0):

@@ -138,8 +138,10 @@ int dsp_mfcc_plan_set_launch(dsp_mfcc_plan *plan, int blocks_per_cu, int frames_
 /* Kernel form: DSP_KERNEL_WAVE = one wavefront per frame, log + DCT once per 16-frame tile
  * (default); DSP_KERNEL_ROW = one 16-lane row per frame (4 frames per wavefront);
  * DSP_KERNEL_WAVE_FRAME = one wavefront per frame with the per-frame log + DCT epilogue (what
- * DSP_LOG_GLOBAL_REF1 plans always run).  Same results to rounding; DESIGN.md has the numbers. */
-enum { DSP_KERNEL_WAVE = 0, DSP_KERNEL_ROW = 1, DSP_KERNEL_WAVE_FRAME = 2 };
+ * DSP_LOG_GLOBAL_REF1 plans always run); DSP_KERNEL_PAIR = two frames per wavefront step for independent
+ * 512-sample frames of the reference shape (an experiment, slower than the default: DESIGN.md 3; other
+ * shapes and clip mode run the default form).  Same results to rounding; DESIGN.md has the numbers. */
+enum { DSP_KERNEL_WAVE = 0, DSP_KERNEL_ROW = 1, DSP_KERNEL_WAVE_FRAME = 2, DSP_KERNEL_PAIR = 3 };
 int dsp_mfcc_plan_set_kernel(dsp_mfcc_plan *plan, int kernel);
 
 /* --- Butterworth band-pass (donut-classifier/classifier.c:319-446) ---------- */

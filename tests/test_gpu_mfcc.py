@@ -234,6 +234,34 @@ def test_row_per_frame_kernel_matches_wave_kernel(dsp, torch_cuda, golden):
         gate(yb, ref, f"row-kernel frames/{n}")
 
 
+def test_two_frames_per_wave_kernel_matches_the_oracle(dsp, torch_cuda):
+    """DSP_KERNEL_PAIR (mfcc512_pair_kernel.hip, an experiment kept selectable): two independent frames per wavefront step on
+    the radix-8 pipeline of the 1024-point kernel.  Same gate against the oracle on ragged frame counts (odd counts: the last
+    frame rides alone), a silent and a quiet frame beside loud ones (the frames of a pair never mix), and agreement with the
+    default form to rounding; other shapes / clip mode fall back to the default kernel."""
+    from oracle import oracle as O
+    torch = torch_cuda
+    fcfg = dsp.default_config(frame_length=512, hop_length=512)
+    a, b = dsp.MfccPlan(fcfg), dsp.MfccPlan(fcfg)
+    b.set_kernel(3)
+    for n in (1, 2, 3, 15, 16, 17, 33, 4099):
+        fr = S.uniform_pm1(512 * n, 700 + n).reshape(n, 512)
+        if n > 4:
+            fr[2] = 0.0
+            fr[3] *= np.float32(1e-4)
+        x = torch.from_numpy(fr).cuda()
+        ya, yb = a.frames(x).cpu().numpy(), b.frames(x).cpu().numpy()
+        assert np.abs(ya - yb).max() <= 2e-4
+        if n > 4:
+            assert not yb[2].any()                                # the silent frame: exact zeros whatever its partner holds
+        ref = O.mfcc_frames(fr, O.default_cfg(frame_length=512, hop_length=512), threads=4)
+        gate(yb, ref, f"pair-kernel frames/{n}")
+    clips = torch.from_numpy(np.stack([S.uniform_pm1(16000, 31), S.chirp(16000, 300.0, 7000.0)])).cuda()
+    c = dsp.MfccPlan()
+    c.set_kernel(3)                                               # clip mode: the default kernel runs
+    assert torch.equal(c.clips(clips, 500), dsp.MfccPlan().clips(clips, 500))
+
+
 def test_config3_1024_point_128_mel_with_prefilter(dsp, torch_cuda):
     """BASELINE config 3 at oracle-friendly size: per-frame float64 Butterworth (3000-7500 Hz literals)
     from zero state -> Hann(1024) -> 1024-pt FFT -> 128 HTK mel -> per-frame dB -> 13 coeffs."""
