@@ -15,7 +15,7 @@ cut -c1-120 $OUT/side_workloads.jsonl
 for w in frames classify config3; do
     ( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python3 $R/bench.py --workload $w --no-cpu-baseline --no-config4 --steps 50 > $OUT/trace_$w.json 2> $OUT/trace_$w.err )
 done
-for w in frames clips config3 config5 classify; do
+for w in frames clips config3 config5 config5_2048 classify; do
     python tools/traffic.py $TAG $w 2>&1 | tail -1
 done
 find $OUT -name "*kernel_stats.csv"
