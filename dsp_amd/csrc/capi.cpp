@@ -56,7 +56,8 @@ bool valid_cfg(const dsp_mfcc_config &c, std::string &why)
     if (!(c.fmax > c.fmin) || c.fmin < 0) { why = "need 0 <= fmin < fmax"; return false; }
     if (!(c.amin > 0)) { why = "amin must be positive"; return false; }
     if (c.log_mode != DSP_LOG_PER_FRAME_MAX && c.log_mode != DSP_LOG_GLOBAL_REF1) { why = "unknown log_mode"; return false; }
-    if (c.log_mode == DSP_LOG_GLOBAL_REF1 && c.n_fft != 512) { why = "DSP_LOG_GLOBAL_REF1 is implemented for n_fft = 512"; return false; }
+    if (c.mel_norm != DSP_MELNORM_NONE && c.mel_norm != DSP_MELNORM_SLANEY && c.mel_norm != DSP_MELNORM_LIBROSA) { why = "unknown mel_norm"; return false; }
+    if (c.log_mode == DSP_LOG_GLOBAL_REF1 && c.n_fft == 1024) { why = "DSP_LOG_GLOBAL_REF1 is implemented for n_fft = 512 and 2048"; return false; }
     if (c.prefilter != DSP_PREFILTER_NONE && c.n_fft == 2048) { why = "the per-frame prefilter is implemented for n_fft = 512 and 1024"; return false; }
     if (c.frame_length > c.n_fft) { why = "frame_length must not exceed n_fft"; return false; }
     if (c.win_length < 0 || c.win_length > c.frame_length) { why = "win_length must be in [0, frame_length]"; return false; }
@@ -354,6 +355,21 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
         const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks_2048;
         const long chunks = (n_frames + a.chunk - 1) / a.chunk;
         const long blocks = std::max(1L, std::min((long)p->n_cu * per_cu, (chunks + 3) / 4));
+        a.log_mode = p->cfg.log_mode;
+        if (a.log_mode == DSP_LOG_GLOBAL_REF1 && frames_per_clip > 0) {
+            // clip-global top_db, as for n_fft = 512 below: pass 1 writes each frame's maximum, a tiny kernel turns them into one
+            // floor per clip, pass 2 is the normal kernel clipping at that floor
+            const long n_clips = n_frames / frames_per_clip;
+            int rc;
+            std::lock_guard<std::recursive_mutex> lock(p->mu);
+            if ((rc = reserve(&p->d_frame_max, &p->frame_max_cap, (size_t)n_frames * sizeof(float))) < 0) return rc;
+            if ((rc = reserve(&p->d_clip_floor, &p->clip_floor_cap, (size_t)n_clips * sizeof(float))) < 0) return rc;
+            a.frame_max = p->d_frame_max;
+            DSP_HIP(dsp::launch_mfcc2048(a, p->d_tables2048, (int)blocks, (hipStream_t)stream, false));
+            DSP_HIP(dsp::launch_clip_floor(p->d_frame_max, n_clips, frames_per_clip, a.top_db, p->d_clip_floor, (hipStream_t)stream));
+            a.frame_max = nullptr;
+            a.clip_floor = p->d_clip_floor;
+        }
         DSP_HIP(dsp::launch_mfcc2048(a, p->d_tables2048, (int)blocks, (hipStream_t)stream, false));
         return DSP_OK;
     }

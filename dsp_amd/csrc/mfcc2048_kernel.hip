@@ -279,13 +279,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
         }
         // ---- 10 log10 with per-frame reference (mfcc.c:169-206), one log of the ratio --------------------------------------
         const float ref = __uint_as_float(max(__float_as_uint(wave_max_nonneg(emax)), amin_u));
-        const float inv = __builtin_amdgcn_rcpf(ref);
+        if (!POOL && args.log_mode != 0) {
+            // librosa power_to_db(ref = 1.0, top_db below the CLIP's maximum), keyword_classifier.py:42-55 / librosa's defaults as
+            // cepstrum/train.py:45-52 uses them; same two passes as the 512-point kernel (mfcc_kernels.hip)
+            const float k10 = 3.01029995663981195f;
+            const float top_db_val = k10 * __builtin_amdgcn_logf(ref);          // this frame's maximum in dB
+            if (args.frame_max != nullptr) {                                    // pass 1: only the frame maximum
+                if (lane == 0) args.frame_max[f] = top_db_val;
+                wave_lds_sync();
+                continue;
+            }
+            const float floor_db = args.clip_floor ? args.clip_floor[clip_f] : top_db_val + neg_top_db;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float ec = __uint_as_float(max(__float_as_uint(e[i]), amin_u));
-            float db = 3.01029995663981195f * __builtin_amdgcn_logf(ec * inv);
-            db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f);
-            lmel[lane + 64 * i] = (lane + 64 * i < n_mels) ? db : 0.0f;          // 128 slots: the DCT may read up to 2 half <= n_mels + 1
+            for (int i = 0; i < 2; ++i) {
+                const float ec = __uint_as_float(max(__float_as_uint(e[i]), amin_u));
+                const float db = fmaxf(k10 * __builtin_amdgcn_logf(ec), floor_db);
+                lmel[lane + 64 * i] = (lane + 64 * i < n_mels) ? db : 0.0f;
+            }
+        } else {
+            const float inv = __builtin_amdgcn_rcpf(ref);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float ec = __uint_as_float(max(__float_as_uint(e[i]), amin_u));
+                float db = 3.01029995663981195f * __builtin_amdgcn_logf(ec * inv);
+                db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f);
+                lmel[lane + 64 * i] = (lane + 64 * i < n_mels) ? db : 0.0f;          // 128 slots: the DCT may read up to 2 half <= n_mels + 1
+            }
         }
         wave_lds_sync();
 

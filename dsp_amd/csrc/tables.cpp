@@ -42,8 +42,19 @@ std::vector<float> make_mel_filterbank(int sample_rate, int n_fft, int n_mels, f
                                        float fmax, int mel_norm)
 {
     const int n_bins = n_fft / 2 + 1;
-    auto to_mel = [](double hz) { return 2595.0 * std::log10(1.0 + hz / 700.0); };
-    auto to_hz = [](double mel) { return 700.0 * (std::pow(10.0, mel / 2595.0) - 1.0); };
+    // DSP_MELNORM_LIBROSA: librosa.filters.mel's defaults -- Slaney's mel SCALE (htk = False: 200/3 Hz per mel below 1 kHz,
+    // log(6.4) / 27 per mel above) with Slaney's area normalisation; what librosa.feature.mfcc, hence cepstrum/train.py:45-52, uses
+    const bool slaney_scale = mel_norm == DSP_MELNORM_LIBROSA;
+    if (slaney_scale) mel_norm = DSP_MELNORM_SLANEY;
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    auto to_mel = [&](double hz) {
+        if (slaney_scale) return hz >= min_log_hz ? min_log_mel + std::log(hz / min_log_hz) / logstep : hz / f_sp;
+        return 2595.0 * std::log10(1.0 + hz / 700.0);
+    };
+    auto to_hz = [&](double mel) {
+        if (slaney_scale) return mel >= min_log_mel ? min_log_hz * std::exp(logstep * (mel - min_log_mel)) : f_sp * mel;
+        return 700.0 * (std::pow(10.0, mel / 2595.0) - 1.0);
+    };
     std::vector<double> edge(n_mels + 2);
     const double lo = to_mel(fmin), hi = to_mel(fmax);
     const double step = (hi - lo) / (n_mels + 1);
@@ -97,7 +108,6 @@ bool build_gen_tables_2048(const dsp_mfcc_config &cfg, GenTables2048 &t, std::st
     if (cfg.frame_length < 2 || cfg.frame_length > n_fft) { why = "frame_length must be in [2, n_fft]"; return false; }
     if (cfg.n_mels < 1 || cfg.n_mels > k2048MaxMels) { why = "n_mels must be in [1, 128] for n_fft = 2048"; return false; }
     if (cfg.n_mfcc < 1 || cfg.n_mfcc > k2048MaxMfcc) { why = "n_mfcc must be in [1, 32] for n_fft = 2048"; return false; }
-    if (cfg.log_mode != DSP_LOG_PER_FRAME_MAX) { why = "n_fft = 2048 runs the per-frame log mode"; return false; }
     if (cfg.prefilter != DSP_PREFILTER_NONE) { why = "the per-frame prefilter is implemented for n_fft = 512 and 1024"; return false; }
     t.n_mels = cfg.n_mels;
     t.n_mfcc = cfg.n_mfcc;

@@ -67,7 +67,7 @@ class ClassifyConfig(C.Structure):
 
 
 WINDOW_HANN, WINDOW_HAMMING, WINDOW_RECT = 0, 1, 2
-MELNORM_NONE, MELNORM_SLANEY = 0, 1
+MELNORM_NONE, MELNORM_SLANEY, MELNORM_LIBROSA = 0, 1, 2
 LOG_PER_FRAME_MAX, LOG_GLOBAL_REF1 = 0, 1
 PREFILTER_NONE, PREFILTER_BUTTER_1000_3000, PREFILTER_BUTTER_3000_7500 = 0, 1, 2
 

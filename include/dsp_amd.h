@@ -65,8 +65,10 @@ enum {
 };
 
 enum { DSP_WINDOW_HANN = 0, DSP_WINDOW_HAMMING = 1, DSP_WINDOW_RECT = 2 };
-enum { DSP_MELNORM_NONE = 0, DSP_MELNORM_SLANEY = 1 };
-enum { DSP_LOG_PER_FRAME_MAX = 0, DSP_LOG_GLOBAL_REF1 = 1 };
+enum { DSP_MELNORM_NONE = 0, DSP_MELNORM_SLANEY = 1,       /* HTK mel scale, triangles of peak 1 / of unit area          */
+       DSP_MELNORM_LIBROSA = 2 };                           /* Slaney mel scale + unit area: librosa.filters.mel defaults */
+enum { DSP_LOG_PER_FRAME_MAX = 0,    /* mfcc.c:169-206: reference = the frame's own maximum                                    */
+       DSP_LOG_GLOBAL_REF1 = 1 };    /* librosa power_to_db(ref = 1, top_db below the CLIP's maximum); n_fft 512 and 2048      */
 enum { DSP_PREFILTER_NONE = 0, DSP_PREFILTER_BUTTER_1000_3000 = 1, DSP_PREFILTER_BUTTER_3000_7500 = 2 };
 
 /* Compile-time constants of the reference (mfcc_params.h:6-12, mfcc.c:172-173)

@@ -64,6 +64,18 @@ void orc_window(int kind, int n, float *out)
 
 static double hz_to_mel_htk(double hz) { return 2595.0 * log10(1.0 + hz / 700.0); }
 static double mel_to_hz_htk(double mel) { return 700.0 * (pow(10.0, mel / 2595.0) - 1.0); }
+/* librosa.hz_to_mel / mel_to_hz with htk=False (Slaney's Auditory Toolbox scale): linear below 1 kHz (200/3 Hz per mel),
+ * logarithmic above (log(6.4) / 27 per mel) -- what librosa.feature.mfcc uses by default (cepstrum/train.py:45-52) */
+static double hz_to_mel_slaney(double hz)
+{
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = 1000.0 / (200.0 / 3.0), logstep = log(6.4) / 27.0;
+    return hz >= min_log_hz ? min_log_mel + log(hz / min_log_hz) / logstep : hz / f_sp;
+}
+static double mel_to_hz_slaney(double mel)
+{
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = 1000.0 / (200.0 / 3.0), logstep = log(6.4) / 27.0;
+    return mel >= min_log_mel ? min_log_hz * exp(logstep * (mel - min_log_mel)) : f_sp * mel;
+}
 
 /* export_mfcc_params.py:49-57 -- librosa.filters.mel(htk=True, norm=None|slaney):
  * n_mels+2 band edges equally spaced on the HTK mel axis, triangles built from
@@ -73,13 +85,15 @@ void orc_mel_filterbank(int sample_rate, int n_fft, int n_mels, float fmin,
 {
     const int n_bins = n_fft / 2 + 1;
     double *edge = (double *)malloc(sizeof(double) * (size_t)(n_mels + 2));
-    const double m_lo = hz_to_mel_htk((double)fmin);
-    const double m_hi = hz_to_mel_htk((double)fmax);
+    const int slaney_scale = mel_norm == ORC_MELNORM_LIBROSA;
+    if (slaney_scale) mel_norm = ORC_MELNORM_SLANEY;
+    const double m_lo = slaney_scale ? hz_to_mel_slaney((double)fmin) : hz_to_mel_htk((double)fmin);
+    const double m_hi = slaney_scale ? hz_to_mel_slaney((double)fmax) : hz_to_mel_htk((double)fmax);
     for (int i = 0; i < n_mels + 2; ++i) {
         /* np.linspace: start + i*step, last point pinned to stop */
         double m = (i == n_mels + 1) ? m_hi
                                      : m_lo + (double)i * ((m_hi - m_lo) / (double)(n_mels + 1));
-        edge[i] = mel_to_hz_htk(m);
+        edge[i] = slaney_scale ? mel_to_hz_slaney(m) : mel_to_hz_htk(m);
     }
     for (int m = 0; m < n_mels; ++m) {
         const double d_lo = edge[m + 1] - edge[m];

@@ -35,7 +35,7 @@ extern "C" {
 /* ---- configuration ------------------------------------------------------ */
 
 enum { ORC_WINDOW_HANN = 0, ORC_WINDOW_HAMMING = 1, ORC_WINDOW_RECT = 2 };
-enum { ORC_MELNORM_NONE = 0, ORC_MELNORM_SLANEY = 1 };
+enum { ORC_MELNORM_NONE = 0, ORC_MELNORM_SLANEY = 1, ORC_MELNORM_LIBROSA = 2 };   /* 2: Slaney mel SCALE (htk=False) + Slaney norm: librosa.filters.mel's defaults */
 /* log mode 0: per-frame ref=max, amin, top_db  (2fa/audio/word/c/mfcc.c:169-206)
  * log mode 1: librosa power_to_db(ref=1.0) with clip-global top_db
  *             (2fa/audio/keyword_classifier.py:37-68; golden test_mfcc.h)      */

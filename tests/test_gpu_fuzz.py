@@ -29,7 +29,8 @@ def draw(rng, n_fft):
     fmin = float(rng.choice([0.0, 0.0, 20.0, 300.0]))
     fmax = float(rng.choice([sr / 2.0, sr / 2.0, 0.45 * sr, 0.3 * sr]))
     return dict(sample_rate=sr, n_fft=n_fft, frame_length=frame, hop_length=hop, n_mels=n_mels, n_mfcc=n_mfcc, fmin=fmin, fmax=fmax,
-                window=int(rng.integers(0, 3)), mel_norm=int(rng.integers(0, 2)))
+                window=int(rng.integers(0, 3)), mel_norm=int(rng.integers(0, 3)),
+                log_mode=int(rng.integers(0, 2)) if n_fft != 1024 else 0)       # clip-global log mode: 512 and 2048
 
 
 @pytest.mark.parametrize("n_fft", [512, 1024, 2048])

@@ -251,3 +251,40 @@ def test_fused_kernel_at_other_coefficient_counts(n_mfcc, n_mels, fmax):
     for i in range(3):
         ref = O.mfcc_stats(O.compute_mfcc(x[i], 500, ocfg))
         gate(feats[i][None, :], ref[None, :], f"fused n_mfcc {n_mfcc} / {n_mels} mel pooled features clip{i}")
+
+
+def test_librosa_default_framing_on_the_2048_kernel():
+    """cepstrum/train.py:45-52 computes its features with librosa's defaults: n_fft 2048, hop 512, centred frames, Hann,
+    128 mel filters on Slaney's scale with Slaney's normalisation (DSP_MELNORM_LIBROSA), power_to_db(ref = 1, top_db = 80 below the CLIP's maximum), 20 ortho DCT-II
+    coefficients, then mean | std.  DSP_LOG_GLOBAL_REF1 on the 2048-point kernel: against the oracle (gate), and the pooled
+    features against the float64 numpy restatement of that librosa call that pinned the SVM's polarity
+    (tools/pin_svm_libsvm.py:librosa_like_features) -- an independent implementation of the same definition."""
+    import importlib.util
+    import os
+    import torch
+    import dsp_amd
+    from dsp_amd.lib import MELNORM_LIBROSA, LOG_GLOBAL_REF1
+    from oracle import oracle as O
+    from tests.conftest import gate
+    spec = importlib.util.spec_from_file_location("pin_svm", os.path.join(os.path.dirname(__file__), "..", "tools", "pin_svm_libsvm.py"))
+    pin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin)
+    for sr in (16000, 22050):
+        over = dict(sample_rate=sr, n_fft=2048, frame_length=2048, hop_length=512, n_mels=128, n_mfcc=20, fmin=0.0, fmax=sr / 2.0,
+                    mel_norm=MELNORM_LIBROSA, log_mode=LOG_GLOBAL_REF1)
+        plan = dsp_amd.MfccPlan(dsp_amd.default_config(**over))
+        ocfg = O.default_cfg(**over)
+        n = (3 * sr // 2) & ~1                                   # even clip stride (8-byte aligned frame loads)
+        ys = [S.uniform_pm1(n, 80 + sr % 7) * np.float32(0.3), S.chirp(n, 150.0, 0.4 * sr, fs=float(sr)).astype(np.float32),
+              (S.uniform_pm1(n, 81) * np.float32(0.002)).astype(np.float32)]
+        ys[2][: n // 3] += S.chirp(n // 3, 500.0, 3000.0, fs=float(sr)).astype(np.float32)       # a loud start, a near-silent rest: the clip floor bites
+        padded = np.stack([np.pad(y, 1024) for y in ys]).astype(np.float32)                      # librosa center=True, constant padding
+        out = plan.clips(torch.from_numpy(padded).cuda(), 1000).cpu().numpy()
+        for i, y in enumerate(ys):
+            ref = O.compute_mfcc(padded[i], 1000, ocfg)
+            assert out[i].shape == ref.shape == (1 + (padded.shape[1] - 2048) // 512, 20)
+            gate(out[i], ref, f"librosa defaults sr {sr} clip{i}")
+            feat = np.concatenate([out[i].mean(axis=0), out[i].std(axis=0)])
+            want = pin.librosa_like_features(y.astype(np.float64), sr)
+            err = np.abs(feat - want).max() / np.abs(want).max()
+            assert err < 2e-4, (sr, i, err)

@@ -96,3 +96,22 @@ def test_pcm16_conversion_known_answer(golden):
     k = golden("pcm_kat.npz")
     x = (k["pcm"][:, 0] / 32768.0)
     assert np.abs(x - k["dump"]).max() <= 5.1e-7
+
+
+def test_librosa_default_mel_filterbank_vs_an_independent_restatement():
+    """ORC_MELNORM_LIBROSA = librosa.filters.mel's defaults (Slaney's mel scale, htk = False, with Slaney's area
+    normalisation): what librosa.feature.mfcc, hence cepstrum/train.py:45-52, builds.  Checked against the float64 numpy
+    restatement of librosa's formulas in tools/pin_svm_libsvm.py (written from librosa's documentation for the SVM polarity
+    pin, independently of the C code)."""
+    import importlib.util
+    import os
+    from oracle import oracle as O
+    spec = importlib.util.spec_from_file_location("pin_svm", os.path.join(os.path.dirname(__file__), "..", "tools", "pin_svm_libsvm.py"))
+    pin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin)
+    for sr, n_fft, n_mels in ((16000, 2048, 128), (22050, 2048, 128), (44100, 2048, 40), (16000, 512, 40)):
+        got = O.mel_filterbank(sr, n_fft, n_mels, 0.0, sr / 2.0, O.MELNORM_LIBROSA)
+        want = pin.slaney_mel(sr, n_fft, n_mels)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-7 * np.abs(want).max()
+        assert (got.sum(axis=1) > 0).all()
