@@ -288,3 +288,36 @@ def test_librosa_default_framing_on_the_2048_kernel():
             want = pin.librosa_like_features(y.astype(np.float64), sr)
             err = np.abs(feat - want).max() / np.abs(want).max()
             assert err < 2e-4, (sr, i, err)
+
+
+def test_end_to_end_on_the_reference_recordings(golden):
+    """Two of the reference's own labelled recordings (cepstrum/testing/P_1363v2-sj-short.WAV, N_1809v2-not-sj.wav; fixture
+    tests/golden/labelled_audio.npz) through the GPU path end to end as cepstrum/train.py / run.py define it: stereo int16 -> mono
+    average -> centred frames -> MFCC with librosa's defaults on the 2048-point kernel (96 kHz) -> mean | std -> Scaler -> RBF-SVM.
+    The 40 features against what the float64 restatement of the librosa call gives for the same file, decision value and
+    probability against libsvm's for that vector, and the label against the FILE's label (P_ = scrub jay)."""
+    import torch
+    import dsp_amd
+    from dsp_amd import scrubjay
+    from dsp_amd.lib import MELNORM_LIBROSA, LOG_GLOBAL_REF1
+    g = golden("labelled_audio.npz")
+    m = golden("scrubjay_svm.npz")
+    svm = scrubjay.SvmModel({k: m[k] for k in m.files})
+    for name in ("sj_short", "not_sj"):
+        pcm, sr, label = g[f"{name}__pcm"], int(g[f"{name}__sr"]), int(g[f"{name}__label"])
+        y = (pcm.astype(np.float64) / 32768.0).mean(axis=1).astype(np.float32)          # librosa.load(sr=None, mono=True)
+        y = np.pad(y, 1024)                                                              # center=True, constant padding
+        if y.size & 1:
+            y = y[:-1]                                                                   # an even stride; the dropped sample lies past the last frame or is padding
+        cfg = dsp_amd.default_config(sample_rate=sr, n_fft=2048, frame_length=2048, hop_length=512, n_mels=128, n_mfcc=20, fmin=0.0,
+                                     fmax=sr / 2.0, mel_norm=MELNORM_LIBROSA, log_mode=LOG_GLOBAL_REF1)
+        mf = dsp_amd.MfccPlan(cfg).clips(torch.from_numpy(y[None, :]).cuda(), 100000)
+        assert mf.shape[1] == 1 + pcm.shape[0] // 512
+        feat = scrubjay.mfcc_stats(mf)                                                   # scrubjay_infer.c:36-66 pooling, float64 sums
+        want = g[f"{name}__feat"]
+        err = np.abs(feat.cpu().numpy()[0] - want).max() / np.abs(want).max()
+        assert err < 3e-4, (name, err)
+        labels, decision, prob1 = svm.predict(feat.contiguous())
+        assert int(labels[0]) == label == int(g[f"{name}__vote"])
+        assert abs(float(decision[0]) - float(g[f"{name}__decision"])) < 5e-3
+        assert abs(float(prob1[0]) - float(g[f"{name}__proba"][1])) < 5e-3
