@@ -16,7 +16,7 @@
 #include "tables.hpp"
 
 #ifndef DSP_PAIR_WAVES
-#define DSP_PAIR_WAVES 3
+#define DSP_PAIR_WAVES 4
 #endif
 #ifndef DSP_PAIR_DIAG
 #define DSP_PAIR_DIAG 0
@@ -33,7 +33,8 @@ namespace {
 constexpr int P_ZBUF = 0;                    // 512 x float2 exchange image; later P of frame 0 at float 0, of frame 1 at float P_PB1
 constexpr int P_PART = 4096;                 // per frame 64 partial sums + the slot that reads 0 (65 floats each)
 constexpr int P_ETILE = P_PART + 528;        // mel energies of 16 frames, E[mel][frame ^ (mel >> 2)]
-constexpr int P_WAVE_BYTES = P_ETILE + 64 * 16 * 4;
+constexpr int P_TILE_ROWS = 40;               // the reference's 40 mel filters (4 P_KS)
+constexpr int P_WAVE_BYTES = P_ETILE + P_TILE_ROWS * 16 * 4;
 static_assert(P_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
 constexpr int P_PB1 = 544;                   // P of frame 1 starts here (floats): 32 banks away from frame 0's, so the two halves of a wave's store do not collide
 constexpr int P_KS = 10;                     // MFMA k-steps (4 mel filters each): the reference's 40 filters
@@ -68,19 +69,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_PAIR_WA
     float *part = reinterpret_cast<float *>(wl + P_PART);
     float *etile = reinterpret_cast<float *>(wl + P_ETILE);
     float *a_lds = reinterpret_cast<float *>(smem + 4 * P_WAVE_BYTES);           // MFMA A operand, block-shared
+    float2 *tw2_lds = reinterpret_cast<float2 *>(a_lds + P_KS * 64);            // [p][lane], p < 7: second-stage twiddles
+    float2 *twp_lds = tw2_lds + 7 * 64;                                          // [t][lane], t < 4: untangling twiddles
     const LaneTables512 *__restrict__ T = args.tables;
 
     // ---- per-lane constants ------------------------------------------------------------------------------------------
     float win[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) win[i] = T->win[i][lane];
-    c32 twa[3], tw2[7], twp[4];
+    c32 twa[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) twa[q] = {T->tw1[2 * q][lane], T->tw1[2 * q + 1][lane]};          // W256^(l q')
-#pragma unroll
-    for (int p = 0; p < 7; ++p) tw2[p] = {X->tw2[2 * p][lane], X->tw2[2 * p + 1][lane]};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) twp[t] = {X->twp[2 * t][lane], X->twp[2 * t + 1][lane]};
+    // the second-stage and the untangling twiddles (22 VGPRs) come from a block-shared LDS copy, 11 ds_read_b64 per pair: that
+    // is the difference between three and four waves per SIMD
+    for (int i = threadIdx.x; i < 7 * 64; i += 256) tw2_lds[i] = make_float2(X->tw2[2 * (i >> 6)][i & 63], X->tw2[2 * (i >> 6) + 1][i & 63]);
+    for (int i = threadIdx.x; i < 4 * 64; i += 256) twp_lds[i] = make_float2(X->twp[2 * (i >> 6)][i & 63], X->twp[2 * (i >> 6) + 1][i & 63]);
     float melw[kMelChunk];
 #pragma unroll
     for (int i = 0; i < kMelChunk; ++i) melw[i] = T->mel_w[i][lane];
@@ -216,7 +219,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_PAIR_WA
         // ---- stage B: radix-8 over l_hi, twiddle W64^(l_lo p) -----------------------------------------------------------
         radix8p(v);
 #pragma unroll
-        for (int p = 1; p < 8; ++p) v[p] = cmul(v[p], tw2[p - 1]);
+        for (int p = 1; p < 8; ++p) {
+            const float2 w = tw2_lds[64 * (p - 1) + lane];
+            v[p] = cmul(v[p], c32{w.x, w.y});
+        }
         // exchange 2: element (q, p, l_lo) at (64 p + 8 q + l_lo) ^ ((p & 3) << 1 | q >> 2): writer lane (q, l_lo) slot p,
         // reader lane (p, q) slot l_lo -> after stage C lane l holds pipeline bins l + 64 r
 #pragma unroll
@@ -245,7 +251,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_PAIR_WA
             const c32 a = v[t];
             const c32 E = {a.x + b.x, a.y - b.y};
             const c32 O = {a.x - b.x, a.y + b.y};
-            const c32 Tw = cmul(O, twp[t]);
+            const float2 wt = twp_lds[64 * t + lane];
+            const c32 Tw = cmul(O, c32{wt.x, wt.y});
             const float xr = E.x + Tw.y, xi = E.y - Tw.x;
             const float mr = E.x - Tw.y, mi = E.y + Tw.x;
             P[2 * t] = xr * xr + xi * xi;
@@ -284,8 +291,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_PAIR_WA
             e[fi] = lane < n_mels ? s : 0.0f;
         }
         if ((slot & 7) == 0) { if (slot == 0) fb0 = f0; else fb1 = f0; }
-        etile[16 * lane + (slot ^ (lane >> 2))] = e[0];
-        if (two) etile[16 * lane + ((slot + 1) ^ (lane >> 2))] = e[1];
+        if (lane < P_TILE_ROWS) {
+            etile[16 * lane + (slot ^ (lane >> 2))] = e[0];
+            if (two) etile[16 * lane + ((slot + 1) ^ (lane >> 2))] = e[1];
+        }
         slot += two ? 2 : 1;
         if (slot >= 16 || !more) { flush(slot); slot = 0; }
         else wave_lds_sync();
@@ -298,7 +307,7 @@ hipError_t launch_mfcc512_pair(const Mfcc512Args &args, const PairExtra512 *extr
     if (args.frames_per_clip != 0 || args.frame_len != 512 || args.in_kind != 0 || args.chunk % 16 != 0 || args.log_mode != 0 ||
         args.n_mels > 4 * P_KS || args.n_mfcc > 16)
         return hipErrorInvalidConfiguration;
-    const size_t lds = (size_t)4 * P_WAVE_BYTES + (size_t)P_KS * 64 * 4;
+    const size_t lds = (size_t)4 * P_WAVE_BYTES + (size_t)P_KS * 64 * 4 + (size_t)11 * 64 * 8;
     hipLaunchKernelGGL(mfcc512_pair_kernel, dim3(blocks), dim3(256), lds, stream, args, extra);
     return hipGetLastError();
 }
@@ -306,7 +315,7 @@ hipError_t launch_mfcc512_pair(const Mfcc512Args &args, const PairExtra512 *extr
 int mfcc512_pair_blocks_per_cu()
 {
     int n = 0;
-    const size_t lds = (size_t)4 * P_WAVE_BYTES + (size_t)P_KS * 64 * 4;
+    const size_t lds = (size_t)4 * P_WAVE_BYTES + (size_t)P_KS * 64 * 4 + (size_t)11 * 64 * 8;
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc512_pair_kernel, 256, lds);
     return e == hipSuccess && n > 0 ? n : 3;
 }
