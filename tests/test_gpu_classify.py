@@ -284,3 +284,24 @@ def test_device_batch_with_unaligned_rows(dsp, golden):
     assert np.array_equal(dsp.classify_device(view).cpu().numpy(), np.tile(want, reps))
     assert np.array_equal(dsp.classify_device(view, config=dsp.CLASSIFY_MICROPHONE).cpu().numpy(),
                           dsp.classify_device(clips, config=dsp.CLASSIFY_MICROPHONE).cpu().numpy())
+
+
+def test_donut_classifier_recordings(dsp, golden):
+    """The donut classifier's own 16 kHz recordings (donut-classifier/16k/*.wav): labels and midpoints as the compiled
+    reference returned them; under the microphone firmware's thresholds (where these recordings have midpoints) midpoints and
+    band sums as the oracle gives them -- bit exact, one call per recording (lengths 0.15 s .. 3 s) and as one padded batch
+    is not possible (classify() has no padding notion), so ragged lengths go one by one."""
+    g = golden("donut16k_ref.npz")
+    names = sorted({k.split("__")[0] for k in g.files})
+    mic = dsp.classify_config(dsp.CLASSIFY_MICROPHONE)
+    seen = 0
+    for n in names:
+        x = (g[n + "__pcm"][:, 0].astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+        assert dsp.classify(x) == int(g[n + "__label"])
+        labels, trace = dsp.classify_batch(x[None, :], with_trace=True)
+        assert labels[0] == int(g[n + "__label"]) and np.array_equal(trace[0][0], g[n + "__midpoints"])
+        labels, trace = dsp.classify_batch(x[None, :], with_trace=True, config=mic)
+        assert labels[0] == int(g[n + "__mic_label"])
+        assert np.array_equal(trace[0][0], g[n + "__mic_midpoints"]) and np.array_equal(trace[0][1], g[n + "__mic_sums"])
+        seen += len(g[n + "__mic_midpoints"])
+    assert seen >= 8

@@ -103,3 +103,19 @@ def test_sum_intense_vs_the_compiled_reference(golden):
         lo, hi, half, mid = (float(v) for v in s[f"c{c}_params"])
         got = O.sum_intense(lo, hi, half, s[f"c{c}_freqs"], s[f"c{c}_times"], s[f"c{c}_db"], mid)
         assert np.float32(got).tobytes() == s[f"c{c}_sum"].tobytes(), c
+
+
+def test_donut_classifier_recordings_vs_compiled_reference(golden):
+    """The donut classifier's own 16 kHz recordings (donut-classifier/16k/*.wav, fixture tests/golden/donut16k_ref.npz):
+    the oracle's classify() and find_midpoints() against what the compiled reference returned for them."""
+    from oracle import oracle as O
+    g = golden("donut16k_ref.npz")
+    names = sorted({k.split("__")[0] for k in g.files})
+    assert len(names) == 6
+    for n in names:
+        x = (g[n + "__pcm"][:, 0].astype(np.float32) / np.float32(32768.0)).astype(np.float32)       # classifier.c:292-297
+        lab, mids, sums = O.classify(x)
+        assert lab == int(g[n + "__label"]) and np.array_equal(mids, g[n + "__midpoints"]) and np.array_equal(sums, g[n + "__sums"])
+        mlab, mmids, msums = O.classify(x, O.CLASSIFY_MICROPHONE)
+        assert mlab == int(g[n + "__mic_label"]) and np.array_equal(mmids, g[n + "__mic_midpoints"]) and np.array_equal(msums, g[n + "__mic_sums"])
+    assert sum(len(g[n + "__mic_midpoints"]) for n in names) >= 8
