@@ -194,7 +194,9 @@ int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long s
  *                                   keep band      midpoint dB   rule  middle <  above >  below >
  *   sync/lib/classifier.cpp         0.65 / 0.80    70            100 / 200 / 80    (:67-68, :436, :109)  default
  *   microphone/src/classifier.cpp   0.70 / 0.85    45            100 / 200 / 150   (:79-80, :448, :123)
- *   microphone/src/classifier.c     0.70 / -       45            50 / 200 / 200    (:120, :608, :164)
+ *   microphone/src/classifier.c     0.70 / 0.85    45            50 / 200 / 200    (:120-121, :608, :164)   float64 file
+ *   donut-classifier/classifier.c   0.70 / 0.85    45            75 / 300 / 100    (:141-142, :660, :184)   float64 file
+ * (the two float64 files: their THRESHOLDS on this library's fp32 arithmetic, which is sync/lib's)
  * The _cfg entry points take a NULL cfg for the default set.                          */
 typedef struct dsp_classify_config {
     float keep_lo, keep_hi;        /* normalised-dB band kept in the 3000-7500 Hz map            */

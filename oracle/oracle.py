@@ -251,6 +251,8 @@ class ClassifyCfg(C.Structure):
 # thresholds of the reference's variants (keep band, midpoint dB, rule middle < / above > / below >)
 CLASSIFY_SYNC_LIB = (0.65, 0.80, 70.0, 100.0, 200.0, 80.0)        # sync/lib/classifier.cpp:67-68, :436, :109
 CLASSIFY_MICROPHONE = (0.70, 0.85, 45.0, 100.0, 200.0, 150.0)     # microphone/src/classifier.cpp:79-80, :448, :123
+CLASSIFY_MICROPHONE_C = (0.70, 0.85, 45.0, 50.0, 200.0, 200.0)    # microphone/src/classifier.c:120-121, :608, :164 (thresholds of the float64 file)
+CLASSIFY_DONUT_C = (0.70, 0.85, 45.0, 75.0, 300.0, 100.0)         # donut-classifier/classifier.c:141-142, :660, :184 (thresholds of the float64 file)
 
 
 def classify(data, cfg=None):

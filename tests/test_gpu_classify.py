@@ -305,3 +305,11 @@ def test_donut_classifier_recordings(dsp, golden):
         assert np.array_equal(trace[0][0], g[n + "__mic_midpoints"]) and np.array_equal(trace[0][1], g[n + "__mic_sums"])
         seen += len(g[n + "__mic_midpoints"])
     assert seen >= 8
+    # the threshold sets of the two float64 files (microphone/src/classifier.c, donut-classifier/classifier.c) against the oracle
+    from oracle import oracle as O
+    for n in names:
+        x = (g[n + "__pcm"][:, 0].astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+        for cname in ("CLASSIFY_MICROPHONE_C", "CLASSIFY_DONUT_C"):
+            labels, trace = dsp.classify_batch(x[None, :], with_trace=True, config=dsp.classify_config(getattr(dsp, cname)))
+            olab, omids, osums = O.classify(x, getattr(O, cname))
+            assert labels[0] == olab and np.array_equal(trace[0][0], omids) and np.array_equal(trace[0][1], osums), (n, cname)
