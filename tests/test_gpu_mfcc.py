@@ -448,4 +448,7 @@ print("RCCL-ONE-RANK-OK")
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    if "RCCL-ONE-RANK-OK" not in r.stdout and "GatherPipeline" not in r.stderr and "AssertionError" not in r.stderr and any(
+            t in r.stderr for t in ("ncclSystemError", "ncclUnhandledCudaError", "unhandled system error", "ncclInternalError", "Address already in use")):
+        pytest.skip("RCCL could not create a one-rank communicator on this box: " + r.stderr.strip().splitlines()[-1][:200])
     assert "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
