@@ -14,6 +14,7 @@
 #include <string>
 
 #include "../../include/dsp_amd.h"
+#include "capi_util.hpp"
 #include "classify_kernels.hpp"
 #include "mfcc_kernels.hpp"
 #include "svm_kernels.hpp"
@@ -112,7 +113,12 @@ const char *dsp_last_error(void) { return g_err.c_str(); }
 #ifndef DSP_AMD_SRC_HASH
 #define DSP_AMD_SRC_HASH "unknown"
 #endif
-const char *dsp_version(void) { return "dsp_amd 0.2 (gfx950) src:" DSP_AMD_SRC_HASH; }
+#ifdef DSP_AMD_EXPERIMENTS
+#define DSP_AMD_EXPERIMENTS_TAG " +experiments"
+#else
+#define DSP_AMD_EXPERIMENTS_TAG ""
+#endif
+const char *dsp_version(void) { return "dsp_amd 0.3 (gfx950)" DSP_AMD_EXPERIMENTS_TAG " src:" DSP_AMD_SRC_HASH; }
 
 int dsp_device_count(void)
 {
@@ -217,7 +223,8 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { delete gen; delete g2k; delete p; return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback"); }
     if (device < 0 || device >= n) { delete gen; delete g2k; delete p; return fail(DSP_EINVAL, "device index out of range"); }
     p->device = device;
-    hipError_t e = hipSetDevice(device);
+    dsp::DeviceScope dsp_device_scope_(device);      // the caller's current device is put back on return
+    hipError_t e = dsp_device_scope_.err;
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) e = hipMalloc(&p->d_tables, sizeof(dsp::LaneTables512));
@@ -239,16 +246,21 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
         dsp_butter_bandpass(cfg->prefilter == DSP_PREFILTER_BUTTER_1000_3000 ? 1000 : 3000,
                             cfg->prefilter == DSP_PREFILTER_BUTTER_1000_3000 ? 3000 : 7500, b, a);
         dsp::PrefilterScan sc;
-        if (!dsp::build_prefilter_scan(b, a, sc, why)) { hipFree(p->d_tables); if (p->d_gen_tables) hipFree(p->d_gen_tables); delete p; return fail(DSP_EINVAL, why); }
+        if (!dsp::build_prefilter_scan(b, a, sc, why)) { dsp_mfcc_plan_destroy(p); return fail(DSP_EINVAL, why); }
         e = hipMalloc(&p->d_scan, sizeof(sc));
         if (e == hipSuccess) e = hipMemcpy(p->d_scan, &sc, sizeof(sc), hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) e = hipMalloc(&p->d_row_tables, sizeof(dsp::RowTables512));
+#ifdef DSP_AMD_EXPERIMENTS
+    // measured dead ends kept buildable (python -m dsp_amd.build with DSP_AMD_EXPERIMENTS=1): the row-per-frame kernel and
+    // the two-frames-per-wave kernel; the default library does not carry them
     if (e == hipSuccess && cfg->n_fft == 512) {
-        auto *rt = new dsp::RowTables512;
-        dsp::build_row_tables_512(*cfg, *rt);
-        e = hipMemcpy(p->d_row_tables, rt, sizeof(*rt), hipMemcpyHostToDevice);
-        delete rt;
+        e = hipMalloc(&p->d_row_tables, sizeof(dsp::RowTables512));
+        if (e == hipSuccess) {
+            auto *rt = new dsp::RowTables512;
+            dsp::build_row_tables_512(*cfg, *rt);
+            e = hipMemcpy(p->d_row_tables, rt, sizeof(*rt), hipMemcpyHostToDevice);
+            delete rt;
+        }
     }
     if (e == hipSuccess && cfg->n_fft == 512) {
         dsp::PairExtra512 px;
@@ -256,11 +268,9 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
         e = hipMalloc(&p->d_pair, sizeof(px));
         if (e == hipSuccess) e = hipMemcpy(p->d_pair, &px, sizeof(px), hipMemcpyHostToDevice);
     }
+#endif
     if (e != hipSuccess) {
-        if (p->d_tables) hipFree(p->d_tables);
-        if (p->d_row_tables) hipFree(p->d_row_tables);
-        if (p->d_pair) hipFree(p->d_pair);
-        delete p;
+        dsp_mfcc_plan_destroy(p);          // frees every member that was allocated
         return fail(DSP_EHIP, std::string("plan_create: ") + hipGetErrorString(e));
     }
     p->n_cu = prop.multiProcessorCount;
@@ -272,17 +282,18 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
                                                               cfg->frame_length == 512, false);
         p->resident_blocks = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
                                                         cfg->frame_length == 512, true);
+#ifdef DSP_AMD_EXPERIMENTS
         p->resident_blocks_row = dsp::mfcc512_row_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
                                                                 cfg->frame_length == 512);
         p->resident_blocks_pair = dsp::mfcc512_pair_blocks_per_cu();
+#endif
     } else {
         p->resident_blocks_gen = dsp::mfcc1024_blocks_per_cu(cfg->frame_length == 1024);
         p->resident_blocks_gen_wave = dsp::mfcc1024_wave_blocks_per_cu(cfg->frame_length == 1024);
         if (p->d_scan) p->resident_blocks_gen_pre = dsp::mfcc1024_wave_blocks_per_cu(true, true);
     }
     if (const char *k = std::getenv("DSP_AMD_KERNEL")) {
-        const int id = std::atoi(k);
-        p->kernel = id == 1 ? DSP_KERNEL_ROW : (id == 2 ? DSP_KERNEL_WAVE_FRAME : (id == 3 ? DSP_KERNEL_PAIR : DSP_KERNEL_WAVE));
+        if (dsp_mfcc_plan_set_kernel(p, std::atoi(k)) != DSP_OK) { dsp_mfcc_plan_destroy(p); return DSP_EINVAL; }
     }
     *out = p;
     return DSP_OK;
@@ -291,7 +302,7 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
 void dsp_mfcc_plan_destroy(dsp_mfcc_plan *p)
 {
     if (!p) return;
-    hipSetDevice(p->device);
+    dsp::DeviceScope dsp_device_scope_(p->device);
     if (p->d_tables) hipFree(p->d_tables);
     if (p->d_row_tables) hipFree(p->d_row_tables);
     if (p->d_gen_tables) hipFree(p->d_gen_tables);
@@ -316,6 +327,12 @@ int dsp_mfcc_plan_config(const dsp_mfcc_plan *p, dsp_mfcc_config *cfg)
 int dsp_mfcc_plan_set_kernel(dsp_mfcc_plan *p, int kernel)
 {
     if (!p || (kernel != DSP_KERNEL_WAVE && kernel != DSP_KERNEL_ROW && kernel != DSP_KERNEL_WAVE_FRAME && kernel != DSP_KERNEL_PAIR)) return fail(DSP_EINVAL, "bad kernel id");
+#ifndef DSP_AMD_EXPERIMENTS
+    // DSP_KERNEL_ROW on a 1024-point plan selects the general Stockham kernel (a product path: the fallback for filterbanks
+    // the wave kernel's tables do not hold); the 512-point row / pair kernels are experiments outside the default build
+    if (kernel == DSP_KERNEL_PAIR || (kernel == DSP_KERNEL_ROW && p->cfg.n_fft != 1024))
+        return fail(DSP_EINVAL, "DSP_KERNEL_ROW / DSP_KERNEL_PAIR (512-point experiments) are not in this build: rebuild with DSP_AMD_EXPERIMENTS=1");
+#endif
     p->kernel = kernel;
     return DSP_OK;
 }
@@ -341,7 +358,7 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
                long clip_stride, void *stream, int in_kind = 0, bool fused_prefilter = false)
 {
     if (n_frames == 0) return DSP_OK;
-    DSP_HIP(hipSetDevice(p->device));       // the caller's current device may be another GPU: tables and workspaces live on the plan's
+    DSP_ON_DEVICE(p->device);       // the caller's current device may be another GPU: tables and workspaces live on the plan's
     const bool single_clip = frames_per_clip > 0 && n_frames == frames_per_clip;   // stride unused
     if ((reinterpret_cast<uintptr_t>(d_in) & (in_kind == 1 ? 3 : 7)) || (!single_clip && (clip_stride & 1)))
         return fail(DSP_EINVAL, "input must be 8-byte aligned (4 for mono int16) with an even clip stride");
@@ -384,10 +401,14 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     a.hop = p->cfg.hop_length;
     a.frame_len = p->cfg.frame_length;
     const bool gen = p->cfg.n_fft == 1024;
-    const bool row = !gen && p->kernel == DSP_KERNEL_ROW;
+#ifdef DSP_AMD_EXPERIMENTS
+    const bool row = !gen && p->kernel == DSP_KERNEL_ROW && p->cfg.n_fft == 512;
     // two frames per wavefront step (experiment): the reference shape on independent full frames only, else the default form
     const bool pair = !gen && p->kernel == DSP_KERNEL_PAIR && p->d_pair && in_kind == 0 && frames_per_clip == 0 && p->cfg.frame_length == 512 &&
                       p->cfg.log_mode == DSP_LOG_PER_FRAME_MAX && p->host.dct_split == 4 && p->host.dct_len == 10 && p->host.mel_gather == 3;
+#else
+    const bool row = false, pair = false;
+#endif
     // 16-frame tile epilogue: per-frame log mode on the wave-per-frame kernel
     const bool tile = !gen && (p->kernel == DSP_KERNEL_WAVE || p->kernel == DSP_KERNEL_PAIR) && p->cfg.log_mode == DSP_LOG_PER_FRAME_MAX;
     // 1024-point: the register-resident wave kernel when the filterbank fits two chunk slots per lane (DSP_KERNEL_ROW selects
@@ -437,11 +458,13 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
         DSP_HIP(dsp::launch_mfcc1024_wave(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream, fused_prefilter ? p->d_scan : nullptr));
     else if (gen)
         DSP_HIP(dsp::launch_mfcc1024(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream));
+#ifdef DSP_AMD_EXPERIMENTS
     else if (pair)
         DSP_HIP(dsp::launch_mfcc512_pair(a, p->d_pair, (int)blocks, (hipStream_t)stream));
     else if (row)
         DSP_HIP(dsp::launch_mfcc512_row(a, p->d_row_tables, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks,
                                         (hipStream_t)stream));
+#endif
     else
         DSP_HIP(dsp::launch_mfcc512(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream, tile));
     return DSP_OK;
@@ -461,7 +484,7 @@ int dsp_mfcc_frames_device(dsp_mfcc_plan *p, const float *d_frames, long n_frame
         return run(p, d_frames, d_out, n_frames, 0, 0, stream, 0, true);
     // Otherwise two passes: filtered frames go through a bounded workspace (sub-batches of <= 1 Mi frames).
     std::lock_guard<std::recursive_mutex> lock(p->mu);
-    DSP_HIP(hipSetDevice(p->device));
+    DSP_ON_DEVICE(p->device);
     const int fl = p->cfg.frame_length;
     const long sub = std::min<long>(n_frames, 1L << 20);
     int rc;
@@ -511,7 +534,7 @@ int dsp_mfcc_frames_host(dsp_mfcc_plan *p, const float *frames, long n_frames, f
     if (!p || n_frames < 0 || (n_frames > 0 && (!frames || !out))) return fail(DSP_EINVAL, "bad argument");
     if (n_frames == 0) return DSP_OK;
     std::lock_guard<std::recursive_mutex> lock(p->mu);
-    DSP_HIP(hipSetDevice(p->device));
+    DSP_ON_DEVICE(p->device);
     const size_t in_b = (size_t)n_frames * p->cfg.frame_length * sizeof(float);
     const size_t out_b = (size_t)n_frames * p->cfg.n_mfcc * sizeof(float);
     int rc;
@@ -534,7 +557,7 @@ int dsp_mfcc_clips_host(dsp_mfcc_plan *p, const float *signal, long n_clips, int
     if (!signal || !out) return fail(DSP_EINVAL, "NULL buffer");
     if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
     std::lock_guard<std::recursive_mutex> lock(p->mu);
-    DSP_HIP(hipSetDevice(p->device));
+    DSP_ON_DEVICE(p->device);
     // device copy is packed with an even stride so every frame start stays 8-byte aligned
     const long dstride = samples_per_clip + (samples_per_clip & 1);
     const size_t in_b = (size_t)n_clips * dstride * sizeof(float);
@@ -611,7 +634,7 @@ int cls_init(int device = -1)
     if (g_cls.d_tab && g_cls.device == device) return DSP_OK;
     if (g_cls.d_tab) cls_release();
     g_cls.device = device;
-    DSP_HIP(hipSetDevice(g_cls.device));
+    DSP_ON_DEVICE(g_cls.device);
     dsp::SpecTables t;
     dsp::build_spec_tables(16000, t);
     DSP_HIP(hipMalloc(&g_cls.d_tab, sizeof(t)));
@@ -638,7 +661,7 @@ void cls_free_workspace()
 
 void cls_release()
 {
-    hipSetDevice(g_cls.device);
+    dsp::DeviceScope dsp_device_scope_(g_cls.device);
     hipDeviceSynchronize();
     cls_free_workspace();
     if (g_cls.d_tab) hipFree(g_cls.d_tab);
@@ -712,7 +735,7 @@ int dsp_butter_bandpass_filter_f32(const float *data, long n_clips, int n, long 
     std::lock_guard<std::mutex> lock(g_cls.mu);
     int rc = cls_init();
     if (rc < 0) return rc;
-    DSP_HIP(hipSetDevice(g_cls.device));
+    DSP_ON_DEVICE(g_cls.device);
     float *dx = nullptr, *dy = nullptr;
     const size_t bytes = (size_t)n_clips * n * sizeof(float);
     DSP_HIP(hipMalloc(&dx, bytes));
@@ -735,7 +758,7 @@ int dsp_butter_bandpass_filter_f64(const double *data, long n_clips, int n, long
     std::lock_guard<std::mutex> lock(g_cls.mu);
     int rc = cls_init();
     if (rc < 0) return rc;
-    DSP_HIP(hipSetDevice(g_cls.device));
+    DSP_ON_DEVICE(g_cls.device);
     double *dx = nullptr, *dy = nullptr;
     const size_t bytes = (size_t)n_clips * n * sizeof(double);
     DSP_HIP(hipMalloc(&dx, bytes));
@@ -762,7 +785,7 @@ int dsp_compute_spectrogram_f32(const float *signal, int n, int fs, float *frequ
     std::lock_guard<std::mutex> lock(g_cls.mu);
     int rc = cls_init();
     if (rc < 0) return rc;
-    DSP_HIP(hipSetDevice(g_cls.device));
+    DSP_ON_DEVICE(g_cls.device);
     float *dx = nullptr, *ds = nullptr;
     dsp::SpecTables *dt = nullptr;               // fs enters only through the PSD scale U = fs * sum w^2 (classifier.cpp:296-301)
     DSP_HIP(hipMalloc(&dx, (size_t)n * sizeof(float)));
@@ -796,7 +819,7 @@ int dsp_compute_spectrogram_f64(const double *signal, int n, int fs, double *fre
     std::lock_guard<std::mutex> lock(g_cls.mu);
     int rc = cls_init();
     if (rc < 0) return rc;
-    DSP_HIP(hipSetDevice(g_cls.device));
+    DSP_ON_DEVICE(g_cls.device);
     double *dx = nullptr, *ds = nullptr;
     DSP_HIP(hipMalloc(&dx, (size_t)n * sizeof(double)));
     const size_t sb = (size_t)dsp::kSpecBins * T * sizeof(double);
@@ -831,7 +854,7 @@ int dsp_sum_intense_f32(float lower, float upper, float half_range, const float 
     std::lock_guard<std::mutex> lock(g_cls.mu);
     int rc = cls_init();
     if (rc < 0) return rc;
-    DSP_HIP(hipSetDevice(g_cls.device));
+    DSP_ON_DEVICE(g_cls.device);
     const size_t nf = freq_bins, nt = time_bins, total = nf + nt + nf * nt + 1;
     float *d = nullptr;
     DSP_HIP(hipMalloc(&d, total * sizeof(float)));
@@ -865,7 +888,7 @@ int dsp_classify_batch_host_cfg(const dsp_classify_config *cfgp, const float *si
     std::lock_guard<std::mutex> lock(g_cls.mu);
     int rc = cls_init();
     if (rc < 0) return rc;
-    DSP_HIP(hipSetDevice(g_cls.device));
+    DSP_ON_DEVICE(g_cls.device);
     for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
         const long cnt = std::min(kClsSubBatch, n_clips - c0);
         if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n, true)) < 0) return rc;
@@ -900,7 +923,7 @@ int dsp_classify_batch_device_cfg(const dsp_classify_config *cfgp, const float *
     }
     int rc = cls_init(attr.device);
     if (rc < 0) return rc;
-    DSP_HIP(hipSetDevice(g_cls.device));
+    DSP_ON_DEVICE(g_cls.device);
     hipStream_t st = (hipStream_t)stream;
     if (spec_bins(n) == 0) { DSP_HIP(hipMemsetAsync(d_labels, 0, (size_t)n_clips * sizeof(int), st)); DSP_HIP(hipStreamSynchronize(st)); return DSP_OK; }
     for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
@@ -960,14 +983,14 @@ int dsp_mfcc_stats_device(const float *d_mfcc, long n_clips, int n_frames, int n
 {
     if (n_clips < 0 || n_frames <= 0 || n_coef <= 0 || n_coef > 64 || (n_clips > 0 && (!d_mfcc || !d_feat)))
         return fail(DSP_EINVAL, "bad argument");
-    if (n_clips > 0) {      // no handle here: launch on the GPU the caller's buffer lives on
-        hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, d_mfcc) != hipSuccess || attr.type != hipMemoryTypeDevice) {
-            (void)hipGetLastError();
-            return fail(DSP_EINVAL, "d_mfcc is not a device pointer");
-        }
-        DSP_HIP(hipSetDevice(attr.device));
+    if (n_clips == 0) return DSP_OK;
+    // no handle here: launch on the GPU the caller's buffer lives on
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, d_mfcc) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(DSP_EINVAL, "d_mfcc is not a device pointer");
     }
+    DSP_ON_DEVICE(attr.device);
     DSP_HIP(dsp::launch_mfcc_stats(d_mfcc, n_clips, n_frames, n_coef, d_feat, (hipStream_t)stream));
     return DSP_OK;
 }
@@ -982,7 +1005,7 @@ int dsp_svm_create(int device, int n_features, int n_sv, const float *offset, co
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback");
     if (device < 0 || device >= n) return fail(DSP_EINVAL, "device index out of range");
-    DSP_HIP(hipSetDevice(device));
+    DSP_ON_DEVICE(device);
     auto *s = new dsp_svm;
     s->device = device;
     const size_t nf = n_features, ns = n_sv, total = 2 * nf + ns * nf + ns;
@@ -1001,7 +1024,7 @@ int dsp_svm_create(int device, int n_features, int n_sv, const float *offset, co
 void dsp_svm_destroy(dsp_svm *s)
 {
     if (!s) return;
-    hipSetDevice(s->device);
+    dsp::DeviceScope dsp_device_scope_(s->device);
     if (s->d_blob) hipFree(s->d_blob);
     delete s;
 }
@@ -1022,7 +1045,7 @@ int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signa
     if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
     if ((reinterpret_cast<uintptr_t>(d_signal) & 7) || (n_clips > 1 && (clip_stride & 1))) return fail(DSP_EINVAL, "input must be 8-byte aligned with an even clip stride");
     if (s->device != p->device) return fail(DSP_EINVAL, "plan and SVM live on different devices");
-    DSP_HIP(hipSetDevice(p->device));
+    DSP_ON_DEVICE(p->device);
     dsp::Mfcc512Args a{};
     a.in = d_signal;
     a.in_kind = 0;
@@ -1060,7 +1083,7 @@ int dsp_svm_predict_device(dsp_svm *s, const float *d_feat, long n_clips, int *d
                            float *d_prob1, void *stream)
 {
     if (!s || n_clips < 0 || (n_clips > 0 && (!d_feat || !d_labels))) return fail(DSP_EINVAL, "bad argument");
-    DSP_HIP(hipSetDevice(s->device));
+    DSP_ON_DEVICE(s->device);
     DSP_HIP(dsp::launch_svm_predict(s->m, d_feat, n_clips, d_labels, d_decision, d_prob1, (hipStream_t)stream));
     return DSP_OK;
 }

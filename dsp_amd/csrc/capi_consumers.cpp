@@ -56,7 +56,7 @@ int dsp_stop_model_create(const dsp_stop_model_params *p, int device, dsp_stop_m
     if (p->units[3] != 1) return capi_fail(DSP_EINVAL, "the last layer must have one unit (sigmoid output)");
     int rc = check_device(device);
     if (rc < 0) return rc;
-    DSP_CAPI_HIP(hipSetDevice(device));
+    DSP_ON_DEVICE(device);
     const size_t n_in = (size_t)p->n_coef * p->max_frames, u1 = p->units[0];
     // divisor with the reference's zero guard (audio_classifier_inference.c:44-45)
     std::vector<float> div(n_in);
@@ -106,7 +106,7 @@ int dsp_stop_model_create(const dsp_stop_model_params *p, int device, dsp_stop_m
 void dsp_stop_model_destroy(dsp_stop_model *m)
 {
     if (!m) return;
-    hipSetDevice(m->device);
+    dsp::DeviceScope dsp_device_scope_(m->device);
     if (m->plan) dsp_mfcc_plan_destroy(m->plan);
     for (void *p : {(void *)m->d_blob, (void *)m->d_mfcc, (void *)m->d_sig, (void *)m->d_prob})
         if (p) hipFree(p);
@@ -131,7 +131,7 @@ int dsp_classify_signal_batch_device(dsp_mfcc_plan *plan, dsp_stop_model *m, con
     if (n_clips == 0) return DSP_OK;
     const int t = dsp_mfcc_frames_for(&cfg, samples_per_clip, m->m.max_frames);          // stop_detector.c:18-21
     std::lock_guard<std::mutex> lock(m->mu);
-    DSP_CAPI_HIP(hipSetDevice(m->device));
+    DSP_ON_DEVICE(m->device);
     const size_t need = (size_t)n_clips * (t > 0 ? t : 1) * cfg.n_mfcc * sizeof(float);
     if (m->mfcc_cap < need) {
         if (m->d_mfcc) { hipFree(m->d_mfcc); m->d_mfcc = nullptr; m->mfcc_cap = 0; }
@@ -152,7 +152,8 @@ float dsp_classify_signal(dsp_stop_model *m, const float *signal, int num_sample
     auto bail = [](const char *what) { std::fprintf(stderr, "libdsp_amd: classify_signal: %s: %s\n", what, dsp_last_error()); return 0.0f; };
     {
         std::lock_guard<std::mutex> lock(m->mu);
-        if (hipSetDevice(m->device) != hipSuccess) { capi_fail(DSP_EHIP, "hipSetDevice"); return bail("device"); }
+        dsp::DeviceScope dsp_device_scope_(m->device);
+        if (dsp_device_scope_.err != hipSuccess) { capi_fail(DSP_EHIP, "hipSetDevice"); return bail("device"); }
         if (!m->plan) {
             dsp_mfcc_config cfg;
             dsp_mfcc_default_config(&cfg);
@@ -187,7 +188,7 @@ int dsp_speaker_model_create(const dsp_gmm_params *target, const dsp_gmm_params 
     if (target->k != ubm->k || target->d != ubm->d) return capi_fail(DSP_EINVAL, "target and UBM must have the same shape");
     int rc = check_device(device);
     if (rc < 0) return rc;
-    DSP_CAPI_HIP(hipSetDevice(device));
+    DSP_ON_DEVICE(device);
     const size_t kd = (size_t)target->k * target->d, k = target->k;
     // layout: int32 inv_covs (t, u), int16 log_consts (t, u), int8 means (t, u)
     const size_t bytes = 2 * kd * 4 + 2 * k * 2 + 2 * kd;
@@ -214,7 +215,7 @@ int dsp_speaker_model_create(const dsp_gmm_params *target, const dsp_gmm_params 
 void dsp_speaker_model_destroy(dsp_speaker_model *m)
 {
     if (!m) return;
-    hipSetDevice(m->device);
+    dsp::DeviceScope dsp_device_scope_(m->device);
     if (m->d_blob) hipFree(m->d_blob);
     delete m;
 }

@@ -16,3 +16,24 @@ int capi_fail(int code, const std::string &msg);   // sets dsp_last_error() for 
         hipError_t e_ = (call);                                                                         \
         if (e_ != hipSuccess) return dsp::capi_fail(DSP_EHIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// The entry points work on the GPU their plan / model / buffers live on, which need not be the caller's current device
+// (torch keeps its own idea of it): switch for the duration of the call and put the caller's device back on every exit.
+namespace dsp {
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device); else prev = -1;      // nothing to restore
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+}
+#define DSP_ON_DEVICE(dev)                                                                                        \
+    dsp::DeviceScope dsp_device_scope_(dev);                                                                      \
+    if (dsp_device_scope_.err != hipSuccess)                                                                      \
+        return dsp::capi_fail(DSP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(dsp_device_scope_.err))

@@ -6,7 +6,7 @@
  * those declarations for callers that do not have the reference tree; it is C++ only (the reference
  * header has no extern "C").  Plain pointers and sizes, host memory, the reference's ownership rules.
  *
- * Results are bit-identical to the compiled reference (tests/test_gpu_boundary_cxx.py); all arithmetic
+ * Results are bit-identical to the compiled reference (tests/test_boundary_cxx.py); all arithmetic
  * runs in the gfx950 kernels of dsp_amd/csrc/classify_kernels.hip, and without a GPU every function
  * fails loudly (reason in dsp_last_error()) while keeping the reference's return convention.
  */

@@ -222,6 +222,20 @@ int orc_classify_speaker(const orc_gmm *target, const orc_gmm *ubm, const float 
 /* sync/particle/main.cpp:62-77  linear-interpolation resampler (fp32, no contraction). */
 void orc_upsample_linear(const float *in, int old_size, float *out, int new_size);
 
+/* ---- aubio front end of cepstrum/scrubjay_infer.c:21-53 (aubio_oracle.c) -- PARITY UNPINNED ------------------
+ * aubio is an unvendored, unpinned third-party dependency (cepstrum/CMakeLists.txt:10) absent from this image;
+ * these restate the published algorithm of aubio 0.4.9 (routine names in aubio_oracle.c).                      */
+/* new_aubio_window("hanningz", n) */
+void orc_aubio_window_hanningz(int n, float *w);
+/* aubio_filterbank_set_mel_coeffs_slaney on a (40, win_s / 2 + 1) bank, unit-area triangles: filters[40][win_s/2+1] */
+void orc_aubio_filterbank_slaney(int sample_rate, int win_s, float *filters);
+/* scrubjay_infer.c:39-53  frames the do/while yields for an n-sample file: ceil(n / hop_s) */
+int orc_aubio_frames_for(int num_samples, int hop_s);
+/* scrubjay_infer.c:41-45  aubio_source_do -> aubio_pvoc_do -> aubio_mfcc_do per hop: out[T][n_coefs], returns T
+ * (-1: unsupported arguments; n_filters must be 40 as in scrubjay_infer.c:13)                                   */
+int orc_aubio_mfcc_clip(const float *signal, int num_samples, int sample_rate, int win_s, int hop_s, int n_filters,
+                        int n_coefs, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,8 +63,8 @@ PREFILTER_NONE, PREFILTER_BUTTER_1000_3000, PREFILTER_BUTTER_3000_7500 = 0, 1, 2
 def build(force: bool = False) -> None:
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "dsp_oracle.c")
-    stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src)
+    srcs = [os.path.join(_HERE, f) for f in ("dsp_oracle.c", "aubio_oracle.c", "dsp_oracle.h")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(so) < os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
     if os.path.isdir(os.environ.get("DSP_REF", "/root/reference")):
@@ -121,6 +121,12 @@ def lib() -> C.CDLL:
         L.orc_classify_speaker.argtypes = [C.POINTER(Gmm), C.POINTER(Gmm), _F, C.c_int]
         L.orc_classify_speaker.restype = C.c_int
         L.orc_upsample_linear.argtypes = [_F, C.c_int, _F, C.c_int]
+        L.orc_aubio_window_hanningz.argtypes = [C.c_int, _F]
+        L.orc_aubio_filterbank_slaney.argtypes = [C.c_int, C.c_int, _F]
+        L.orc_aubio_frames_for.argtypes = [C.c_int, C.c_int]
+        L.orc_aubio_frames_for.restype = C.c_int
+        L.orc_aubio_mfcc_clip.argtypes = [_F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]
+        L.orc_aubio_mfcc_clip.restype = C.c_int
         _lib = L
     return _lib
 
@@ -375,6 +381,36 @@ def upsample_linear(x: np.ndarray, new_size: int) -> np.ndarray:
 
 
 # ---- the reference itself (only where oracle/_ref was built) -------------------
+
+# ---- aubio front end of cepstrum/scrubjay_infer.c:21-53 (aubio_oracle.c, parity unpinned) ----
+
+def aubio_window_hanningz(n: int) -> np.ndarray:
+    w = np.empty(n, np.float32)
+    lib().orc_aubio_window_hanningz(n, w)
+    return w
+
+
+def aubio_filterbank_slaney(sample_rate: int = 16000, win_s: int = 2048) -> np.ndarray:
+    fb = np.empty((40, win_s // 2 + 1), np.float32)
+    lib().orc_aubio_filterbank_slaney(sample_rate, win_s, fb)
+    return fb
+
+
+def aubio_frames_for(n: int, hop_s: int = 1024) -> int:
+    return lib().orc_aubio_frames_for(n, hop_s)
+
+
+def aubio_mfcc_clip(signal: np.ndarray, sample_rate: int = 16000, win_s: int = 2048, hop_s: int = 1024, n_filters: int = 40,
+                    n_coefs: int = 20) -> np.ndarray:
+    """scrubjay_infer.c:41-45 per hop: [T][n_coefs], T = ceil(n / hop_s)."""
+    signal = np.ascontiguousarray(signal, np.float32)
+    T = aubio_frames_for(signal.size, hop_s)
+    out = np.empty((max(T, 1), n_coefs), np.float32)
+    got = lib().orc_aubio_mfcc_clip(signal, signal.size, sample_rate, win_s, hop_s, n_filters, n_coefs, out)
+    if got < 0:
+        raise ValueError("orc_aubio_mfcc_clip: unsupported arguments")
+    return out[:got]
+
 
 def have_ref() -> bool:
     return os.path.exists(os.path.join(_HERE, "_ref", "libref_mfcc.so"))
