@@ -16,6 +16,11 @@ measured beside it in the same line (`config4`: 12 500 x 1 s clips per rank per 
 batch k overlaps the kernels of batch k + 1; dsp_amd/dist.py GatherPipeline).  --gather
 adds the same pipelined gather to the frames workload.
 
+The line explains itself: `sensors` holds shader clock, package power and temperatures read in-process from sysfs (amdgpu
+hwmon; tools/gpu_sensors.py) before, during and after the timed region -- the headline kernel runs at the package power
+cap, so its time follows the clock the power manager grants, which differs from box to box -- and `roofline` carries the
+minimum and median of the per-launch times beside their average.
+
 Rank 0 prints ONE JSON line.  `value` = frames all ranks processed / max-over-
 ranks wall time of the K timed steps.  `roofline.achieved` = algorithmic bytes
 per launch (2100 B/frame) / average kernel time measured with HIP events on the
@@ -71,6 +76,58 @@ def pmc_traffic(workload: str, units_per_launch: int):
     return best
 
 
+_REF_WORKER = r"""
+import ctypes, sys, time
+import numpy as np
+lib, n, seconds, seed = sys.argv[1], int(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4])
+L = ctypes.CDLL(lib)
+F = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+L.compute_mfcc.argtypes = [F, ctypes.c_int, F, ctypes.c_int]
+L.compute_mfcc.restype = ctypes.c_int
+sig = np.random.default_rng(seed).uniform(-1, 1, 400 + 160 * (n - 1)).astype(np.float32)
+out = np.empty(n * 13, np.float32)
+L.compute_mfcc(sig, sig.size, out, n)                 # page everything in
+print("READY", flush=True)
+sys.stdin.readline()                                  # all workers start together
+got, t0 = 0, time.perf_counter()
+while time.perf_counter() - t0 < seconds:
+    got += L.compute_mfcc(sig, sig.size, out, n)
+print(got, time.perf_counter() - t0, flush=True)
+"""
+
+
+def reference_all_cores(ncpu: int, seconds: float = 6.0):
+    """The reference's own compute_mfcc on every host core: its static scratch (mfcc.c:21-22) forbids threads, not processes, so
+    `ncpu` child PROCESSES each load the compiled reference (oracle/_ref) and run it on a private clip for `seconds`; frames of all
+    of them / the longest child's time.  The children never touch the GPU."""
+    import subprocess
+    from oracle import oracle as O
+    lib = os.path.join(os.path.dirname(os.path.abspath(O.__file__)), "_ref", "libref_mfcc.so")
+    n = 20_000                                            # frames per pass: ~0.2 s, so every child stops close to `seconds`
+    procs = [subprocess.Popen([sys.executable, "-c", _REF_WORKER, lib, str(n), str(seconds), str(100 + i)], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, text=True) for i in range(ncpu)]
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "READY":
+                raise RuntimeError("reference worker did not start")
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        res = [p.stdout.readline().split() for p in procs]
+        frames = sum(int(r[0]) for r in res)
+        wall = max(float(r[1]) for r in res)
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:  # noqa: BLE001
+                pass
+            p.wait(timeout=30)
+    return {"value": frames / wall, "unit": "frames/s", "cores": ncpu, "kind": "reference",
+            "sample": f"{frames} frames: {ncpu} processes x the reference's compute_mfcc (compiled -O2 from its own mfcc.c) over a "
+                      f"{400 + 160 * (n - 1)}-sample clip each (frame 400 / hop 160, n_fft 512), {wall:.1f} s"}
+
+
 def cpu_baseline(sample_frames: int, seconds_budget: float = 25.0):
     """Time the CPU path on this host.  Only bench.py's baseline leg touches oracle/."""
     import numpy as np
@@ -89,19 +146,23 @@ def cpu_baseline(sample_frames: int, seconds_budget: float = 25.0):
         L = O.ref_mfcc_lib()
         out = np.empty((n, 13), np.float32)
         reps, got, t0 = 0, 0, time.perf_counter()
-        while reps < 1 or time.perf_counter() - t0 < 0.4 * seconds_budget:      # ~10 s of single-thread work
+        while reps < 1 or time.perf_counter() - t0 < 0.3 * seconds_budget:      # ~8 s of single-thread work
             got += L.compute_mfcc(sig, sig.size, out.reshape(-1), n)
             reps += 1
         dt = time.perf_counter() - t0
         res = {"value": got / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
                "sample": f"{got} frames ({reps} passes over one {sig.size}-sample clip, frame 400 / hop 160, n_fft 512) through "
                          f"the reference's compute_mfcc compiled -O2 from its own mfcc.c, {dt:.1f} s"}
+        try:
+            res["reference_all_cores"] = reference_all_cores(ncpu, 0.25 * seconds_budget)
+        except Exception as exc:  # noqa: BLE001
+            res["reference_all_cores"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     # (b) the oracle (restatement) on the bench's own frame shape, all host cores
     cfg = O.default_cfg(frame_length=FRAME, hop_length=FRAME)
     n = min(sample_frames, 60_000 * max(1, ncpu))
     fr = rng.uniform(-1, 1, (n, FRAME)).astype(np.float32)
     reps, t0 = 0, time.perf_counter()
-    while reps < 1 or time.perf_counter() - t0 < 0.4 * seconds_budget:
+    while reps < 1 or time.perf_counter() - t0 < 0.3 * seconds_budget:
         O.mfcc_frames(fr, cfg, threads=ncpu)
         reps += 1
     dt = time.perf_counter() - t0
@@ -113,9 +174,62 @@ def cpu_baseline(sample_frames: int, seconds_budget: float = 25.0):
     return res
 
 
+def open_sensors(local: int):
+    """sysfs sensors of this rank's GPU (None where the box does not expose them)."""
+    try:
+        from tools.gpu_sensors import Sensors
+        s = Sensors.for_device(local)
+        return s if s.available else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def sensor_block(sens, before, during, after):
+    if sens is None:
+        return None
+    return {"source": "amdgpu hwmon (sysfs), read in-process; the SMU low-pass filters these readings over ~0.3 s",
+            "power_cap_w": sens.power_cap_w(), "before": before, "during": during, "after": after}
+
+
+def step_stats(events, torch):
+    """Per-launch times from an event recorded after every step: average over the region, minimum, median."""
+    import statistics
+    per = [events[i].elapsed_time(events[i + 1]) for i in range(len(events) - 1)]
+    return {"avg": events[0].elapsed_time(events[-1]) / len(per), "min": min(per), "median": statistics.median(per), "max": max(per)}
+
+
+class Watchdog:
+    """A secondary leg that talks to other ranks can hang when ONE rank fails (the others wait in a collective).  The headline is
+    already measured when such a leg starts: after `seconds` every rank leaves the process, rank 0 printing the stashed line
+    first.  Cancelled when the leg returns."""
+
+    def __init__(self, seconds: float, rank: int, stash_line):
+        import threading
+        self.rank, self.stash_line = rank, stash_line
+        self.timer = threading.Timer(seconds, self.fire)
+        self.timer.daemon = True
+        self.seconds = seconds
+
+    def fire(self, reason: str = None):
+        if self.rank == 0:
+            line = self.stash_line()
+            line["config4"] = {"error": reason or f"no result after {self.seconds:.0f} s (a rank failed or a collective hung); the headline above was measured before this leg"}
+            print(json.dumps(line), flush=True)
+        os._exit(0 if self.rank == 0 else 3)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
 def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
     """Secondary measurements (not the headline metric): same timing protocol, its own JSON line."""
     gen = torch.Generator(device=dev).manual_seed(2000 + rank)
+    side_finish = None                 # drains a pipelined gather at the end of a region (config 5 at N > 1)
     if args.workload == "pcm16":
         n = args.clips or 1_000_000
         pcm = torch.randint(-32768, 32768, (n, FRAME), dtype=torch.int16, device=dev, generator=gen)
@@ -133,12 +247,30 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         attrs = dict(np.load(os.path.join(ROOT, "tests", "golden", "scrubjay_svm.npz")))
         own = args.workload == "config5_2048"                  # scrubjay_infer.c:10-14's own framing: WIN_SIZE 2048, HOP_SIZE 1024
         sj = ScrubJay(attrs, local, config=scrubjay_infer_config(16000)) if own else ScrubJay(attrs, local)
-        step = lambda: sj(clips, 500, fused=True)              # noqa: E731
+        # N > 1: the per-clip results -- int32 label + fp32 probability, 8 B per clip, 1 MB per rank at 125 000 clips --
+        # are all-gathered every step, pipelined like config 4's matrices (dist.GatherPipeline on a packed [n][2] int32 block)
+        from dsp_amd.dist import GatherPipeline
+        lab_pipe = GatherPipeline(n, (2,), torch.int32, dev) if world > 1 else None
+
+        def step():
+            if lab_pipe is None:
+                sj(clips, 500, fused=True)
+                return
+
+            def compute(block):
+                labels, _dec, p1, _feat = sj(clips, 500, fused=True)
+                block[:, 0].copy_(labels)
+                block[:, 1].copy_(p1.view(torch.int32))
+            lab_pipe.submit(compute)
+        side_finish = lab_pipe.drain if lab_pipe is not None else None
         units, unit, bytes_per = n, "clips/s", 64_000 + 8      # label + probability out
         what = (f"BASELINE configs[4] per-GPU share ({n} clips): 1 s 16 kHz fp32 clip -> MFCC(20) -> mean|std -> Scaler -> RBF-SVM "
                 "(scrubjay_svm.onnx attributes) fused in ONE kernel, one wavefront per clip; the MFCC matrix never reaches HBM"
-                + ("; framing of scrubjay_infer.c itself (n_fft 2048, hop 1024, 40 mel, 20 coefficients: 14 frames per clip)" if own else ""))
-        kernel = "mfcc2048_kernel<POOL>" if own else "mfcc512_wave_kernel<POOL>"
+                + ("; the front end cepstrum/scrubjay_infer.c itself runs, aubio semantics (dsp_mfcc_scrubjay_infer_config: streaming 2048 / 1024 "
+                   "frames with zero history and the padded last hop = 16 frames per clip, magnitude spectrum, 40-filter Slaney bank, log10, "
+                   "20 coefficients; restated from aubio 0.4, parity unpinned)" if own else "")
+                + (f"; labels + probabilities (8 B per clip) all-gathered over {world} ranks every step, pipelined" if world > 1 else ""))
+        kernel = "mfcc2048_kernel<POOL, AUB>" if own else "mfcc512_wave_kernel<POOL>"
     elif args.workload == "config3":
         n = args.clips or 1_000_000
         frames = torch.rand((n, 1024), device=dev, generator=gen) * 2 - 1
@@ -173,20 +305,33 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         what = (f"{n} x 1 s 16 kHz fp32 clips (25 % with a call-like burst pattern, label 1) through classify() "
                 "(2 x IIR, 2 x spectrogram, rule), bit-exact with the reference")
         kernel = "iir2_ckpt_kernel + spec_from_ckpt_kernel<flags> + classify_midpoints_kernel + spec_from_ckpt_kernel<[time][bin]> + classify_bands_kernel"
+    sens = open_sensors(local)
     settle(step, torch, args.settle)
     for _ in range(max(1, args.warmup // 4)):
         step()
+    if side_finish:
+        side_finish()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     steps = max(1, args.steps // 10) if args.workload == "classify" else args.steps
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s_before = sens.read() if sens else None
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(steps):
+    evs[0].record()
+    for i in range(steps):
         step()
-    ev1.record()
+        evs[i + 1].record()
+    s_during = sens.read() if sens else None
+    if side_finish:
+        side_finish()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ms = ev0.elapsed_time(ev1) / steps
+    s_after = sens.read() if sens else None
+    kstats = step_stats(evs, torch)
+    ms = kstats["avg"]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -202,54 +347,101 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                          "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/" + tr["file"]) if tr else None,
-                         "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes_per_launch": bytes_per * n},
+                         "kernel": kernel, "kernel_ms": ms, "kernel_ms_min": kstats["min"], "kernel_ms_median": kstats["median"],
+                         "algorithmic_bytes_per_launch": bytes_per * n},
+            "sensors": sensor_block(sens, s_before, s_during, s_after),
             "step_calls": (max(1, args.warmup // 4) + steps) if args.settle <= 0 else None}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def config4(args, torch, dist, dsp_amd, dev, local, rank, world, sync):
+def config4(args, torch, dist, dsp_amd, dev, local, rank, world, sync, watchdog_line=None):
     """BASELINE configs[3] beside the headline number: every rank computes its 12 500-clip share ([98][13] per clip) and the
     per-rank feature blocks (63.7 MB each) are all-gathered -- ONE RCCL collective per batch, issued asynchronously so that it
     runs over xGMI while the next batch's MFCC kernel runs (GatherPipeline, depth 2).  Same timing protocol as the headline:
-    W warmup steps, K timed steps between barrier + synchronize, max over ranks.  At N = 1 there is nothing to gather and the
-    number is the compute-only baseline of the same workload."""
+    W warmup steps, K timed steps between barrier + synchronize, max over ranks.  At N > 1 the same run also times the
+    compute alone (no collective) and the gather alone (K back-to-back all-gathers of the same blocks), so the line says how much
+    of the gather the pipeline hides: gather_hidden_frac = 1 - (pipelined - compute_only) / gather_only.  At N = 1 there is
+    nothing to gather and the number is the compute-only baseline of the same workload.
+
+    Failure handling (N > 1): the setup phase makes no collective call, and the ranks agree on its outcome with one all-reduce
+    before the first gather, so a rank that cannot allocate does not leave the others waiting in a collective; the timed phase
+    runs under a watchdog (see Watchdog) because there a failure of one rank cannot be seen by the others."""
     from dsp_amd.dist import GatherPipeline
     n, T = args.clips or 12_500, 98
-    gen = torch.Generator(device=dev).manual_seed(3000 + rank)
-    clips = torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1
-    plan = dsp_amd.MfccPlan(dsp_amd.default_config(), local)
-    pipe = GatherPipeline(n, (T, N_MFCC), torch.float32, dev)
-
-    def step():
-        pipe.submit(lambda block: plan.clips(clips, 500, block))
-
-    for _ in range(args.warmup):
-        step()
-    pipe.drain()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    pipe.drain()
-    sync()
-    elapsed = time.perf_counter() - t0
+    err = None
+    try:      # ---- setup: local work only
+        gen = torch.Generator(device=dev).manual_seed(3000 + rank)
+        clips = torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1
+        plan = dsp_amd.MfccPlan(dsp_amd.default_config(), local)
+        pipe = GatherPipeline(n, (T, N_MFCC), torch.float32, dev)
+        plan.clips(clips, 500, pipe.local[0])
+        torch.cuda.synchronize()
+    except Exception as exc:  # noqa: BLE001
+        err = f"{type(exc).__name__}: {exc}"[:300]
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    full = pipe.result((pipe.k - 1) % pipe.depth)
-    assert tuple(full.shape) == (world * n, T, N_MFCC)
+        ok = torch.tensor([0 if err else 1], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            return {"error": err or "another rank failed in the setup of this leg"} if rank == 0 else None
+    elif err:
+        return {"error": err}
+
+    def timed(step_fn, finish=None):
+        for _ in range(args.warmup):
+            step_fn()
+        if finish:
+            finish()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        if finish:
+            finish()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    import contextlib
+    guard = Watchdog(float(os.environ.get("BENCH_CONFIG4_TIMEOUT", "120")), rank, watchdog_line) if (world > 1 and watchdog_line) else contextlib.nullcontext()
+    with guard:
+        elapsed = timed(lambda: pipe.submit(lambda block: plan.clips(clips, 500, block)), pipe.drain)
+        full = pipe.result((pipe.k - 1) % pipe.depth)
+        assert tuple(full.shape) == (world * n, T, N_MFCC)
+        compute_only = gather_only = None
+        if world > 1:
+            compute_only = timed(lambda: plan.clips(clips, 500, pipe.local[0]))
+            pipe.drain()
+            work = []
+
+            def gather_step():
+                work.append(dist.all_gather_into_tensor(pipe.gathered[len(work) % pipe.depth], pipe.local[len(work) % pipe.depth], async_op=True))
+
+            def gather_finish():
+                while work:
+                    work.pop().wait()
+
+            gather_only = timed(gather_step, gather_finish)
     del clips
     if rank != 0:
         return None
-    return {"workload": f"BASELINE configs[3]: {world} x {n} x 1 s 16 kHz fp32 clips per step, frame 400 / hop 160 -> [98][13] per clip, "
-                        "per-clip MFCC matrices gathered on every rank",
-            "value": world * n * args.steps / elapsed, "unit": "clips/s", "frames_per_s": world * n * T * args.steps / elapsed,
-            "ms_per_step": elapsed / args.steps * 1e3, "gather": world > 1,
-            "collective": "one all_gather_into_tensor (RCCL over xGMI) per batch, async on the backend's stream, double-buffered: "
-                          "the gather of batch k overlaps the MFCC kernel of batch k + 1" if world > 1 else None,
-            "gathered_bytes_per_rank_per_step": n * T * N_MFCC * 4, "clips_per_gpu": n, "algorithmic_bytes_per_clip": 64_000 + T * 52}
+    out = {"workload": f"BASELINE configs[3]: {world} x {n} x 1 s 16 kHz fp32 clips per step, frame 400 / hop 160 -> [98][13] per clip, "
+                       "per-clip MFCC matrices gathered on every rank",
+           "value": world * n * args.steps / elapsed, "unit": "clips/s", "frames_per_s": world * n * T * args.steps / elapsed,
+           "ms_per_step": elapsed / args.steps * 1e3, "gather": world > 1,
+           "collective": "one all_gather_into_tensor (RCCL over xGMI) per batch, async on the backend's stream, double-buffered: "
+                         "the gather of batch k overlaps the MFCC kernel of batch k + 1" if world > 1 else None,
+           "gathered_bytes_per_rank_per_step": n * T * N_MFCC * 4, "clips_per_gpu": n, "algorithmic_bytes_per_clip": 64_000 + T * 52,
+           "compute_only_ms_per_step": None, "gather_only_ms_per_step": None, "gather_hidden_frac": None}
+    if world > 1:
+        c_ms, g_ms, p_ms = compute_only / args.steps * 1e3, gather_only / args.steps * 1e3, elapsed / args.steps * 1e3
+        out.update(compute_only_ms_per_step=c_ms, gather_only_ms_per_step=g_ms,
+                   gather_hidden_frac=max(0.0, min(1.0, 1.0 - (p_ms - c_ms) / g_ms)) if g_ms > 0 else None)
+    return out
 
 
 def settle(step, torch, seconds):
@@ -346,42 +538,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sens = open_sensors(local)
     settle(lambda: plan.frames(frames, out), torch, args.settle)      # compute only: ranks may do different counts
     for _ in range(args.warmup):
         step()
     sync()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
+    s_before = sens.read() if sens else None
+    # an event after every step (on torch's current stream == the stream plan.frames launches on): the region's average launch
+    # time is last - first over K, the per-launch minimum / median come from the pairs (BENCH_STEP_EVENTS=0: two events only)
+    every = os.environ.get("BENCH_STEP_EVENTS", "1") != "0"
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1 if every else 2)]
     t0 = time.perf_counter()
-    ev0.record()                       # torch's current stream == the stream plan.frames launches on
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
-    ev1.record()
+        if every:
+            evs[i + 1].record()
+    if not every:
+        evs[1].record()
+    s_during = sens.read() if sens else None      # the K launches are queued / running
     if pipe is not None:
         pipe.drain()                   # the last gathers are part of the timed work
     sync()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps    # back-to-back launches: avg launch duration
+    s_after = sens.read() if sens else None
+    kernel_ms = evs[0].elapsed_time(evs[-1]) / args.steps    # back-to-back launches: avg launch duration
+    kstats = step_stats(evs, torch) if every else None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # the headline above is measured; a failure in the secondary config-4 leg must not cost the line
-    c4 = None
-    if not args.no_config4:
-        try:
-            c4 = config4(args, torch, dist, dsp_amd, dev, local, rank, world, sync)
-        except Exception as exc:  # noqa: BLE001
-            c4 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-
-    if rank == 0:
+    def headline():
         total_frames = world * n * args.steps
-        value = total_frames / elapsed
         achieved = BYTES_PER_FRAME * n / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "MFCC frames/sec (512-pt FFT, 40 mel, 13 coeffs)",
-            "value": value,
+            "value": total_frames / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -402,17 +595,36 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "mfcc512_wave_kernel", "kernel_ms": kernel_ms,
+                         "kernel_ms_min": kstats["min"] if kstats else None, "kernel_ms_median": kstats["median"] if kstats else None,
+                         "kernel_ms_max": kstats["max"] if kstats else None,
                          "algorithmic_bytes_per_launch": BYTES_PER_FRAME * n},
+            "sensors": sensor_block(sens, s_before, s_during, s_after),
         }
         tr = pmc_traffic("frames", n)
         if tr:
             line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/" + tr["file"]
         line["step_calls"] = args.warmup + args.steps if args.settle <= 0 else None      # tools/traffic.py divides by this
-        if c4:
-            line["config4"] = c4
         if rehearsal:
             line["rehearsal"] = f"gloo backend, {world} ranks sharing cuda:0 -- control-flow check only, not a measurement"
+        return line
+
+    # the headline above is measured; a failure in the secondary config-4 leg must not cost the line (nor hang the job: config4())
+    c4 = None
+    if not args.no_config4:
+        try:
+            c4 = config4(args, torch, dist, dsp_amd, dev, local, rank, world, sync, watchdog_line=headline if rank == 0 else (lambda: {}))
+        except Exception as exc:  # noqa: BLE001
+            c4 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            if world > 1:
+                # this rank failed inside the leg's collective phase: the others may be waiting for it.  Rank 0 still owes the
+                # line; every rank then leaves (the others' watchdogs end them)
+                Watchdog(0, rank, headline).fire(c4["error"])
+
+    if rank == 0:
+        line = headline()
+        if c4:
+            line["config4"] = c4
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(600_000)
         print(json.dumps(line), flush=True)

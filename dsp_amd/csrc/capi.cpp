@@ -56,8 +56,18 @@ bool valid_cfg(const dsp_mfcc_config &c, std::string &why)
     if (c.hop_length & 1) { why = "hop_length must be even (8-byte aligned frame loads)"; return false; }
     if (!(c.fmax > c.fmin) || c.fmin < 0) { why = "need 0 <= fmin < fmax"; return false; }
     if (!(c.amin > 0)) { why = "amin must be positive"; return false; }
-    if (c.log_mode != DSP_LOG_PER_FRAME_MAX && c.log_mode != DSP_LOG_GLOBAL_REF1) { why = "unknown log_mode"; return false; }
-    if (c.mel_norm != DSP_MELNORM_NONE && c.mel_norm != DSP_MELNORM_SLANEY && c.mel_norm != DSP_MELNORM_LIBROSA) { why = "unknown mel_norm"; return false; }
+    if (c.log_mode != DSP_LOG_PER_FRAME_MAX && c.log_mode != DSP_LOG_GLOBAL_REF1 && c.log_mode != DSP_LOG_LOG10_FLOOR) { why = "unknown log_mode"; return false; }
+    if (c.mel_norm != DSP_MELNORM_NONE && c.mel_norm != DSP_MELNORM_SLANEY && c.mel_norm != DSP_MELNORM_LIBROSA && c.mel_norm != DSP_MELNORM_AUBIO_SLANEY) { why = "unknown mel_norm"; return false; }
+    if (c.spectrum != DSP_SPECTRUM_POWER && c.spectrum != DSP_SPECTRUM_MAGNITUDE) { why = "unknown spectrum"; return false; }
+    if (c.framing != DSP_FRAMING_COMPLETE && c.framing != DSP_FRAMING_STREAM) { why = "unknown framing"; return false; }
+    // the aubio-semantics options of cepstrum/scrubjay_infer.c's front end live on the 2048-point kernel
+    if (c.n_fft != 2048 && (c.mel_norm == DSP_MELNORM_AUBIO_SLANEY || c.log_mode == DSP_LOG_LOG10_FLOOR || c.spectrum != DSP_SPECTRUM_POWER ||
+                            c.framing != DSP_FRAMING_COMPLETE)) {
+        why = "DSP_MELNORM_AUBIO_SLANEY, DSP_LOG_LOG10_FLOOR, DSP_SPECTRUM_MAGNITUDE and DSP_FRAMING_STREAM are implemented for n_fft = 2048";
+        return false;
+    }
+    if (c.mel_norm == DSP_MELNORM_AUBIO_SLANEY && c.n_mels != 40) { why = "DSP_MELNORM_AUBIO_SLANEY is aubio's 40-filter bank: n_mels must be 40"; return false; }
+    if (c.framing == DSP_FRAMING_STREAM && c.hop_length > c.frame_length) { why = "DSP_FRAMING_STREAM needs hop_length <= frame_length"; return false; }
     if (c.log_mode == DSP_LOG_GLOBAL_REF1 && c.n_fft == 1024) { why = "DSP_LOG_GLOBAL_REF1 is implemented for n_fft = 512 and 2048"; return false; }
     if (c.prefilter != DSP_PREFILTER_NONE && c.n_fft == 2048) { why = "the per-frame prefilter is implemented for n_fft = 512 and 1024"; return false; }
     if (c.frame_length > c.n_fft) { why = "frame_length must not exceed n_fft"; return false; }
@@ -140,6 +150,8 @@ void dsp_mfcc_default_config(dsp_mfcc_config *c)
     c->mel_norm = DSP_MELNORM_NONE;
     c->log_mode = DSP_LOG_PER_FRAME_MAX;
     c->prefilter = DSP_PREFILTER_NONE;
+    c->spectrum = DSP_SPECTRUM_POWER;
+    c->framing = DSP_FRAMING_COMPLETE;
     c->win_length = 0;
     c->fmin = 0.0f;
     c->fmax = 8000.0f;
@@ -147,10 +159,36 @@ void dsp_mfcc_default_config(dsp_mfcc_config *c)
     c->top_db = 80.0f;
 }
 
+void dsp_mfcc_scrubjay_infer_config(dsp_mfcc_config *c, int sample_rate)
+{
+    // cepstrum/scrubjay_infer.c:9-13 (N_MFCC 20, WIN_SIZE 2048, HOP_SIZE 1024, N_FILTERS 40), :28-30 (new_aubio_pvoc, new_aubio_mfcc)
+    dsp_mfcc_default_config(c);
+    c->sample_rate = sample_rate;
+    c->n_fft = 2048;
+    c->frame_length = 2048;
+    c->hop_length = 1024;
+    c->n_mels = 40;
+    c->n_mfcc = 20;
+    c->window = DSP_WINDOW_HANN;                 // new_aubio_window("hanningz"): the periodic Hann
+    c->mel_norm = DSP_MELNORM_AUBIO_SLANEY;
+    c->log_mode = DSP_LOG_LOG10_FLOOR;
+    c->spectrum = DSP_SPECTRUM_MAGNITUDE;
+    c->framing = DSP_FRAMING_STREAM;
+    c->fmin = 0.0f;
+    c->fmax = 0.5f * (float)sample_rate;         // not used by the aubio bank
+}
+
 int dsp_mfcc_frames_for(const dsp_mfcc_config *cfg, int num_samples, int max_frames)
 {
+    if (!cfg || max_frames <= 0) return 0;
+    if (cfg->framing == DSP_FRAMING_STREAM) {
+        // cepstrum/scrubjay_infer.c:39-53: a frame per aubio_source_do that returned samples
+        if (num_samples <= 0) return 0;
+        const long t = ((long)num_samples + cfg->hop_length - 1) / cfg->hop_length;
+        return (int)std::min<long>(t, max_frames);
+    }
     // mfcc.c:117-119, 132-139
-    if (!cfg || num_samples < cfg->frame_length || max_frames <= 0) return 0;
+    if (num_samples < cfg->frame_length) return 0;
     const int t = 1 + (num_samples - cfg->frame_length) / cfg->hop_length;
     return std::min(t, max_frames);
 }
@@ -355,7 +393,7 @@ static int reserve(float **buf, size_t *cap, size_t need)
 }
 
 static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, int frames_per_clip,
-               long clip_stride, void *stream, int in_kind = 0, bool fused_prefilter = false)
+               long clip_stride, void *stream, int in_kind = 0, bool fused_prefilter = false, int samples_per_clip = 0)
 {
     if (n_frames == 0) return DSP_OK;
     DSP_ON_DEVICE(p->device);       // the caller's current device may be another GPU: tables and workspaces live on the plan's
@@ -369,6 +407,10 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
         a.in = d_in; a.out = d_out; a.n_frames = n_frames; a.clip_stride = clip_stride; a.frames_per_clip = frames_per_clip;
         a.hop = p->cfg.hop_length; a.frame_len = p->cfg.frame_length; a.chunk = p->chunk > 0 ? p->chunk : 8;
         a.n_mels = p->cfg.n_mels; a.n_mfcc = p->cfg.n_mfcc; a.amin = p->cfg.amin; a.top_db = p->cfg.top_db;
+        a.spectrum = p->cfg.spectrum;
+        a.stream_framing = frames_per_clip > 0 && p->cfg.framing == DSP_FRAMING_STREAM;
+        a.samples_per_clip = samples_per_clip;
+        if (a.stream_framing && samples_per_clip <= 0) return fail(DSP_EINVAL, "internal: stream framing without the clip length");
         const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks_2048;
         const long chunks = (n_frames + a.chunk - 1) / a.chunk;
         const long blocks = std::max(1L, std::min((long)p->n_cu * per_cu, (chunks + 3) / 4));
@@ -509,7 +551,7 @@ int dsp_mfcc_clips_device(dsp_mfcc_plan *p, const float *d_signal, long n_clips,
     if (t == 0 || n_clips == 0) return 0;
     if (!d_signal || !d_out) return fail(DSP_EINVAL, "NULL buffer");
     if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
-    const int rc = run(p, d_signal, d_out, n_clips * (long)t, t, clip_stride, stream);
+    const int rc = run(p, d_signal, d_out, n_clips * (long)t, t, clip_stride, stream, 0, false, samples_per_clip);
     return rc < 0 ? rc : t;
 }
 
@@ -567,7 +609,7 @@ int dsp_mfcc_clips_host(dsp_mfcc_plan *p, const float *signal, long n_clips, int
     if ((rc = reserve(&p->d_out, &p->out_cap, out_b)) < 0) return rc;
     DSP_HIP(hipMemcpy2DAsync(p->d_in, dstride * sizeof(float), signal, clip_stride * sizeof(float),
                              (size_t)samples_per_clip * sizeof(float), (size_t)n_clips, hipMemcpyHostToDevice, nullptr));
-    if ((rc = run(p, p->d_in, p->d_out, n_clips * (long)t, t, dstride, nullptr)) < 0) return rc;
+    if ((rc = run(p, p->d_in, p->d_out, n_clips * (long)t, t, dstride, nullptr, 0, false, samples_per_clip)) < 0) return rc;
     DSP_HIP(hipMemcpyAsync(out, p->d_out, out_b, hipMemcpyDeviceToHost, nullptr));
     DSP_HIP(hipStreamSynchronize(nullptr));
     return t;
@@ -1034,9 +1076,9 @@ int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signa
                               void *stream)
 {
     if (!p || !s || n_clips < 0) return fail(DSP_EINVAL, "bad argument");
-    if ((p->cfg.n_fft != 512 && p->cfg.n_fft != 2048) || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX || p->cfg.prefilter != DSP_PREFILTER_NONE ||
-        p->kernel != DSP_KERNEL_WAVE)
-        return fail(DSP_EINVAL, "the fused clip -> label path runs on the 512- and 2048-point wave-per-frame kernels, per-frame log mode");
+    if ((p->cfg.n_fft != 512 && p->cfg.n_fft != 2048) || (p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX && p->cfg.log_mode != DSP_LOG_LOG10_FLOOR) ||
+        p->cfg.prefilter != DSP_PREFILTER_NONE || p->kernel != DSP_KERNEL_WAVE)
+        return fail(DSP_EINVAL, "the fused clip -> label path runs on the 512- and 2048-point wave-per-frame kernels, per-frame log modes");
     if (s->m.n_features != 2 * p->cfg.n_mfcc || s->m.n_features > 64) return fail(DSP_EINVAL, "SVM n_features must equal 2 * n_mfcc (<= 64)");
     const int t = dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
     if (n_clips == 0) return 0;
@@ -1061,7 +1103,10 @@ int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signa
     a.n_mfcc = p->cfg.n_mfcc;
     a.amin = p->cfg.amin;
     a.top_db = p->cfg.top_db;
-    a.log_mode = 0;
+    a.log_mode = p->cfg.log_mode;
+    a.spectrum = p->cfg.spectrum;
+    a.stream_framing = p->cfg.framing == DSP_FRAMING_STREAM;
+    a.samples_per_clip = samples_per_clip;
     a.pool.svm = s->m;
     a.pool.labels = d_labels;
     a.pool.decision = d_decision;

@@ -69,7 +69,15 @@ constexpr int Q_BLOCK_BYTES = Q_DCT;               // + 256 B per DCT row, added
 
 }  // namespace
 
-template <bool CLIPS, bool POOL>
+// AUB: the aubio-semantics front end of cepstrum/scrubjay_infer.c:21-53 (dsp_mfcc_scrubjay_infer_config; restated from aubio
+// 0.4's published algorithm, parity unpinned): any of
+//   args.spectrum = 1         the MAGNITUDE |X[k]| goes into the filterbank (aubio_fft_get_norm + aubio_filterbank_do, power 1)
+//   args.log_mode = 2         plain log10 of each filter output, inputs below 2e-42 count as 2e-42 (fvec_log10 / SAFE_LOG10)
+//   args.stream_framing       aubio_source_do + aubio_pvoc_do: frame t of a clip = samples [(t + 1) hop - frame_len, (t + 1) hop),
+//                             zeros before the clip (the vocoder's empty history) and past its end (the short last read)
+// The filterbank (DSP_MELNORM_AUBIO_SLANEY) is a table like any other.  A separate instantiation: the reference-semantics
+// kernels keep their code and registers.
+template <bool CLIPS, bool POOL, bool AUB = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mfcc2048_kernel(const Mfcc512Args args, const GenTables2048 *__restrict__ G)
 {
     static_assert(!POOL || CLIPS, "pooling is per clip");
@@ -139,6 +147,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
         const bool last_of_chunk = cur.left == 0 || cur.remaining == 1;
         (void)clip_f; (void)last_of_chunk;
         const float *src = static_cast<const float *>(args.in) + cur.off;
+        // samples [lo_i, hi_i) of the frame exist; the rest reads as zero.  Complete frames: [0, frame_len).
+        int lo_i = 0, hi_i = frame_len;
+        if (AUB && CLIPS && args.stream_framing) {
+            const int start = (cur.t + 1) * args.hop - frame_len;        // first sample of the frame inside its clip (even; < 0: history)
+            src += args.hop - frame_len;                                 // cur.off = clip_off + t * hop
+            lo_i = start < 0 ? -start : 0;
+            hi_i = min(frame_len, args.samples_per_clip - start);
+        }
         cur.next();
 
         // ---- load + window: v[a] = z[lane + 64 a] --------------------------------------------------------------------
@@ -147,10 +163,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
         for (int a = 0; a < 16; ++a) {
             const int i = 2 * (lane + 64 * a);
             float x0 = 0.0f, x1 = 0.0f;
-            if (i + 1 < frame_len) {
+            if (i + 1 < hi_i && (!AUB || i >= lo_i)) {                   // lo_i is even: a pair never straddles it
                 const f2v x = CLIPS ? *reinterpret_cast<const f2v *>(src + i) : __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));   // clips re-read samples: cacheable
                 x0 = x.x; x1 = x.y;
-            } else if (i < frame_len) {
+            } else if (i < hi_i && (!AUB || i >= lo_i)) {
                 x0 = src[i];
             }
             if (WIN_LDS) {
@@ -230,6 +246,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             P[2 * t] = xr * xr + xi * xi;
             P[2 * t + 1] = mr * mr + mi * mi;
         }
+        const bool magnitude = AUB && args.spectrum != 0;
+        if (magnitude) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) P[t] = __builtin_amdgcn_sqrtf(P[t]);       // |X[k]|: aubio_fft_get_norm
+        }
         const float2 zm = zbuf[ZI(512)];
         wave_lds_sync();
 #pragma unroll
@@ -237,7 +258,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             pbuf[lane + 64 * t] = P[2 * t];
             pbuf[1024 - lane - 64 * t] = P[2 * t + 1];
         }
-        if (lane == 0) pbuf[512] = 4.0f * (zm.x * zm.x + zm.y * zm.y);
+        if (lane == 0) {
+            const float p512 = 4.0f * (zm.x * zm.x + zm.y * zm.y);
+            pbuf[512] = magnitude ? __builtin_amdgcn_sqrtf(p512) : p512;
+        }
         wave_lds_sync();
 
         // ---- mel: lane m (and m + 64) walks filter m's run of weights in ascending bins (mfcc.c:158-164) --------------------
@@ -277,9 +301,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 emax = fmaxf(emax, acc);
             }
         }
+        const bool aub_log = AUB && args.log_mode == 2;
+        if (aub_log) {
+            // aubio_mfcc_do: fvec_log10 = log10(x < 2e-42 ? 2e-42 : x), no reference, no floor relative to the frame.  v_log_f32
+            // does not take denormal inputs: values below 2^-100 are scaled into range first.
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float v = e[i];
+                const bool tiny = v < 0x1p-100f;
+                const float l2 = __builtin_amdgcn_logf(tiny ? v * 0x1p+64f : v) - (tiny ? 64.0f : 0.0f);
+                const float lg = v < 2e-42f ? -41.69897f : 0.30102999566398120f * l2;       // log10(2e-42) = -41.69897
+                lmel[lane + 64 * i] = (lane + 64 * i < n_mels) ? lg : 0.0f;
+            }
+        }
         // ---- 10 log10 with per-frame reference (mfcc.c:169-206), one log of the ratio --------------------------------------
-        const float ref = __uint_as_float(max(__float_as_uint(wave_max_nonneg(emax)), amin_u));
-        if (!POOL && args.log_mode != 0) {
+        const float ref = aub_log ? 0.0f : __uint_as_float(max(__float_as_uint(wave_max_nonneg(emax)), amin_u));
+        if (aub_log) {
+        } else if (!POOL && args.log_mode != 0) {
             // librosa power_to_db(ref = 1.0, top_db below the CLIP's maximum), keyword_classifier.py:42-55 / librosa's defaults as
             // cepstrum/train.py:45-52 uses them; same two passes as the 512-point kernel (mfcc_kernels.hip)
             const float k10 = 3.01029995663981195f;
@@ -378,15 +416,20 @@ hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables,
     const bool clips = args.frames_per_clip > 0;
     const dim3 g(blocks), b(256);
     const size_t Q_BLOCK_BYTES = lds_bytes_2048(args.n_mels);
+    const bool aub = args.spectrum != 0 || args.log_mode == 2 || args.stream_framing != 0;
+    if (args.stream_framing && (!clips || args.samples_per_clip <= 0 || args.hop > args.frame_len)) return hipErrorInvalidConfiguration;
     if (pool) {
         if (!clips || args.chunk != args.frames_per_clip || !args.pool.labels || args.pool.svm.n_features != 2 * args.n_mfcc ||
-            args.pool.svm.n_features > 64)
+            args.pool.svm.n_features > 64 || (args.log_mode != 0 && args.log_mode != 2))
             return hipErrorInvalidConfiguration;
-        hipLaunchKernelGGL((mfcc2048_kernel<true, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        if (aub) hipLaunchKernelGGL((mfcc2048_kernel<true, true, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        else hipLaunchKernelGGL((mfcc2048_kernel<true, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);
     } else if (clips) {
-        hipLaunchKernelGGL((mfcc2048_kernel<true, false>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        if (aub) hipLaunchKernelGGL((mfcc2048_kernel<true, false, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        else hipLaunchKernelGGL((mfcc2048_kernel<true, false>), g, b, Q_BLOCK_BYTES, stream, args, tables);
     } else {
-        hipLaunchKernelGGL((mfcc2048_kernel<false, false>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        if (aub) hipLaunchKernelGGL((mfcc2048_kernel<false, false, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        else hipLaunchKernelGGL((mfcc2048_kernel<false, false>), g, b, Q_BLOCK_BYTES, stream, args, tables);
     }
     return hipGetLastError();
 }

@@ -36,7 +36,13 @@ struct Mfcc512Args {
     //   frame_max != nullptr : pass 1, only write 10 log10(max mel energy) per frame, no MFCC
     //   clip_floor != nullptr: pass 2, clip log-mel at clip_floor[clip]
     //   both nullptr         : every frame is its own clip (independent frames), one pass
+    // log_mode 2 (DSP_LOG_LOG10_FLOOR, n_fft 2048): plain log10 with aubio's 2e-42 floor
     int log_mode;
+    // n_fft 2048 only (the aubio-semantics front end of cepstrum/scrubjay_infer.c): spectrum 1 = magnitude into the filterbank;
+    // stream_framing: frame t of a clip covers samples [(t + 1) hop - frame_len, (t + 1) hop), zeros outside [0, samples_per_clip)
+    int spectrum = 0;
+    int stream_framing = 0;
+    int samples_per_clip = 0;
     float *frame_max;
     const float *clip_floor;
     PoolSvmArgs pool;              // only read by the POOL instantiations (launch_mfcc512_pool)

@@ -37,10 +37,41 @@ std::vector<float> make_frame_window(const dsp_mfcc_config &cfg)
     return w;
 }
 
+// DSP_MELNORM_AUBIO_SLANEY: the bank new_aubio_mfcc(win_s, 40, ...) installs (cepstrum/scrubjay_infer.c:30 ->
+// aubio_filterbank_set_mel_coeffs_slaney, aubio 0.4 src/spectral/filterbank_mel.c): Malcolm Slaney's Auditory Toolbox
+// edges -- 13 filters spaced 66.67 Hz from 133.33 Hz, then 27 spaced by the factor 1.0711703, 42 edges in all, computed in
+// float like aubio's smpl_t -- and triangles of UNIT AREA (height 2 / (upper - lower)) sampled at the bin frequencies
+// k * sample_rate / n_fft.  aubio fills the rows with three loops (skip to the first bin above `lower`, rise while the NEXT
+// bin is below `center`, fall while the next bin is below `upper`, never touching the Nyquist bin); bin for bin that is
+// min(rise, fall) clipped at 0 of the triangle's two lines, which is what is evaluated here.  Parity unpinned (aubio is
+// not vendored by the reference): tests/ check it against a loop-for-loop restatement and a float64 formula.
+static std::vector<float> make_aubio_slaney_filterbank(int sample_rate, int n_fft)
+{
+    const int n_bins = n_fft / 2 + 1, n_filters = 40;
+    float edge[42];
+    for (int i = 0; i < 13; ++i) edge[i] = 133.3333f + (float)i * 66.66666666f;
+    for (int i = 0; i < 29; ++i) edge[13 + i] = edge[12] * std::pow(1.0711703f, (float)(i + 1));
+    const float bin_hz = (float)sample_rate / (float)n_fft;
+    std::vector<float> fb((size_t)n_filters * n_bins, 0.0f);
+    for (int m = 0; m < n_filters; ++m) {
+        const float lo = edge[m], ce = edge[m + 1], hi = edge[m + 2];
+        const float height = 2.0f / (hi - lo);
+        const float rise = height / (ce - lo), fall = height / (hi - ce);
+        for (int k = 0; k + 1 < n_bins; ++k) {
+            const float f = bin_hz * (float)k;
+            if (!(f > lo) || !(f < hi)) continue;
+            const float w = f < ce ? (f - lo) * rise : (hi - f) * fall;
+            fb[(size_t)m * n_bins + k] = w > 0.0f ? w : 0.0f;
+        }
+    }
+    return fb;
+}
+
 // librosa.filters.mel(htk=True, norm=None|'slaney') (export_mfcc_params.py:49-57).
 std::vector<float> make_mel_filterbank(int sample_rate, int n_fft, int n_mels, float fmin,
                                        float fmax, int mel_norm)
 {
+    if (mel_norm == DSP_MELNORM_AUBIO_SLANEY && n_mels == 40) return make_aubio_slaney_filterbank(sample_rate, n_fft);
     const int n_bins = n_fft / 2 + 1;
     // DSP_MELNORM_LIBROSA: librosa.filters.mel's defaults -- Slaney's mel SCALE (htk = False: 200/3 Hz per mel below 1 kHz,
     // log(6.4) / 27 per mel above) with Slaney's area normalisation; what librosa.feature.mfcc, hence cepstrum/train.py:45-52, uses

@@ -21,6 +21,7 @@ class MfccConfig(C.Structure):
         ("window", C.c_int), ("mel_norm", C.c_int), ("log_mode", C.c_int),
         ("prefilter", C.c_int), ("win_length", C.c_int),
         ("fmin", C.c_float), ("fmax", C.c_float), ("amin", C.c_float), ("top_db", C.c_float),
+        ("spectrum", C.c_int), ("framing", C.c_int),
     ]
 
 
@@ -78,7 +79,7 @@ SYMBOLS = [
     "dsp_butter_bandpass_filter_f32", "dsp_butter_bandpass_filter_f64", "dsp_compute_spectrogram_f32", "dsp_compute_spectrogram_f64",
     "dsp_classify_batch_host", "dsp_classify_batch_device", "dsp_find_midpoints",
     "dsp_mfcc_stats_device", "dsp_svm_create", "dsp_svm_destroy", "dsp_svm_predict_device",
-    "dsp_mfcc_default_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
+    "dsp_mfcc_default_config", "dsp_mfcc_scrubjay_infer_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
     "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",
     "dsp_mfcc_clips_host", "dsp_mfcc_clips_pcm16_device", "dsp_mfcc_plan_set_launch", "dsp_mfcc_plan_set_kernel", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables",
     "dsp_scrubjay_fused_device", "dsp_stop_model_create", "dsp_stop_model_destroy", "dsp_stop_predict_device", "dsp_classify_signal_batch_device",
@@ -129,6 +130,7 @@ def load() -> C.CDLL:
     cfgp = C.POINTER(MfccConfig)
     L.compute_mfcc.argtypes = [vp, ip, vp, ip]; L.compute_mfcc.restype = ip
     L.dsp_mfcc_default_config.argtypes = [cfgp]; L.dsp_mfcc_default_config.restype = None
+    L.dsp_mfcc_scrubjay_infer_config.argtypes = [cfgp, ip]; L.dsp_mfcc_scrubjay_infer_config.restype = None
     L.dsp_mfcc_plan_create.argtypes = [cfgp, ip, C.POINTER(vp)]; L.dsp_mfcc_plan_create.restype = ip
     L.dsp_mfcc_plan_destroy.argtypes = [vp]; L.dsp_mfcc_plan_destroy.restype = None
     L.dsp_mfcc_plan_config.argtypes = [vp, cfgp]; L.dsp_mfcc_plan_config.restype = ip

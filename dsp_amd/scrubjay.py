@@ -69,11 +69,19 @@ def mfcc_stats(mfcc):
     return feat
 
 
-def scrubjay_infer_config(sample_rate: int = 16000):
-    """The framing cepstrum/scrubjay_infer.c itself uses (:10-14): WIN_SIZE 2048, HOP_SIZE 1024, N_FILTERS 40, N_MFCC 20 at the
-    file's sample rate, mel band up to Nyquist.  (aubio's own filterbank / scaling details are not vendored: unpinned.)"""
-    return default_config(sample_rate=sample_rate, n_fft=2048, frame_length=2048, hop_length=1024, n_mels=40, n_mfcc=20,
-                          fmin=0.0, fmax=sample_rate / 2.0)
+def scrubjay_infer_config(sample_rate: int = 16000, aubio: bool = True):
+    """The front end cepstrum/scrubjay_infer.c itself runs (:9-13, :28-30, :39-53).  aubio=True (default):
+    dsp_mfcc_scrubjay_infer_config -- aubio 0.4's semantics for the calls the file makes: streaming 2048 / 1024 frames with zero
+    history and the zero-padded last hop (T = ceil(n / 1024)), periodic Hann, MAGNITUDE spectrum, the 40-filter Slaney bank,
+    log10, orthonormal DCT-II, 20 coefficients (aubio is unvendored: restated from its published algorithm, parity unpinned).
+    aubio=False: only the file's numbers (2048 / 1024 / 40 / 20) on this library's mfcc.c semantics (round 2's config5_2048)."""
+    if not aubio:
+        return default_config(sample_rate=sample_rate, n_fft=2048, frame_length=2048, hop_length=1024, n_mels=40, n_mfcc=20,
+                              fmin=0.0, fmax=sample_rate / 2.0)
+    from .lib import MfccConfig
+    cfg = MfccConfig()
+    _lib.load().dsp_mfcc_scrubjay_infer_config(C.byref(cfg), int(sample_rate))
+    return cfg
 
 
 class ScrubJay:

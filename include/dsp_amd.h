@@ -66,9 +66,21 @@ enum {
 
 enum { DSP_WINDOW_HANN = 0, DSP_WINDOW_HAMMING = 1, DSP_WINDOW_RECT = 2 };
 enum { DSP_MELNORM_NONE = 0, DSP_MELNORM_SLANEY = 1,       /* HTK mel scale, triangles of peak 1 / of unit area          */
-       DSP_MELNORM_LIBROSA = 2 };                           /* Slaney mel scale + unit area: librosa.filters.mel defaults */
+       DSP_MELNORM_LIBROSA = 2,                             /* Slaney mel scale + unit area: librosa.filters.mel defaults */
+       DSP_MELNORM_AUBIO_SLANEY = 3 };                      /* aubio_filterbank_set_mel_coeffs_slaney (what new_aubio_mfcc picks for 40
+                                                               filters, cepstrum/scrubjay_infer.c:30): Slaney's Auditory-Toolbox bank, 13
+                                                               linear + 27 log-spaced unit-area triangles, 133 Hz .. 6.85 kHz; n_mels must
+                                                               be 40, fmin / fmax are not used; n_fft 2048                              */
 enum { DSP_LOG_PER_FRAME_MAX = 0,    /* mfcc.c:169-206: reference = the frame's own maximum                                    */
-       DSP_LOG_GLOBAL_REF1 = 1 };    /* librosa power_to_db(ref = 1, top_db below the CLIP's maximum); n_fft 512 and 2048      */
+       DSP_LOG_GLOBAL_REF1 = 1,      /* librosa power_to_db(ref = 1, top_db below the CLIP's maximum); n_fft 512 and 2048      */
+       DSP_LOG_LOG10_FLOOR = 2 };    /* aubio fvec_log10 (aubio_mfcc_do): plain log10 of each filter output, inputs below 2e-42
+                                        count as 2e-42; no dB factor, no reference, no top_db; n_fft 2048                      */
+enum { DSP_SPECTRUM_POWER = 0,       /* mfcc.c:151-155: |X[k]|^2 into the filterbank                                             */
+       DSP_SPECTRUM_MAGNITUDE = 1 }; /* aubio: the phase vocoder's norm |X[k]| (aubio_fft_get_norm), filterbank power 1; n_fft 2048 */
+enum { DSP_FRAMING_COMPLETE = 0,     /* mfcc.c:132-139: frames that lie completely inside the clip, T = 1 + (n - frame) / hop    */
+       DSP_FRAMING_STREAM = 1 };     /* aubio_source_do + aubio_pvoc_do as cepstrum/scrubjay_infer.c:39-53 drives them: one frame per
+                                        hop of NEW samples, T = ceil(n / hop); frame t ends with hop t and starts frame_length - hop
+                                        samples earlier (zeros before the clip), the last partial hop is zero padded; clips, n_fft 2048 */
 enum { DSP_PREFILTER_NONE = 0, DSP_PREFILTER_BUTTER_1000_3000 = 1, DSP_PREFILTER_BUTTER_3000_7500 = 2 };
 
 /* Compile-time constants of the reference (mfcc_params.h:6-12, mfcc.c:172-173)
@@ -88,9 +100,16 @@ typedef struct dsp_mfcc_config {
     float fmin, fmax; /* 0, 8000 */
     float amin;       /* 1e-10 */
     float top_db;     /* 80 */
+    int spectrum;     /* DSP_SPECTRUM_* (reference: power) */
+    int framing;      /* DSP_FRAMING_*  (reference: complete frames only) */
 } dsp_mfcc_config;
 
 void dsp_mfcc_default_config(dsp_mfcc_config *cfg);
+/* The parameterisation of cepstrum/scrubjay_infer.c:9-13,28-30 with aubio 0.4's semantics for the calls it makes:
+ * WIN_SIZE 2048 / HOP_SIZE 1024 streaming frames (DSP_FRAMING_STREAM), "hanningz" = periodic Hann, magnitude spectrum,
+ * the 40-filter Slaney bank, log10, orthonormal DCT-II, 20 coefficients.  sample_rate: the file's own (aubio_source with
+ * samplerate 0).  aubio is an unvendored dependency of the reference: restated from its published algorithm, parity unpinned. */
+void dsp_mfcc_scrubjay_infer_config(dsp_mfcc_config *cfg, int sample_rate);
 
 typedef struct dsp_mfcc_plan dsp_mfcc_plan; /* opaque: device tables for one config on one GPU */
 

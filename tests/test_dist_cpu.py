@@ -141,3 +141,56 @@ def test_pipeline_without_a_process_group_is_the_local_block():
     slot = pipe.submit(lambda out: out.fill_(2.5))
     assert pipe.world == 1 and torch.equal(pipe.result(slot), torch.full((4, 13), 2.5))
     pipe.drain()
+
+
+def _label_worker(rank, world, port, n_batches, rows, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # BASELINE config 5 at N > 1 (bench.py --workload config5): per clip an int32 label and a float32 probability,
+        # packed into one [rows][2] int32 block (the probability's bits) so that ONE all-gather per batch carries both
+        def results(k, r):
+            lab = torch.tensor([(7 * k + 3 * r + i) % 2 for i in range(rows)], dtype=torch.int32)
+            p1 = torch.tensor([0.25 + 0.001 * (100 * k + 10 * r + i) for i in range(rows)], dtype=torch.float32)
+            return lab, p1
+
+        pipe = D.GatherPipeline(rows, (2,), torch.int32, "cpu")
+        got, pending = [], None
+        for k in range(n_batches):
+            def compute(block, k=k):
+                lab, p1 = results(k, rank)
+                block[:, 0].copy_(lab)
+                block[:, 1].copy_(p1.view(torch.int32))
+            slot = pipe.submit(compute)
+            if pending is not None:
+                got.append(pipe.result(pending).clone())
+            pending = slot
+        got.append(pipe.result(pending).clone())
+        pipe.drain()
+        ok = True
+        for k, g in enumerate(got):
+            assert g.shape == (world * rows, 2)
+            for r in range(world):
+                lab, p1 = results(k, r)
+                blk = g[r * rows:(r + 1) * rows]
+                ok &= bool(torch.equal(blk[:, 0], lab)) and bool(torch.equal(blk[:, 1].contiguous().view(torch.float32), p1))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_label_gather_two_ranks():
+    """The per-clip labels + probabilities of the fused clip -> label path gathered on every rank, one packed collective per
+    batch, pipelined (5 batches, depth 2): every rank ends with rank 0's clips first, then rank 1's, bit for bit."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_label_worker, args=(r, world, port, 5, 7, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == [0, 1] and all(ok for _, ok in res)

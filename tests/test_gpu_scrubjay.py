@@ -175,7 +175,7 @@ def test_n_fft_2048_scrubjay_infer_framing(golden):
     from tests.conftest import gate
     m = golden("scrubjay_svm.npz")
     for sr, extra in ((16000, {}), (44100, {}), (16000, dict(n_mels=128, n_mfcc=32, frame_length=1600, hop_length=800))):
-        cfg = scrubjay.scrubjay_infer_config(sr)
+        cfg = scrubjay.scrubjay_infer_config(sr, aubio=False)       # the file's numbers on mfcc.c semantics; aubio's own: next test
         over = dict(sample_rate=sr, n_fft=2048, frame_length=2048, hop_length=1024, n_mels=40, n_mfcc=20, fmin=0.0, fmax=sr / 2.0)
         over.update(extra)
         for k, v in extra.items():
@@ -197,7 +197,7 @@ def test_n_fft_2048_scrubjay_infer_framing(golden):
             gate(got, O.mfcc_frames(fr, O.default_cfg(**dict(over, hop_length=2048)), threads=4), f"n_fft 2048 frames sr {sr}")
             assert not got[3].any()
     # fused: clip -> MFCC(2048/1024/40/20) -> mean | std -> SVM
-    sj = scrubjay.ScrubJay({k: m[k] for k in m.files}, config=scrubjay.scrubjay_infer_config(16000))
+    sj = scrubjay.ScrubJay({k: m[k] for k in m.files}, config=scrubjay.scrubjay_infer_config(16000, aubio=False))
     gen = torch.Generator(device="cuda").manual_seed(23)
     clips = torch.rand((300, 16000), device="cuda", generator=gen) * 2 - 1
     clips[::3] *= 0.01
@@ -213,6 +213,70 @@ def test_n_fft_2048_scrubjay_infer_framing(golden):
         ofeat = O.mfcc_stats(omfcc)
         feat = b[3][i].cpu().numpy()
         assert np.all(np.abs(feat - ofeat) <= 1e-4 * np.abs(omfcc).max() + (3e-4 if np.abs(omfcc).max() < 3.0 else 0.0))
+        lab, odec, op1 = O.svm_predict(model, feat)
+        assert abs(float(b[1][i]) - odec) <= 2e-5 * max(1.0, abs(odec)) and _prob_close(float(b[2][i]), op1)[0]
+        if abs(odec) > 1e-5:
+            assert int(b[0][i]) == lab
+
+
+def test_aubio_semantics_front_end_of_scrubjay_infer(golden):
+    """cepstrum/scrubjay_infer.c:21-53 as the file runs it: aubio_source_do -> aubio_pvoc_do -> aubio_mfcc_do per hop, pooled
+    (:36-66) and classified (:105-141).  GPU (dsp_mfcc_scrubjay_infer_config on mfcc2048_kernel<AUB>, plain and fused) against
+    the oracle's restatement of aubio 0.4 (oracle/aubio_oracle.c) under the 1e-4 * L-inf gate.  PARITY UNPINNED at the aubio
+    boundary (the library is not in the image, the reference holds no vector there); pinned below it: pooling and SVM."""
+    import torch
+    import dsp_amd
+    from dsp_amd import scrubjay
+    from oracle import oracle as O
+    from tests.conftest import gate
+    m = golden("scrubjay_svm.npz")
+    cfg = scrubjay.scrubjay_infer_config(16000)
+    plan = dsp_amd.MfccPlan(cfg)
+    # the frame count is the do/while's (:39-53): 16 frames for a 16 000-sample clip, not 14
+    for n, t in ((1, 1), (1024, 1), (1025, 2), (16000, 16), (16384, 16), (16385, 17)):
+        assert dsp_amd.frames_for(cfg, n, 1 << 20) == t == O.aubio_frames_for(n, 1024)
+    noise = S.uniform_pm1(16000, 70)
+    cases = {
+        "noise": noise,
+        "chirp+noise": S.chirp(16000, 200.0, 6000.0) + np.float32(1e-3) * S.uniform_pm1(16000, 71),
+        "quiet": noise * np.float32(1e-3),
+        "silent tail": np.concatenate([noise[:5000], np.zeros(11000, np.float32)]),
+    }
+    x = np.stack(list(cases.values()))
+    out = plan.clips(torch.from_numpy(x).cuda(), 1 << 20).cpu().numpy()
+    assert out.shape == (4, 16, 20)
+    for i, name in enumerate(cases):
+        gate(out[i], O.aubio_mfcc_clip(x[i]), f"aubio front end/{name}")
+    # silent frames sit on SAFE_LOG10's floor: log10(2e-42) in every filter -> c0 = sqrt(40) * floor, the rest 0
+    assert np.abs(out[3, 8:, 0] - np.sqrt(40.0) * np.log10(np.float64(np.float32(2e-42)))).max() < 1e-3 and np.abs(out[3, 8:, 1:]).max() < 1e-4
+    # ragged lengths: zero history in front, the zero-padded short last hop, odd lengths (host entry point packs the stride)
+    for n in (1, 2, 1023, 1025, 2500, 4097, 15999):
+        sig = S.uniform_pm1(n, 80 + n)
+        got = plan.clips_host(sig, 1 << 20)[0]
+        ref = O.aubio_mfcc_clip(sig)
+        assert got.shape == ref.shape == (-(-n // 1024), 20)
+        gate(got, ref, f"aubio front end/len{n}")
+    # max_frames caps the clip like any other framing; another sample rate (the reference's recordings are 96 kHz) moves the bank
+    assert torch.equal(plan.clips(torch.from_numpy(x).cuda(), 5), torch.from_numpy(out[:, :5]).cuda())
+    p96 = dsp_amd.MfccPlan(scrubjay.scrubjay_infer_config(96000))
+    sig = S.uniform_pm1(30000, 90)
+    gate(p96.clips_host(sig, 1 << 20)[0], O.aubio_mfcc_clip(sig, sample_rate=96000), "aubio front end/96 kHz")
+    # fused clip -> label: same features as MFCC -> pooling -> SVM in three kernels, and as the oracle chain
+    sj = scrubjay.ScrubJay({k: m[k] for k in m.files}, config=cfg)
+    gen = torch.Generator(device="cuda").manual_seed(29)
+    clips = torch.rand((200, 16000), device="cuda", generator=gen) * 2 - 1
+    clips[::3] *= 0.01
+    clips[4, 3000:] = 0.0
+    a = sj(clips, fused=False)
+    b = sj(clips, fused=True)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    model = _model(m)
+    for i in (0, 3, 4, 199):
+        omfcc = O.aubio_mfcc_clip(clips[i].cpu().numpy())
+        assert omfcc.shape == (16, 20)
+        ofeat = O.mfcc_stats(omfcc)
+        feat = b[3][i].cpu().numpy()
+        assert np.all(np.abs(feat - ofeat) <= 1e-4 * np.abs(omfcc).max())
         lab, odec, op1 = O.svm_predict(model, feat)
         assert abs(float(b[1][i]) - odec) <= 2e-5 * max(1.0, abs(odec)) and _prob_close(float(b[2][i]), op1)[0]
         if abs(odec) > 1e-5:
