@@ -94,6 +94,42 @@ def classify_batch(clips: np.ndarray, with_trace: bool = False, config=None):
     return labels, out
 
 
+def classify_batch_f64(clips: np.ndarray, with_trace: bool = False, config=None):
+    """The float64 classifier of donut-classifier/classifier.c (:83-192) on the GPU: clips [n_clips][n] float64 (host) -> labels
+    int32 (+ per-clip float64 midpoints / band sums).  config: None (the file's thresholds 0.70 / 0.85, 45 dB, 75 / 300 / 100) or a
+    6-tuple (keep_lo, keep_hi, midpoint_db, middle_max, above_min, below_min) of doubles."""
+    clips = np.ascontiguousarray(np.atleast_2d(clips), np.float64)
+    n_clips, n = clips.shape
+    labels = np.zeros(n_clips, np.int32)
+    tr = (_lib.ClassifyTraceF64 * n_clips)() if with_trace else None
+    cfg = None if config is None else _lib.ClassifyConfigF64(*[float(v) for v in config])
+    _lib.check(_lib.load().dsp_classify_batch_host_f64(C.byref(cfg) if cfg is not None else None, clips.ctypes.data, n_clips, n, n,
+                                                        labels.ctypes.data, C.byref(tr) if with_trace else None), "dsp_classify_batch_host_f64")
+    if not with_trace:
+        return labels
+    out = []
+    for t in tr:
+        k = t.n_midpoints
+        out.append((np.array(t.midpoints[:k], np.float64),
+                    np.array([[t.sums[i][j] for j in range(3)] for i in range(k)], np.float64).reshape(-1, 3)))
+    return labels, out
+
+
+def classify_device_f64(clips, labels=None, config=None):
+    """clips: cuda float64 [n_clips][n] -> cuda int32 labels (dsp_classify_batch_device_f64); runs on torch's current stream."""
+    import torch
+    if not (clips.is_cuda and clips.dtype == torch.float64 and clips.dim() == 2 and clips.stride(1) == 1):
+        raise ValueError("clips must be a float64 CUDA tensor [n_clips][n] with unit inner stride")
+    n_clips, n = clips.shape
+    if labels is None:
+        labels = torch.empty(n_clips, dtype=torch.int32, device=clips.device)
+    st = C.c_void_p(torch.cuda.current_stream(clips.device).cuda_stream)
+    cfg = None if config is None else _lib.ClassifyConfigF64(*[float(v) for v in config])
+    _lib.check(_lib.load().dsp_classify_batch_device_f64(C.byref(cfg) if cfg is not None else None, clips.data_ptr(), n_clips, n,
+                                                          clips.stride(0), labels.data_ptr(), None, st), "dsp_classify_batch_device_f64")
+    return labels
+
+
 def find_midpoints(data: np.ndarray, fs: int = 16000) -> np.ndarray:
     """sync/lib/classifier.h:18: midpoints (seconds) of the loud 1000-3000 Hz stretches of one clip."""
     data = np.ascontiguousarray(data, np.float32).reshape(-1)

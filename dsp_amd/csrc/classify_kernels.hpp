@@ -104,6 +104,18 @@ hipError_t launch_spec_threshold(SpecTables *tables, float threshold_db, hipStre
 hipError_t launch_sum_intense(float lower, float upper, float half_range, const float *freqs, int nf, const float *times, int nt,
                               const float *db, float midpoint, float *out, hipStream_t stream);
 
+// ---- the float64 classifier of donut-classifier/classifier.c (classify_f64_kernels.hip) ----
+struct ClassifyRuleD { double keep_lo, keep_hi, midpoint_db, middle_max, above_min, below_min; };
+struct ClassifyTraceD {
+    int n_midpoints;
+    double midpoints[kMaxMidpoints];
+    double sums[kMaxMidpoints][3];
+};
+// sxx_bp / sxx_mp: [c][129][T] float64 PSD maps of the 3000-7500 Hz / 1000-3000 Hz filtered clips (launch_spectrogram_f64);
+// labels[c] = the rule's verdict (classifier.c:184), trace (optional): midpoints and band sums per clip
+hipError_t launch_classify_f64_tail(const double *sxx_bp, const double *sxx_mp, long n_clips, int n, int fs, const ClassifyRuleD &rule,
+                                    int *labels, ClassifyTraceD *trace, hipStream_t stream);
+
 void build_spec_tables(int fs, SpecTables &t);
 
 }  // namespace dsp

@@ -67,14 +67,27 @@ class ClassifyConfig(C.Structure):
                 ("middle_max", C.c_float), ("above_min", C.c_float), ("below_min", C.c_float)]
 
 
+class ClassifyConfigF64(C.Structure):
+    """dsp_classify_config_f64: the same thresholds as doubles, for the float64 classifier (donut-classifier/classifier.c)."""
+
+    _fields_ = [(k, C.c_double) for k in ("keep_lo", "keep_hi", "midpoint_db", "middle_max", "above_min", "below_min")]
+
+
+class ClassifyTraceF64(C.Structure):
+    _fields_ = [("n_midpoints", C.c_int), ("midpoints", C.c_double * 64), ("sums", (C.c_double * 3) * 64)]
+
+
 WINDOW_HANN, WINDOW_HAMMING, WINDOW_RECT = 0, 1, 2
-MELNORM_NONE, MELNORM_SLANEY, MELNORM_LIBROSA = 0, 1, 2
-LOG_PER_FRAME_MAX, LOG_GLOBAL_REF1 = 0, 1
+MELNORM_NONE, MELNORM_SLANEY, MELNORM_LIBROSA, MELNORM_AUBIO_SLANEY = 0, 1, 2, 3
+LOG_PER_FRAME_MAX, LOG_GLOBAL_REF1, LOG_LOG10_FLOOR = 0, 1, 2
+SPECTRUM_POWER, SPECTRUM_MAGNITUDE = 0, 1
+FRAMING_COMPLETE, FRAMING_STREAM = 0, 1
 PREFILTER_NONE, PREFILTER_BUTTER_1000_3000, PREFILTER_BUTTER_3000_7500 = 0, 1, 2
 
 # every symbol include/dsp_amd.h declares (tests check the library exports them all)
 SYMBOLS = [
     "compute_mfcc", "dsp_classify",
+    "dsp_classify_default_config_f64", "dsp_classify_batch_host_f64", "dsp_classify_batch_device_f64",
     "dsp_classify_default_config", "dsp_classify_batch_host_cfg", "dsp_classify_batch_device_cfg", "dsp_sum_intense_f32",
     "dsp_butter_bandpass_filter_f32", "dsp_butter_bandpass_filter_f64", "dsp_compute_spectrogram_f32", "dsp_compute_spectrogram_f64",
     "dsp_classify_batch_host", "dsp_classify_batch_device", "dsp_find_midpoints",
@@ -175,6 +188,9 @@ def load() -> C.CDLL:
     L.dsp_version.argtypes = []; L.dsp_version.restype = C.c_char_p
     L.dsp_classify_default_config.argtypes = [C.POINTER(ClassifyConfig)]; L.dsp_classify_default_config.restype = None
     L.dsp_classify_batch_host_cfg.argtypes = [C.POINTER(ClassifyConfig), vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_batch_host_cfg.restype = ip
+    L.dsp_classify_default_config_f64.argtypes = [C.POINTER(ClassifyConfigF64)]; L.dsp_classify_default_config_f64.restype = None
+    L.dsp_classify_batch_host_f64.argtypes = [C.POINTER(ClassifyConfigF64), vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_batch_host_f64.restype = ip
+    L.dsp_classify_batch_device_f64.argtypes = [C.POINTER(ClassifyConfigF64), vp, C.c_long, ip, C.c_long, vp, vp, vp]; L.dsp_classify_batch_device_f64.restype = ip
     L.dsp_classify_batch_device_cfg.argtypes = [C.POINTER(ClassifyConfig), vp, C.c_long, ip, C.c_long, vp, vp]; L.dsp_classify_batch_device_cfg.restype = ip
     L.dsp_sum_intense_f32.argtypes = [C.c_float, C.c_float, C.c_float, vp, ip, vp, ip, vp, C.c_float, C.POINTER(C.c_float)]
     L.dsp_sum_intense_f32.restype = ip

@@ -228,6 +228,27 @@ int dsp_classify_batch_host_cfg(const dsp_classify_config *cfg, const float *sig
 int dsp_classify_batch_device_cfg(const dsp_classify_config *cfg, const float *d_signal, long n_clips, int n, long stride,
                                   int *d_labels, void *stream);
 
+/* The float64 classifier, donut-classifier/classifier.c (the file's per-clip body :83-192, sum_intense :594-653,
+ * find_midpoints :655-830): both Butterworth filters, both spectrograms, dB maps, 45 dB midpoints, normalisation, keep band,
+ * band sums and rule in double on the GPU.  Thresholds are doubles as in the file; cfg NULL = its own
+ * (0.70 / 0.85 :141-142, 45 dB :660, middle < 75 && above > 300 && below > 100 :184).  fs is 16000 (the rate butter_bandpass has
+ * coefficients for).  The reference transforms with FFTW (unvendored): the spectrogram is a float64 DFT, so parity is by
+ * tolerance (labels and midpoints equal, band sums to ~1e-9 relative); correctness first, this path is not tuned.
+ * _host: host pointers; _device: HBM pointers (d_trace may be NULL), synchronised before returning.                        */
+typedef struct dsp_classify_config_f64 {
+    double keep_lo, keep_hi, midpoint_db, middle_max, above_min, below_min;
+} dsp_classify_config_f64;
+typedef struct dsp_classify_trace_f64 {
+    int n_midpoints;
+    double midpoints[64];
+    double sums[64][3];
+} dsp_classify_trace_f64;
+void dsp_classify_default_config_f64(dsp_classify_config_f64 *cfg);
+int dsp_classify_batch_host_f64(const dsp_classify_config_f64 *cfg, const double *signal, long n_clips, int n, long stride,
+                                int *labels, dsp_classify_trace_f64 *trace);
+int dsp_classify_batch_device_f64(const dsp_classify_config_f64 *cfg, const double *d_signal, long n_clips, int n, long stride,
+                                  int *d_labels, dsp_classify_trace_f64 *d_trace, void *stream);
+
 /* sum_intense (sync/lib/classifier.h:17, classifier.cpp:370-431) on a flat matrix: db[freq_bins][time_bins] (NaN = dropped
  * cell), the reference's index searches and its (row, column) summation order.  Host pointers; *out receives the sum.   */
 int dsp_sum_intense_f32(float lower, float upper, float half_range, const float *frequencies, int freq_bins,

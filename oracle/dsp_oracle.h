@@ -156,6 +156,23 @@ typedef struct orc_classify_cfg {
 int orc_classify_with(const float *data, int n, const orc_classify_cfg *cfg, orc_classify_trace *trace);
 int orc_find_midpoints_thr(const float *data, int n, int fs, float threshold_db, float *midpoints, int cap);
 
+/* ---- the float64 classifier, donut-classifier/classifier.c (classify_f64_oracle.c) ---- */
+typedef struct orc_classify_cfg_f64 {
+    double keep_lo, keep_hi, midpoint_db, middle_max, above_min, below_min;
+} orc_classify_cfg_f64;
+typedef struct orc_classify_trace_f64 {
+    int n_midpoints;
+    double midpoints[64];
+    double sums[64][3];
+} orc_classify_trace_f64;
+/* classifier.c:594-653 */
+double orc_sum_intense_f64(double lower, double upper, double half_range, const double *freqs, int n_freq, const double *times,
+                           int n_time, const double *db, double midpoint);
+/* classifier.c:655-830 (threshold_db: 45 at :660) */
+int orc_find_midpoints_f64(const double *data, int n, int fs, double threshold_db, double *midpoints, int cap);
+/* classifier.c:83-192 per clip; cfg NULL = the file's thresholds (0.70 / 0.85 :141-142, 45 dB :660, 75 / 300 / 100 :184) */
+int orc_classify_f64(const double *data, int n, const orc_classify_cfg_f64 *cfg, orc_classify_trace_f64 *trace);
+
 /* ---- pooling + SVM (cepstrum/scrubjay_infer.c, scrubjay_svm.onnx) ------- */
 
 /* scrubjay_infer.c:36-66  mean | population-std over T frames of n_coef,

@@ -35,6 +35,14 @@ class ClassifyTrace(C.Structure):
                 ("sums", (C.c_float * 3) * 64)]
 
 
+class ClassifyCfgF64(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("keep_lo", "keep_hi", "midpoint_db", "middle_max", "above_min", "below_min")]
+
+
+class ClassifyTraceF64(C.Structure):
+    _fields_ = [("n_midpoints", C.c_int), ("midpoints", C.c_double * 64), ("sums", (C.c_double * 3) * 64)]
+
+
 class SvmModel(C.Structure):
     _fields_ = [("n_features", C.c_int), ("n_sv", C.c_int), ("gamma", C.c_float),
                 ("rho", C.c_float), ("prob_a", C.c_float), ("prob_b", C.c_float),
@@ -63,7 +71,7 @@ PREFILTER_NONE, PREFILTER_BUTTER_1000_3000, PREFILTER_BUTTER_3000_7500 = 0, 1, 2
 def build(force: bool = False) -> None:
     """Compile liboracle.so (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("dsp_oracle.c", "aubio_oracle.c", "dsp_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("dsp_oracle.c", "aubio_oracle.c", "classify_f64_oracle.c", "dsp_oracle.h")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(so) < os.path.getmtime(f) for f in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
@@ -121,6 +129,10 @@ def lib() -> C.CDLL:
         L.orc_classify_speaker.argtypes = [C.POINTER(Gmm), C.POINTER(Gmm), _F, C.c_int]
         L.orc_classify_speaker.restype = C.c_int
         L.orc_upsample_linear.argtypes = [_F, C.c_int, _F, C.c_int]
+        L.orc_classify_f64.argtypes = [_D, C.c_int, C.POINTER(ClassifyCfgF64), C.POINTER(ClassifyTraceF64)]
+        L.orc_classify_f64.restype = C.c_int
+        L.orc_find_midpoints_f64.argtypes = [_D, C.c_int, C.c_int, C.c_double, _D, C.c_int]
+        L.orc_find_midpoints_f64.restype = C.c_int
         L.orc_aubio_window_hanningz.argtypes = [C.c_int, _F]
         L.orc_aubio_filterbank_slaney.argtypes = [C.c_int, C.c_int, _F]
         L.orc_aubio_frames_for.argtypes = [C.c_int, C.c_int]
@@ -381,6 +393,26 @@ def upsample_linear(x: np.ndarray, new_size: int) -> np.ndarray:
 
 
 # ---- the reference itself (only where oracle/_ref was built) -------------------
+
+def classify_f64(data, cfg=None):
+    """donut-classifier/classifier.c per clip (float64): -> (label, midpoints[n_mid], sums[n_mid][3]).  cfg: dict of the six
+    thresholds (keep_lo, keep_hi, midpoint_db, middle_max, above_min, below_min) or None for the file's own."""
+    data = np.ascontiguousarray(data, np.float64)
+    tr = ClassifyTraceF64()
+    c = None
+    if cfg is not None:
+        c = ClassifyCfgF64(*[float(cfg[k]) for k in ("keep_lo", "keep_hi", "midpoint_db", "middle_max", "above_min", "below_min")])
+    label = lib().orc_classify_f64(data, data.size, C.byref(c) if c is not None else None, C.byref(tr))
+    n = tr.n_midpoints
+    return label, np.array(tr.midpoints[:n], np.float64), np.array([list(r) for r in tr.sums[:n]], np.float64).reshape(n, 3)
+
+
+def find_midpoints_f64(data, fs=16000, threshold_db=45.0) -> np.ndarray:
+    data = np.ascontiguousarray(data, np.float64)
+    out = np.empty(64, np.float64)
+    n = lib().orc_find_midpoints_f64(data, data.size, fs, float(threshold_db), out, 64)
+    return out[:n]
+
 
 # ---- aubio front end of cepstrum/scrubjay_infer.c:21-53 (aubio_oracle.c, parity unpinned) ----
 

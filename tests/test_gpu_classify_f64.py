@@ -1,0 +1,91 @@
+"""GPU: the float64 classifier of donut-classifier/classifier.c (dsp_classify_batch_*_f64: both Butterworth filters, both
+spectrograms, dB maps, 45 dB midpoints, normalisation, keep band, band sums and rule in double) against the oracle's float64
+restatement (oracle/classify_f64_oracle.c).  The reference transforms with FFTW (unvendored): the GPU spectrogram is a float64
+DFT, so the bar is tolerance -- labels and midpoint counts equal, midpoints to 1e-12 s, band sums to 1e-8 relative."""
+import numpy as np
+import pytest
+
+from tests import signals as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dsp():
+    import dsp_amd
+    return dsp_amd
+
+
+def _check(got_label, got_trace, x, cfg=None, what=""):
+    from oracle import oracle as O
+    olab, omids, osums = O.classify_f64(np.asarray(x, np.float64), cfg)
+    mids, sums = got_trace
+    assert int(got_label) == olab, what
+    assert mids.shape == omids.shape and np.allclose(mids, omids, rtol=0, atol=1e-12), what
+    # the reference stops at the first midpoint that fires the rule: rows after it are 0 on both sides
+    assert sums.shape == osums.shape and np.allclose(sums, osums, rtol=1e-8, atol=1e-8), what
+    return olab, len(omids)
+
+
+def test_classify_cases_vs_oracle(dsp):
+    cases = S.classify_cases()
+    clips = np.stack([c.astype(np.float64) for c in cases.values()])
+    labels, trace = dsp.classify_batch_f64(clips, with_trace=True)
+    seen, n_mid = set(), 0
+    for i, name in enumerate(cases):
+        lab, k = _check(labels[i], trace[i], clips[i], what=name)
+        seen.add(lab)
+        n_mid += k
+    assert seen == {0, 1} and n_mid >= 5
+    assert np.array_equal(dsp.classify_batch_f64(clips), labels)            # without the trace: same labels
+
+
+def test_other_thresholds_and_the_rule(dsp):
+    x = S.classify_cases()["scrub_a"].astype(np.float64)[None, :]
+    donut = (0.70, 0.85, 45.0, 75.0, 300.0, 100.0)
+    assert dsp.classify_batch_f64(x)[0] == dsp.classify_batch_f64(x, config=donut)[0] == 1
+    for cfg in ((0.70, 0.85, 45.0, 75.0, 1e9, 100.0), (0.65, 0.80, 70.0, 100.0, 200.0, 80.0), (0.70, 0.85, 45.0, 50.0, 200.0, 200.0)):
+        labels, trace = dsp.classify_batch_f64(x, with_trace=True, config=cfg)
+        _check(labels[0], trace[0], x[0], dict(zip(("keep_lo", "keep_hi", "midpoint_db", "middle_max", "above_min", "below_min"), cfg)), str(cfg))
+    with pytest.raises(dsp.DspError):
+        dsp.classify_batch_f64(x, config=(0.9, 0.8, 45.0, 75.0, 300.0, 100.0))      # keep_lo >= keep_hi
+
+
+def test_donut_classifier_recordings_in_float64(dsp, golden):
+    """The classifier's own 16 kHz recordings (donut-classifier/16k/*.wav, channel 0 / 32768.0 as classifier.c:55-59)."""
+    g = golden("donut16k_ref.npz")
+    names = sorted({k.split("__")[0] for k in g.files})
+    n_mid = 0
+    for n in names:
+        x = g[n + "__pcm"][:, 0].astype(np.float64) / 32768.0
+        labels, trace = dsp.classify_batch_f64(x[None, :], with_trace=True)
+        n_mid += _check(labels[0], trace[0], x, what=n)[1]
+    assert n_mid >= 5
+
+
+def test_lengths_sub_batches_and_the_device_entry_point(dsp):
+    import torch
+    from oracle import oracle as O
+    # shorter than one spectrogram segment -> label 0, no midpoints; exactly one segment; odd lengths
+    for n in (10, 255):
+        labels, trace = dsp.classify_batch_f64(np.ones((3, n)), with_trace=True)
+        assert not labels.any() and all(len(m) == 0 for m, _ in trace)
+    for n in (256, 479, 480, 5001):
+        x = S.uniform_pm1(n, 40 + n).astype(np.float64)[None, :] * 0.3
+        labels, trace = dsp.classify_batch_f64(x, with_trace=True)
+        _check(labels[0], trace[0], x[0], what=f"len{n}")
+    # more clips than one scratch pass (2048): every clip is its own problem, whatever its place in the batch
+    call = S.classify_cases()["scrub_a"].astype(np.float64)
+    rng = np.random.default_rng(5)
+    clips = rng.uniform(-0.05, 0.05, (2100, 16000))
+    clips[::7] = clips[::7] * 0.01 + call                          # the call over a quiet floor: label 1
+    labels = dsp.classify_batch_f64(clips)
+    for i in (0, 1, 6, 7, 2047, 2048, 2093, 2099):
+        assert labels[i] == O.classify_f64(clips[i])[0], i
+    assert labels[::7].all() and not labels[1::7].any()
+    dl = dsp.classify_device_f64(torch.from_numpy(clips).cuda())
+    assert np.array_equal(dl.cpu().numpy(), labels)
+    # a strided device batch (rows padded): same labels
+    padded = torch.zeros((64, 16016), dtype=torch.float64, device="cuda")
+    padded[:, :16000] = torch.from_numpy(clips[:64]).cuda()
+    assert np.array_equal(dsp.classify_device_f64(padded[:, :16000]).cpu().numpy(), labels[:64])
