@@ -271,6 +271,18 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
                    "20 coefficients; restated from aubio 0.4, parity unpinned)" if own else "")
                 + (f"; labels + probabilities (8 B per clip) all-gathered over {world} ranks every step, pipelined" if world > 1 else ""))
         kernel = "mfcc2048_kernel<POOL, AUB>" if own else "mfcc512_wave_kernel<POOL>"
+    elif args.workload == "stop":
+        import numpy as np
+        n = args.clips or 125_000
+        clips = torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1
+        net = dsp_amd.StopModel(dict(np.load(os.path.join(ROOT, "tests", "golden", "stop_model.npz"))), local)
+        plan = dsp_amd.MfccPlan(dsp_amd.default_config(), local)
+        step = lambda: net.classify_signal_batch(plan, clips)   # noqa: E731
+        units, unit, bytes_per = n, "clips/s", 64_000 + 4      # probability out
+        two = bool(os.environ.get("DSP_AMD_STOP_TWO_KERNELS"))
+        what = (f"classify_signal (stop_detector.c:12-55) on {n} x 1 s 16 kHz fp32 clips: MFCC(13) -> StandardScaler -> 6500-4-2-2-1 net -> P(stop), "
+                + ("two kernels (MFCC matrix written, then the net)" if two else "ONE kernel (the tile epilogue feeds layer 1; the MFCC matrix never reaches HBM)"))
+        kernel = "mfcc512_wave_kernel + stop_tail_kernel" if two else "mfcc512_wave_kernel<POOL = 2>"
     elif args.workload == "config3":
         n = args.clips or 1_000_000
         frames = torch.rand((n, 1024), device=dev, generator=gen) * 2 - 1
@@ -463,7 +475,7 @@ def main():
                          "steps end before the GPU's clocks have ramped (first launches after idle run 0.6 ms); reported in config")
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="all-gather the per-rank features every step (RCCL)")
-    ap.add_argument("--workload", choices=["frames", "clips", "classify", "config3", "config5", "config5_2048", "pcm16"], default="frames",
+    ap.add_argument("--workload", choices=["frames", "clips", "classify", "config3", "config5", "config5_2048", "pcm16", "stop"], default="frames",
                     help="frames = BASELINE configs[1] (the headline metric, default); clips = configs[3] per-GPU share "
                          "(12 500 x 1 s clips, reference framing 400/160); classify = the donut classifier on 1 s clips")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step for --workload clips / classify")

@@ -99,7 +99,8 @@ struct dsp_mfcc_plan {
     int resident_blocks_gen = 3;
     int gen_slots = 0;                            // mel chunk slots per lane the 1024-point tables use (<= 3: wave kernel)
     int resident_blocks_gen_wave = 2;
-    dsp::PrefilterScan *d_scan = nullptr;         // prefilter fused into the 1024-point wave kernel (full frames): its parallel form
+    dsp::PrefilterScan *d_scan = nullptr;         // prefilter fused into the 1024-point wave kernel (full frames): its tables
+    int scan_steps[4] = {6, 6, 6, 6};             // host copy of PrefilterScan::c_steps (picks the kernel instantiation)
     int resident_blocks_gen_pre = 2;
     float *d_filtered = nullptr;                  // per-frame prefilter output (sub-batch)
     size_t filtered_cap = 0;
@@ -285,8 +286,11 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
                             cfg->prefilter == DSP_PREFILTER_BUTTER_1000_3000 ? 3000 : 7500, b, a);
         dsp::PrefilterScan sc;
         if (!dsp::build_prefilter_scan(b, a, sc, why)) { dsp_mfcc_plan_destroy(p); return fail(DSP_EINVAL, why); }
-        e = hipMalloc(&p->d_scan, sizeof(sc));
-        if (e == hipSuccess) e = hipMemcpy(p->d_scan, &sc, sizeof(sc), hipMemcpyHostToDevice);
+        if (sc.c_ok) {      // the kernel runs the cascade form; coefficients without it (none of the two literal sets) take the two-pass path
+            e = hipMalloc(&p->d_scan, sizeof(sc));
+            if (e == hipSuccess) e = hipMemcpy(p->d_scan, &sc, sizeof(sc), hipMemcpyHostToDevice);
+            for (int k = 0; k < 4; ++k) p->scan_steps[k] = sc.c_steps[k];
+        }
     }
 #ifdef DSP_AMD_EXPERIMENTS
     // measured dead ends kept buildable (python -m dsp_amd.build with DSP_AMD_EXPERIMENTS=1): the row-per-frame kernel and
@@ -497,7 +501,7 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     }
     if (fused_prefilter && !(gen_wave && p->d_scan)) return fail(DSP_EINVAL, "internal: fused prefilter without its tables");
     if (gen_wave)
-        DSP_HIP(dsp::launch_mfcc1024_wave(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream, fused_prefilter ? p->d_scan : nullptr));
+        DSP_HIP(dsp::launch_mfcc1024_wave(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream, fused_prefilter ? p->d_scan : nullptr, p->scan_steps));
     else if (gen)
         DSP_HIP(dsp::launch_mfcc1024(a, p->d_gen_tables, (int)blocks, (hipStream_t)stream));
 #ifdef DSP_AMD_EXPERIMENTS
@@ -1123,6 +1127,47 @@ int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signa
     DSP_HIP(dsp::launch_mfcc512_pool(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
     return t;
 }
+
+}  // extern "C"
+
+// capi_util.hpp: the fused form of dsp_classify_signal_batch_device (capi_consumers.cpp)
+int dsp::stop_fused_device(dsp_mfcc_plan *p, const dsp::StopModelDev &m, const float *d_signal, long n_clips, int samples_per_clip,
+                           long clip_stride, int t, float *d_prob, void *stream)
+{
+    (void)samples_per_clip;
+    // the reference's shape on the default kernel: 512-point, per-frame log, 13 coefficients of 40 mel energies, complete frames
+    if (p->cfg.n_fft != 512 || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX || p->cfg.prefilter != DSP_PREFILTER_NONE || p->kernel != DSP_KERNEL_WAVE ||
+        p->host.dct_split != 4 || p->host.dct_len != 10 || m.n_coef != p->cfg.n_mfcc || m.units[0] > dsp::kStopFusedUnits || !m.fold_a || t <= 0 ||
+        std::getenv("DSP_AMD_STOP_TWO_KERNELS"))
+        return 0;
+    if ((reinterpret_cast<uintptr_t>(d_signal) & 7) || (n_clips > 1 && (clip_stride & 1))) return 0;      // the two-kernel path reports it
+    if (m.max_frames <= 0) return fail(DSP_EINVAL, "stop model without frames");
+    DSP_ON_DEVICE(p->device);
+    dsp::Mfcc512Args a{};
+    a.in = d_signal;
+    a.in_kind = 0;
+    a.out = nullptr;
+    a.tables = p->d_tables;
+    a.n_frames = n_clips * (long)t;
+    a.clip_stride = clip_stride;
+    a.frames_per_clip = t;
+    a.hop = p->cfg.hop_length;
+    a.frame_len = p->cfg.frame_length;
+    a.chunk = t;                                  // one wavefront walks one clip
+    a.n_mels = p->cfg.n_mels;
+    a.n_mfcc = p->cfg.n_mfcc;
+    a.amin = p->cfg.amin;
+    a.top_db = p->cfg.top_db;
+    a.log_mode = 0;
+    a.stop.m = m;
+    a.stop.prob = d_prob;
+    const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks;
+    const long blocks = std::max(1L, std::min((long)p->n_cu * per_cu, (n_clips + 3) / 4));
+    DSP_HIP(dsp::launch_mfcc512_stop(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+    return 1;
+}
+
+extern "C" {
 
 int dsp_svm_predict_device(dsp_svm *s, const float *d_feat, long n_clips, int *d_labels, float *d_decision,
                            float *d_prob1, void *stream)

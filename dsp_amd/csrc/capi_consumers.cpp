@@ -73,11 +73,33 @@ int dsp_stop_model_create(const dsp_stop_model_params *p, int device, dsp_stop_m
             }
             pad[(size_t)t * u1 + j] = s;
         }
+    // the fused epilogue's form of layer 1 (consumer_kernels.hpp): A = w / div per input, and per T the constant the live
+    // inputs' B = -mean A add up to, on top of the padded frames' contribution
+    const bool foldable = u1 <= (size_t)dsp::kStopFusedUnits;
+    std::vector<float> fold_a;
+    std::vector<double> pad_b;
+    if (foldable) {
+        fold_a.assign(n_in * dsp::kStopFusedUnits, 0.0f);
+        pad_b.assign(pad.size(), 0.0);
+        std::vector<double> live(u1, 0.0);                          // sum_{t' < t, c} B
+        for (int t = 0; t <= p->max_frames; ++t) {
+            for (size_t j = 0; j < u1; ++j) pad_b[(size_t)t * u1 + j] = pad[(size_t)t * u1 + j] + live[j];
+            if (t == p->max_frames) break;
+            for (int c = 0; c < p->n_coef; ++c) {
+                const size_t i = (size_t)c * p->max_frames + t;
+                for (size_t j = 0; j < u1; ++j) {
+                    const double a = (double)p->kernel[0][i * u1 + j] / (double)div[i];
+                    fold_a[i * dsp::kStopFusedUnits + j] = (float)a;
+                    live[j] += -(double)p->scaler_mean[i] * (double)(float)a;      // B pairs with the ROUNDED A the kernel multiplies by
+                }
+            }
+        }
+    }
     // one device blob: doubles first (alignment), then floats
-    size_t n_f = 2 * n_in;
+    size_t n_f = 2 * n_in + fold_a.size();
     size_t fan_in = n_in;
     for (int l = 0; l < 4; ++l) { n_f += fan_in * p->units[l] + p->units[l]; fan_in = p->units[l]; }
-    const size_t bytes = pad.size() * sizeof(double) + n_f * sizeof(float);
+    const size_t bytes = (pad.size() + pad_b.size() + 1) * sizeof(double) + n_f * sizeof(float);
     auto *m = new dsp_stop_model;
     m->device = device;
     if (hipMalloc(&m->d_blob, bytes) != hipSuccess) { delete m; return capi_fail(DSP_ENOMEM, "hipMalloc"); }
@@ -89,6 +111,9 @@ int dsp_stop_model_create(const dsp_stop_model_params *p, int device, dsp_stop_m
     m->m.n_coef = p->n_coef;
     m->m.max_frames = p->max_frames;
     m->m.pad = static_cast<const double *>(put(pad.data(), pad.size() * sizeof(double)));
+    m->m.pad_b = foldable ? static_cast<const double *>(put(pad_b.data(), pad_b.size() * sizeof(double))) : nullptr;
+    if ((pad.size() + pad_b.size()) % 2) { static const double zero = 0.0; (void)put(&zero, sizeof(double)); }      // keep fold_a 16-byte aligned
+    m->m.fold_a = foldable ? static_cast<const float *>(put(fold_a.data(), fold_a.size() * sizeof(float))) : nullptr;
     m->m.mean = static_cast<const float *>(put(p->scaler_mean, n_in * 4));
     m->m.div = static_cast<const float *>(put(div.data(), n_in * 4));
     fan_in = n_in;
@@ -130,6 +155,10 @@ int dsp_classify_signal_batch_device(dsp_mfcc_plan *plan, dsp_stop_model *m, con
     if (cfg.n_mfcc != m->m.n_coef) return capi_fail(DSP_EINVAL, "plan n_mfcc differs from the model's n_coef");
     if (n_clips == 0) return DSP_OK;
     const int t = dsp_mfcc_frames_for(&cfg, samples_per_clip, m->m.max_frames);          // stop_detector.c:18-21
+    {   // one kernel from PCM to probability when the plan is the reference's shape: the MFCC matrix is never written
+        const int fused = dsp::stop_fused_device(plan, m->m, d_signal, n_clips, samples_per_clip, clip_stride, t, d_prob, stream);
+        if (fused != 0) return fused < 0 ? fused : DSP_OK;
+    }
     std::lock_guard<std::mutex> lock(m->mu);
     DSP_ON_DEVICE(m->device);
     const size_t need = (size_t)n_clips * (t > 0 ? t : 1) * cfg.n_mfcc * sizeof(float);

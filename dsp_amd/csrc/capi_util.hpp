@@ -7,8 +7,15 @@
 
 #include "../../include/dsp_amd.h"
 
+struct dsp_mfcc_plan;
 namespace dsp {
 int capi_fail(int code, const std::string &msg);   // sets dsp_last_error() for this thread, returns code
+struct StopModelDev;
+// capi.cpp (owner of dsp_mfcc_plan): classify_signal in one kernel -- clip -> MFCC -> stop-word net, the MFCC matrix never written.
+// Returns 1 when the fused kernel was enqueued, 0 when this plan / model shape has no fused form (the caller runs the two-kernel
+// path), < 0 on error.  t = frames per clip (already capped at the model's max_frames).
+int stop_fused_device(dsp_mfcc_plan *plan, const StopModelDev &m, const float *d_signal, long n_clips, int samples_per_clip,
+                      long clip_stride, int t, float *d_prob, void *stream);
 }
 
 #define DSP_CAPI_HIP(call)                                                                              \

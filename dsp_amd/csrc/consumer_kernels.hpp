@@ -11,6 +11,7 @@
 namespace dsp {
 
 constexpr int kStopMaxUnits = 16;    // widest hidden layer the tail kernel is built for
+constexpr int kStopFusedUnits = 4;   // first-layer width the fused MFCC epilogue is built for (model_params.h: 4 units)
 
 struct StopModelDev {
     int n_coef, max_frames;          // 13, 500
@@ -19,6 +20,10 @@ struct StopModelDev {
     const float *kernel[4];          // (in, out) row-major
     const float *bias[4];
     const double *pad;               // [max_frames + 1][units[0]]: layer-1 contribution of the zero-padded frames t >= T
+    // The fused MFCC epilogue (mfcc512_wave_kernel<POOL = 2>, units[0] <= kStopFusedUnits; nullptr otherwise): layer 1 with the
+    // scaler folded in, w (x - mean) / div = x A + B per input and unit:
+    const float *fold_a;             // [n_coef * max_frames][kStopFusedUnits]: A[i][j] = w[i][j] / div[i] (0 past units[0])
+    const double *pad_b;             // [max_frames + 1][units[0]]: pad[T][j] + sum over the live inputs (t < T) of B[i][j] = -mean[i] A[i][j]
 };
 
 // prob[c] = net(coefficient-major, zero-padded view of mfcc[c][T][n_coef]); one wave per clip

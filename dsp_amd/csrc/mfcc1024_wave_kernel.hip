@@ -44,6 +44,16 @@ constexpr int W_WAVE_BYTES = W_ETILE + 128 * 16 * 4;
 static_assert(W_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
 constexpr int kWaveSlots = 3;                       // chunk slots per lane this kernel holds in registers (128 HTK filters on 513 bins: 155 chunks)
 constexpr int kWaveZero = 192;                      // partial slot that always reads 0
+// block-shared LDS copies behind the four per-wave carves (round 3):
+//   the MFMA A operand of the tile epilogue (32 k-steps x 64 lanes): a global re-read in the rolled k loop sat latency-exposed
+//   in front of every MFMA (the 512-point kernel's larger shapes had the same cure);
+//   PRE only: the mel weights (3 slots x 12 taps x 64 lanes) as float4 rows [slot][quad][lane] -- the PRE variant has no registers
+//   for them, and 36 dword re-reads per frame from L1 made the kernel's speed hang on how many of them hipcc kept in flight
+//   (2.58 .. 3.64 ms per 1 M frames between builds that differed in nothing else).
+constexpr int B_DCTA = 4 * W_WAVE_BYTES;
+constexpr int B_MELW = B_DCTA + kGenDctSteps * 64 * 4;
+constexpr int B_BYTES_PLAIN = B_MELW;
+constexpr int B_BYTES_PRE = B_MELW + kWaveSlots * kMelChunk * 64 * 4;
 
 // forward radix-8 butterfly: u[q] = sum_a v[a] W8^(a q)
 __device__ __forceinline__ void radix8w(c32 (&v)[8])
@@ -128,12 +138,107 @@ __device__ __forceinline__ void prefilter_scan(const float (&x)[kScanChunk], flo
     }
 }
 
+// The same filter as a CASCADE of four second-order sections (PrefilterScan::c_*, tables.hpp), the form this kernel runs since
+// round 3.  Section s maps the lane's 16 samples u -> y in place: w[n] = u[n] - a1 w[n-1] - a2 w[n-2], y[n] = w[n] - w[n-2]
+// (the literal numerators are g (1 - z^-2)^4).  Lane-parallel like the parallel form: the chunk from zero state, a Kogge-Stone
+// scan over the lanes with M^(16 * 2^d), the chunk again from its true state.  T = double for the first two sections (they see
+// the unattenuated stop-band energy), float for the last two: no cancellation between sections of a cascade, so float32 there
+// costs 1e-5 of the parity gate's 1e-4 on stop-band-only frames (tools/emulate_prefilter_cascade.py) and half the issue cycles
+// of the float64 parallel form (552 float64 instructions per lane and frame -> ~210 float64 + ~210 float32).
+template <typename T>
+__device__ __forceinline__ T shfl_lane(T v, int byte_addr);
+template <>
+__device__ __forceinline__ double shfl_lane<double>(double v, int byte_addr) { return shfl_up_f64(v, byte_addr); }
+template <>
+__device__ __forceinline__ float shfl_lane<float>(float v, int byte_addr)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
+// STEPS: scan steps of this section, a compile-time count (the two literal filters need 1 / 3 / 3 / 5 and 2 / 3 / 3 / 4: one kernel
+// instantiation each; more steps than the poles need multiply by matrices below the tolerance and are harmless): the section is
+// straight-line code without a branch, so that it can share a scheduling region with the transform of the previous frame.
+template <typename T, int STEPS>
+__device__ __forceinline__ void cascade_section(T (&u)[kScanChunk], T a1, T a2, const T (*pw)[4][4], int sc, int lane)
+{
+    // pass 1: the chunk from zero state -> its own contribution to the state (w[n-1], w[n-2]) at its end
+    T t0 = 0, t1 = 0;
+#pragma unroll
+    for (int i = 0; i < kScanChunk; ++i) {
+        const T w0 = __builtin_fma(-a1, t0, __builtin_fma(-a2, t1, u[i]));      // the older state first: one dependent fma per sample
+        t1 = t0;
+        t0 = w0;
+    }
+    // inclusive scan over the lanes
+#pragma unroll
+    for (int d = 0; d < STEPS; ++d) {
+        const int from = ((lane - (1 << d)) & 63) << 2;
+        const bool on = lane >= (1 << d);
+        const T u0 = shfl_lane<T>(t0, from), u1 = shfl_lane<T>(t1, from);
+        const T *m = pw[d][sc];
+        const T n0 = __builtin_fma(m[1], u1, __builtin_fma(m[0], u0, t0)), n1 = __builtin_fma(m[3], u1, __builtin_fma(m[2], u0, t1));
+        t0 = on ? n0 : t0;
+        t1 = on ? n1 : t1;
+    }
+    // a chunk starts from the scan value of the lane before it (zero for lane 0)
+    {
+        const int from = ((lane - 1) & 63) << 2;
+        const T u0 = shfl_lane<T>(t0, from), u1 = shfl_lane<T>(t1, from);
+        t0 = lane ? u0 : (T)0;
+        t1 = lane ? u1 : (T)0;
+    }
+    // pass 2: the chunk again from its true state, output y = w[n] - w[n-2]
+#pragma unroll
+    for (int i = 0; i < kScanChunk; ++i) {
+        const T w0 = __builtin_fma(-a1, t0, __builtin_fma(-a2, t1, u[i]));
+        u[i] = w0 - t1;
+        t1 = t0;
+        t0 = w0;
+    }
+}
+
+// timing-only diagnostic build (never shipped; outputs are wrong): 1 = no filter at all
+#ifndef DSP_PRE_DIAG
+#define DSP_PRE_DIAG 0
+#endif
+template <int S0, int S1, int S2, int S3>
+__device__ __forceinline__ void prefilter_cascade(const float (&x)[kScanChunk], float (&y)[kScanChunk], const PrefilterScan *__restrict__ S, int lane)
+{
+#if DSP_PRE_DIAG == 1
+    for (int i = 0; i < kScanChunk; ++i) y[i] = x[i];
+    return;
+#endif
+    double ud[kScanChunk];
+#pragma unroll
+    for (int i = 0; i < kScanChunk; ++i) ud[i] = (double)x[i];
+    cascade_section<double, S0>(ud, S->c_a1[0], S->c_a2[0], S->c_pw, 0, lane);
+    cascade_section<double, S1>(ud, S->c_a1[1], S->c_a2[1], S->c_pw, 1, lane);
+    float uf[kScanChunk];
+#pragma unroll
+    for (int i = 0; i < kScanChunk; ++i) uf[i] = (float)ud[i];
+    cascade_section<float, S2>(uf, S->c_a1f[2], S->c_a2f[2], S->c_pwf, 2, lane);
+    cascade_section<float, S3>(uf, S->c_a1f[3], S->c_a2f[3], S->c_pwf, 3, lane);
+    const float g = (float)S->c_gain;
+#pragma unroll
+    for (int i = 0; i < kScanChunk; ++i) y[i] = uf[i] * g;
+}
+
 }  // namespace
+
+// Prefilter form of the PRE variant: 1 = cascade (default where the tables allow it), 0 = the float64 parallel form of round 2
+#ifndef DSP_PRE_CASCADE
+#define DSP_PRE_CASCADE 1
+#endif
 
 // PRE: independent full frames run through the Butterworth prefilter in this kernel (lane-contiguous loads, scan, one LDS
 // transpose into the FFT's sample order) instead of a separate pass that writes a filtered copy to HBM.
-template <bool FULL, bool CLIPS, bool PRE = false>
-__global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args args, const GenTables1024 *__restrict__ G,
+// Two waves per SIMD for every instantiation, stated: VGPRs + AGPRs share one 512-entry file per lane, and left alone hipcc
+// parks spills in AGPRs (a build with 256 VGPRs + 25 AGPRs ran at ONE wave per SIMD: 3.9 ms instead of 2.5 per 1 M config-3
+// frames; SQ_WAVES 1024 instead of 2048 was what gave it away).
+#define DSP_PRE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+// PS0..PS3 (PRE): scan steps of the four cascade sections (cascade_section)
+template <bool FULL, bool CLIPS, bool PRE = false, int PS0 = 6, int PS1 = 6, int PS2 = 6, int PS3 = 6>
+__global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(const Mfcc512Args args, const GenTables1024 *__restrict__ G,
                                                             const PrefilterScan *__restrict__ S = nullptr)
 {
     static_assert(!PRE || (FULL && !CLIPS), "the fused prefilter runs on independent 1024-sample frames");
@@ -146,6 +251,17 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
     float *pbuf = reinterpret_cast<float *>(wl + W_ZBUF);
     float *part = reinterpret_cast<float *>(wl + W_PART);
     float *etile = reinterpret_cast<float *>(wl + W_ETILE);
+
+    float *dcta_lds = reinterpret_cast<float *>(smem + B_DCTA);
+    f4v *melw_lds = reinterpret_cast<f4v *>(smem + B_MELW);
+    (void)melw_lds;
+    for (int i = threadIdx.x; i < kGenDctSteps * 64; i += 256) dcta_lds[i] = (&G->dct_a[0][0])[i];
+    if (PRE)
+        for (int i = threadIdx.x; i < kWaveSlots * 3 * 64; i += 256) {      // row (slot c, quad qd), lane l: taps 4 qd .. 4 qd + 3
+            const int l = i & 63, qd = (i >> 6) % 3, c = i / 192;
+            melw_lds[i] = f4v{G->mel_w[c][4 * qd][l], G->mel_w[c][4 * qd + 1][l], G->mel_w[c][4 * qd + 2][l], G->mel_w[c][4 * qd + 3][l]};
+        }
+    __syncthreads();
 
     // ---- per-lane constants ------------------------------------------------------------------------------------
     float win[16];
@@ -218,7 +334,7 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
         }
     };
 
-    // one cursor, one frame of look-ahead (8 more VGPRs per lane would buy a second one; not needed at 3 waves/SIMD)
+    // one cursor, one frame of look-ahead (a second one was measured in the PRE variant and changes nothing: 2.58 / 2.60 ms)
     WaveCursor<CLIPS> pre;
     pre.init(wave, n_waves, args.chunk, n_frames, args.frames_per_clip, CLIPS ? args.hop : frame_len, args.clip_stride);
     if (!pre.valid()) return;
@@ -250,7 +366,7 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
             float db = 3.01029995663981195f * __builtin_amdgcn_logf(ec * rinv);
             db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f);
             if (4 * s + q >= n_mels) db = 0.0f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(G->dct_a[s][lane], db, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dcta_lds[s * 64 + lane], db, acc, 0, 0, 0);
         };
 #pragma unroll 1
         for (int s = 0; s < kGenDctSteps; s += 2) { kstep(s, acc0); kstep(s + 1, acc1); }
@@ -265,15 +381,40 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
         wave_lds_sync();
     };
 
+    // PRE: an iteration transforms frame k from its filtered samples `ys` (in the lanes' chunk order) and filters frame k + 1 --
+    // after the transform (default), or (DSP_PRE_PIPE = 1, an experiment) in front of it in the same branch-free scheduling region,
+    // in the hope that the scheduler overlaps the two latency-bound chains.  The last iteration filters a frame nobody uses.
+// DSP_PRE_PIPE = 1 was built and measured: hipcc does not interleave the two chains, it only stretches the live ranges (256 VGPRs,
+// 16 spilled): 3.52 ms against 2.43 for the plain order (profiles/r03_config3_ab.txt).  The plain order is the default.
+#ifndef DSP_PRE_PIPE
+#define DSP_PRE_PIPE 0
+#endif
+    float ys[kScanChunk];
+    (void)ys;
+    auto filter_next = [&](float (&out)[kScanChunk]) {
+        float xs[kScanChunk];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) { xs[2 * a] = nxt[a].x; xs[2 * a + 1] = nxt[a].y; }
+#if DSP_PRE_CASCADE
+        prefilter_cascade<PS0, PS1, PS2, PS3>(xs, out, S, lane);
+#else
+        prefilter_scan(xs, out, S, lane);
+#endif
+    };
+    long f_cur = f_next;
+    if (PRE) {                      // prologue: frame 0 filtered, frame 1 in flight
+        filter_next(ys);
+        if (pre.valid()) { f_next = pre.f; load_frame8(pre.off, nxt); pre.next(); } else f_next = -1;
+    }
+
     while (true) {
-        const long f = f_next;
+        const long f = PRE ? f_cur : f_next;
         c32 v[8];
         if (SCH) __builtin_amdgcn_s_setprio(0);
+        bool more;
+        float ys_next[kScanChunk];
+        (void)ys_next;
         if (PRE) {
-            float xs[kScanChunk], ys[kScanChunk];
-#pragma unroll
-            for (int a = 0; a < 8; ++a) { xs[2 * a] = nxt[a].x; xs[2 * a + 1] = nxt[a].y; }
-            prefilter_scan(xs, ys, S, lane);
             // filtered samples into the FFT's order: lane l takes the pairs (2 (l + 64 a), 2 (l + 64 a) + 1)
             float *yb = reinterpret_cast<float *>(zbuf);
 #pragma unroll
@@ -285,12 +426,18 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
                 v[a] = {q.x * win[2 * a], q.y * win[2 * a + 1]};
             }
             wave_lds_sync();
+            // the next frame: its samples are in `nxt` (or nothing is left: then what `nxt` still holds is filtered for nobody);
+            // the frame after it starts loading behind the filter's reads of `nxt`
+            more = f_next >= 0;
+            f_cur = f_next;
+            if (DSP_PRE_PIPE) filter_next(ys_next);
+            if (DSP_PRE_PIPE) { if (pre.valid()) { f_next = pre.f; load_frame8(pre.off, nxt); pre.next(); } else f_next = -1; }
         } else {
 #pragma unroll
             for (int a = 0; a < 8; ++a) v[a] = {nxt[a].x * win[2 * a], nxt[a].y * win[2 * a + 1]};
+            more = pre.valid();
+            if (more) { f_next = pre.f; load_frame8(pre.off, nxt); pre.next(); }
         }
-        const bool more = pre.valid();
-        if (more) { f_next = pre.f; load_frame8(pre.off, nxt); pre.next(); }
 
         // ---- stage A: radix-8 over a, twiddle W512^(l q) -----------------------------------------------------------
         if (SCH == 3) __builtin_amdgcn_s_setprio(1);
@@ -365,13 +512,22 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
 
         // ---- sparse mel: two chunk slots per lane, weights in registers ---------------------------------------------
         int wl_lane = lane;
-        if (PRE) asm volatile("" : "+v"(wl_lane));       // opaque per frame: the weight loads stay in the loop (not hoisted back into registers)
+        if (PRE) asm volatile("" : "+v"(wl_lane));       // opaque per frame: the weight reads stay in the loop (not hoisted back into registers)
 #pragma unroll
         for (int c = 0; c < kWaveSlots; ++c) {
             const float *rd = pbuf + mel_k0[c];
             float acc = 0.0f;
+            if (PRE) {
 #pragma unroll
-            for (int i = 0; i < kMelChunk; ++i) acc = fmaf(PRE ? G->mel_w[c][i][wl_lane] : melw[c][i], rd[i], acc);
+                for (int qd = 0; qd < 3; ++qd) {
+                    const f4v w = melw_lds[(c * 3 + qd) * 64 + wl_lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = fmaf(w[j], rd[4 * qd + j], acc);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kMelChunk; ++i) acc = fmaf(melw[c][i], rd[i], acc);
+            }
             part[c * 64 + lane] = acc;
         }
         wave_lds_sync();
@@ -388,18 +544,35 @@ __global__ __launch_bounds__(256) void mfcc1024_wave_kernel(const Mfcc512Args ar
         if (++slot == 16 || !more) { flush(slot); slot = 0; }
         else wave_lds_sync();
         if (!more) return;
+        if (PRE) {
+            if (!DSP_PRE_PIPE) {        // not pipelined: the next frame is filtered here, after this one's transform
+                filter_next(ys_next);
+                if (pre.valid()) { f_next = pre.f; load_frame8(pre.off, nxt); pre.next(); } else f_next = -1;
+            }
+#pragma unroll
+            for (int i = 0; i < kScanChunk; ++i) ys[i] = ys_next[i];
+        }
     }
 }
 
-hipError_t launch_mfcc1024_wave(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream, const PrefilterScan *scan)
+hipError_t launch_mfcc1024_wave(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream, const PrefilterScan *scan,
+                                const int *scan_steps)
 {
     const bool full = args.frame_len == 1024, clips = args.frames_per_clip > 0;
     if (args.chunk % 8 != 0) return hipErrorInvalidConfiguration;
-    const size_t lds = (size_t)4 * W_WAVE_BYTES;
+    const size_t lds = B_BYTES_PLAIN;
     const dim3 g(blocks), b(256);
     if (scan) {
         if (!full || clips || (reinterpret_cast<uintptr_t>(args.in) & 15)) return hipErrorInvalidConfiguration;
-        hipLaunchKernelGGL((mfcc1024_wave_kernel<true, false, true>), g, b, lds, stream, args, tables, scan);
+        // the scan-step counts are compile-time: one instantiation per literal filter (donut-classifier/classifier.c:342-401), a
+        // generic one (six steps everywhere) for anything else
+        const int *st = scan_steps;
+        if (st && st[0] <= 1 && st[1] <= 3 && st[2] <= 3 && st[3] <= 5)
+            hipLaunchKernelGGL((mfcc1024_wave_kernel<true, false, true, 1, 3, 3, 5>), g, b, (size_t)B_BYTES_PRE, stream, args, tables, scan);
+        else if (st && st[0] <= 2 && st[1] <= 3 && st[2] <= 3 && st[3] <= 4)
+            hipLaunchKernelGGL((mfcc1024_wave_kernel<true, false, true, 2, 3, 3, 4>), g, b, (size_t)B_BYTES_PRE, stream, args, tables, scan);
+        else
+            hipLaunchKernelGGL((mfcc1024_wave_kernel<true, false, true>), g, b, (size_t)B_BYTES_PRE, stream, args, tables, scan);
         return hipGetLastError();
     }
     const PrefilterScan *none = nullptr;
@@ -413,9 +586,9 @@ hipError_t launch_mfcc1024_wave(const Mfcc512Args &args, const GenTables1024 *ta
 int mfcc1024_wave_blocks_per_cu(bool full, bool prefilter)
 {
     int n = 0;
-    const size_t lds = (size_t)4 * W_WAVE_BYTES;
+    const size_t lds = B_BYTES_PLAIN;
     if (prefilter) {
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc1024_wave_kernel<true, false, true>, 256, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc1024_wave_kernel<true, false, true>, 256, (size_t)B_BYTES_PRE);
         return e == hipSuccess && n > 0 ? n : 1;
     }
     hipError_t e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc1024_wave_kernel<true, false>, 256, lds)

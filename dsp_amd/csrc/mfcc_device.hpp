@@ -129,7 +129,8 @@ constexpr int LDS_PART = 2048 + 64;         // 65 partial sums (+ zero slot)
 constexpr int LDS_LOGMEL = LDS_PART + 320;  // up to 80 log-mel values
 constexpr int LDS_WAVE_BYTES = LDS_LOGMEL + 320;
 constexpr int LDS_TILE_BYTES = 64 * 16 * 4;   // mel energies of 16 frames, E[mel][frame ^ (mel>>2)]
-constexpr int LDS_POOL_BYTES = 32 * 16;       // POOL: (sum, sum of squares) in double for up to 32 coefficients
+constexpr int LDS_POOL_BYTES = 32 * 16;       // POOL 1: (sum, sum of squares) in double for up to 32 coefficients
+constexpr int LDS_STOP_BYTES = 64 * kStopFusedUnits * 8;    // POOL 2: float64 layer-1 partial sums per lane (stop-word net)
 static_assert(LDS_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
 // wave-uniform cursor over the frames this wave owns: chunks of `chunk`
 // consecutive frames dealt round-robin to the waves of the grid, so one wave's

@@ -28,6 +28,8 @@
 // contractions.  The bound is HBM (2048 B in + 52 B out per frame).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "mfcc_device.hpp"
 
 // Timing-only diagnostic builds (never shipped), -DDSP_DIAG_MODE=<bit mask>:
@@ -157,7 +159,8 @@ __device__ __forceinline__ c32 unpack_pcm16(c32 raw)
 // Saves ~45 of ~225 VALU issue slots and 10 LDS dwords per frame.
 // POOL (TILE, CLIPS, chunk = frames per clip: one wavefront walks one clip): instead of storing the coefficients the
 // tile epilogue pools them per clip and the clip ends with the SVM (PoolSvmArgs) -- BASELINE config 5 in one kernel.
-template <int DCT_SPLIT, int DCT_LEN, int GATHER, int FLEN, int IN, int TILE, bool CLIPS, bool POOL = false>
+// POOL = 2: the epilogue feeds the stop-word net instead (StopNetArgs): classify_signal (stop_detector.c:12-55) in one kernel.
+template <int DCT_SPLIT, int DCT_LEN, int GATHER, int FLEN, int IN, int TILE, bool CLIPS, int POOL = 0>
 #ifndef DSP_WAVES_PER_EU
 #define DSP_WAVES_PER_EU 4
 #endif
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
     static_assert(!POOL || (TILE && CLIPS), "pooling lives in the tile epilogue of the clip-mode kernel");
     constexpr int KS = DCT_SPLIT == 2 ? DCT_LEN / 2 : DCT_LEN;    // MFMA k-steps (4 mel filters each)
     constexpr int CT = DCT_SPLIT == 2 ? 2 : 1;                    // 16-coefficient output tiles
-    constexpr int WAVE_BYTES = LDS_WAVE_BYTES + (TILE ? LDS_TILE_BYTES : 0) + (POOL ? LDS_POOL_BYTES : 0);
+    constexpr int WAVE_BYTES = LDS_WAVE_BYTES + (TILE ? LDS_TILE_BYTES : 0) + (POOL == 1 ? LDS_POOL_BYTES : (POOL == 2 ? LDS_STOP_BYTES : 0));
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -282,7 +285,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 
     // ---- POOL: per-clip running sums of lane c's coefficient (float64, frames in order), the clip's end -------------
     int pool_t = 0;
-    if (POOL && lane < 32) { pool_acc[2 * lane] = 0.0; pool_acc[2 * lane + 1] = 0.0; }
+    if (POOL == 1 && lane < 32) { pool_acc[2 * lane] = 0.0; pool_acc[2 * lane + 1] = 0.0; }
+    // POOL = 2: layers 2-4 of the net (<= 16 x 16 weights + 16 biases each) in a block-shared LDS copy: the clip's tail runs on one
+    // lane, and a dependent chain of global loads there would cost tens of microseconds per clip
+    float *stop_small = reinterpret_cast<float *>(smem + 4 * WAVE_BYTES) + (TILE && !A_IN_REGS ? CT * KS * 64 : 0);
+    (void)stop_small;
+    if (POOL == 2) {
+#pragma unroll
+        for (int j = 0; j < kStopFusedUnits; ++j) pool_acc[kStopFusedUnits * lane + j] = 0.0;
+        const StopModelDev &m = args.stop.m;
+        int n_in = m.units[0], off = 0;
+        for (int l = 1; l < 4; ++l) {                          // packed: weights of layer l, then its biases
+            const int n_w = n_in * m.units[l];
+            for (int i = threadIdx.x; i < n_w; i += 256) stop_small[off + i] = m.kernel[l][i];
+            for (int i = threadIdx.x; i < m.units[l]; i += 256) stop_small[off + n_w + i] = m.bias[l][i];
+            off += n_w + m.units[l];
+            n_in = m.units[l];
+        }
+        __syncthreads();
+    }
     auto pool_tile = [&](const f4v (&d)[CT], int count) {
         // coefficients of the tile -> LDS as Dt[c][n] (the mel-energy tile has been consumed), then lane c adds its
         // row frame by frame: the same order of float64 additions as mfcc_stats (svm_kernels.hip / scrubjay_infer.c:36-66)
@@ -352,7 +373,92 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         pool_t = 0;
         wave_lds_sync();
     };
-    (void)pool_tile; (void)pool_finish; (void)pool_t;
+    // ---- POOL = 2: the stop-word net's first layer accumulated tile by tile (audio_classifier_inference.c:18-36, 44-47) ----
+    // lane (c = lane % 16, tq = lane / 16) takes coefficient c of the tile's frames 4 tq .. 4 tq + 3 -- input index
+    // i = c * max_frames + t, the coefficient-major view of stop_detector.c:36-50.  The scaler is folded into the weights at model
+    // creation, w (x - mean) / div = x A + B (StopModelDev::fold_a, pad_b): ONE 16-byte load and four float64 FMAs per input, no
+    // division in the loop; the B terms of the live inputs are a per-T constant added at the end.  float64 sums: their order
+    // shows at 1e-16; the folding moves a term by <= 1e-7 relative (the reference itself adds 6500 fp32 terms in sequence).
+    auto stop_tile = [&](const f4v (&d)[CT], int count) {
+        const StopModelDev &m = args.stop.m;
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        const int n = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) etile[(4 * q + j) * 16 + n] = d[0][j];       // Dt[c][n], one coefficient tile
+        wave_lds_sync();
+        const int c = lane & 15, tq = lane >> 4;
+        const bool live_c = c < m.n_coef;
+        const f4v *A = reinterpret_cast<const f4v *>(m.fold_a);
+        double acc[kStopFusedUnits];
+#pragma unroll
+        for (int j = 0; j < kStopFusedUnits; ++j) acc[j] = pool_acc[kStopFusedUnits * lane + j];
+#pragma unroll 1
+        for (int k0 = 0; k0 < 4; k0 += 2) {                                    // two inputs at a time: their loads go out together; four at once spill
+            f4v a[2];
+            float x[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int tt = 4 * tq + k0 + k, t = pool_t + tt;
+                const bool on = live_c && tt < count && t < m.max_frames;      // stop_detector.c:26-30: frames past max_frames are dropped
+                a[k] = A[on ? c * m.max_frames + t : 0];
+                x[k] = on ? etile[c * 16 + tt] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double xd = (double)x[k];
+#pragma unroll
+                for (int j = 0; j < kStopFusedUnits; ++j) acc[j] = fma((double)a[k][j], xd, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kStopFusedUnits; ++j) pool_acc[kStopFusedUnits * lane + j] = acc[j];
+        pool_t += count;
+        wave_lds_sync();
+    };
+    auto stop_finish = [&](long clip) {
+#pragma clang fp contract(off)
+        const StopModelDev &m = args.stop.m;
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
+        double acc[kStopFusedUnits];
+#pragma unroll
+        for (int j = 0; j < kStopFusedUnits; ++j) {
+            acc[j] = pool_acc[kStopFusedUnits * lane + j];
+            pool_acc[kStopFusedUnits * lane + j] = 0.0;
+            for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+        }
+        if (lane == 0) {
+            // layers 1 (bias + zero-padded frames + live sums) .. 4 and the sigmoid, as stop_tail_kernel
+            const int u1 = m.units[0];
+            const int Tc = pool_t < m.max_frames ? pool_t : m.max_frames;
+            float *h = etile;                                                    // two rows of kStopMaxUnits activations (the tile is free here)
+#pragma unroll
+            for (int j = 0; j < kStopFusedUnits; ++j)
+                if (j < u1) {
+                    const float sum = (float)((double)m.bias[0][j] + m.pad_b[(long)Tc * u1 + j] + acc[j]);
+                    h[j] = sum > 0.0f ? sum : 0.0f;
+                }
+            int n_in = u1, off = 0;
+            for (int l = 1; l < 4; ++l) {                                        // dense_forward, :18-35
+                const int n_out = m.units[l];
+                const float *src = h + ((l - 1) & 1) * kStopMaxUnits;
+                float *dst = h + (l & 1) * kStopMaxUnits;
+                const float *wl_ = stop_small + off, *bl_ = wl_ + n_in * n_out;
+                off += n_in * n_out + n_out;
+                for (int j = 0; j < n_out; ++j) {
+                    float sum = bl_[j];
+                    for (int i = 0; i < n_in; ++i) sum = sum + wl_[i * n_out + j] * src[i];
+                    dst[j] = (l < 3 && !(sum > 0.0f)) ? 0.0f : sum;
+                }
+                n_in = n_out;
+            }
+            args.stop.prob[clip] = 1.0f / (1.0f + expf(-h[kStopMaxUnits]));     // :13-15 (layer 4's output sits in row 1)
+        }
+        pool_t = 0;
+        wave_lds_sync();
+    };
+    (void)pool_tile; (void)pool_finish; (void)pool_t; (void)stop_tile; (void)stop_finish;
 
     // ---- 16-frame tile epilogue (TILE): log + DCT for the frames in slots [0, count) ----
     int slot = 0;               // frames in the tile
@@ -413,7 +519,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) dd[ct] = acc[ct][0] + acc[ct][1];
             wave_lds_sync();                                 // every lane has read its tile column
-            pool_tile(dd, count);
+            if (POOL == 2) { if constexpr (CT == 1) stop_tile(dd, count); }
+            else pool_tile(dd, count);
             return;
         }
         const long fl = (n < 8 ? fb0 : fb1 - 8) + n;
@@ -594,7 +701,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
             etile[16 * lane + (slot ^ (lane >> 2))] = e;
             const bool clip_ends = POOL && last_f;
             if (++slot == 16 || !more || clip_ends) { flush(slot); slot = 0; }
-            if (clip_ends) pool_finish(clip_f);
+            if (clip_ends) { if (POOL == 2) stop_finish(clip_f); else pool_finish(clip_f); }
             return more;
         }
 
@@ -667,10 +774,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 
 // S, L: DCT_SPLIT, DCT_LEN of the instantiation (shapes whose MFMA A operand does not fit registers keep it in LDS)
 template <int S, int L>
-static size_t lds_bytes(bool tile, bool pool = false)
+static size_t lds_bytes(bool tile, int pool = 0, int stop_small_floats = 0)
 {
     constexpr int KS = S == 2 ? L / 2 : L, CT = S == 2 ? 2 : 1;
-    return (size_t)4 * (LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0) + (pool ? LDS_POOL_BYTES : 0)) + (tile && (CT * KS > 10 || pool) ? (size_t)CT * KS * 64 * 4 : 0);
+    return (size_t)4 * (LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0) + (pool == 1 ? LDS_POOL_BYTES : (pool == 2 ? LDS_STOP_BYTES : 0))) +
+           (tile && (CT * KS > 10 || pool) ? (size_t)CT * KS * 64 * 4 : 0) + (pool == 2 ? (size_t)((stop_small_floats + 3) & ~3) * 4 : 0);
+}
+
+static int stop_small_floats(const StopModelDev &m)
+{
+    int n = 0;
+    for (int l = 1; l < 4; ++l) n += m.units[l - 1] * m.units[l] + m.units[l];
+    return n;
 }
 
 template <int S, int L, int G>
@@ -707,17 +822,43 @@ hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_l
     const dim3 g(blocks), b(256);
 #define DSP_LAUNCH_POOL(S, L, G)                                                                                            \
     if (dct_split == S && dct_len == L && gather == G) {                                                                    \
-        const size_t lds = lds_bytes<S, L>(true, true);                                                                     \
+        const size_t lds = lds_bytes<S, L>(true, 1);                                                                        \
         const int flen = flen_of<S, L, G>(args.frame_len);                                                                  \
-        if (flen == 512) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 512, 0, 1, true, true>), g, b, lds, stream, args); \
+        if (flen == 512) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 512, 0, 1, true, 1>), g, b, lds, stream, args);   \
         else if (flen == 400) {                                                                                             \
-            if constexpr (kHas400<S, L, G>) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 400, 0, 1, true, true>), g, b, lds, stream, args); \
-        } else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 0, 0, 1, true, true>), g, b, lds, stream, args);          \
+            if constexpr (kHas400<S, L, G>) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 400, 0, 1, true, 1>), g, b, lds, stream, args); \
+        } else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 0, 0, 1, true, 1>), g, b, lds, stream, args);             \
         return hipGetLastError();                                                                                           \
     }
     DSP_FOR_SHAPES(DSP_LAUNCH_POOL)
 #undef DSP_LAUNCH_POOL
     return hipErrorInvalidConfiguration;
+}
+
+// classify_signal fused (POOL = 2): the reference's shape only (13 coefficients of 40 mel energies: DCT_SPLIT 4, DCT_LEN 10)
+hipError_t launch_mfcc512_stop(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream)
+{
+    const StopModelDev &m = args.stop.m;
+    if (args.frames_per_clip <= 0 || args.chunk != args.frames_per_clip || args.log_mode != 0 || args.in_kind != 0 || !args.stop.prob ||
+        dct_split != 4 || dct_len != 10 || m.n_coef != args.n_mfcc || m.n_coef > 16 || m.units[0] < 1 || m.units[0] > kStopFusedUnits ||
+        !m.fold_a || !m.pad_b)
+        return hipErrorInvalidConfiguration;
+    for (int l = 1; l < 4; ++l)
+        if (m.units[l] < 1 || m.units[l] > kStopMaxUnits) return hipErrorInvalidConfiguration;
+    const size_t lds = lds_bytes<4, 10>(true, 2, stop_small_floats(m));
+    // persistent-style grid: the blocks the chip really holds with this variant's LDS (the caller's count is the plain kernel's)
+    auto launch = [&](auto kernel) {
+        int per_cu = 0, dev = 0, n_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0)
+            blocks = std::min(blocks, per_cu * n_cu);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, stream, args);
+    };
+    if (gather == 3 && args.frame_len == 400) launch(mfcc512_wave_kernel<4, 10, 3, 400, 0, 1, true, 2>);
+    else if (gather == 3) launch(mfcc512_wave_kernel<4, 10, 3, 0, 0, 1, true, 2>);
+    else if (gather == 6) launch(mfcc512_wave_kernel<4, 10, 6, 0, 0, 1, true, 2>);
+    else return hipErrorInvalidConfiguration;
+    return hipGetLastError();
 }
 
 hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks,

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "consumer_kernels.hpp"
 #include "svm_kernels.hpp"
 #include "tables.hpp"
 
@@ -17,6 +18,14 @@ struct PoolSvmArgs {
     float *decision;       // [n_clips] or nullptr
     float *prob1;          // [n_clips] or nullptr
     float *feat;           // [n_clips][2 * n_mfcc] or nullptr
+};
+
+// classify_signal in ONE kernel (2fa/audio/word/c/stop_detector.c:12-55): the tile epilogue standardises its
+// 16 x 13 coefficients and adds their layer-1 products (audio_classifier_inference.c:18-36, 44-47) to float64 partial sums,
+// the clip ends with layers 2-4 and the sigmoid -- the MFCC matrix never reaches HBM.
+struct StopNetArgs {
+    StopModelDev m;        // units[0] <= kStopFusedUnits, n_coef = n_mfcc <= 16
+    float *prob;           // [n_clips]
 };
 
 struct Mfcc512Args {
@@ -46,6 +55,7 @@ struct Mfcc512Args {
     float *frame_max;
     const float *clip_floor;
     PoolSvmArgs pool;              // only read by the POOL instantiations (launch_mfcc512_pool)
+    StopNetArgs stop{};            // only read by the stop-net instantiations (launch_mfcc512_stop)
 };
 
 // clip_floor[c] = max_t frame_max[c][t] - top_db
@@ -57,6 +67,8 @@ hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, i
                           hipStream_t stream, bool tile);
 // fused clip -> label path: args.chunk must equal args.frames_per_clip, args.out is not written
 hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream);
+// fused clip -> stop-word probability (reference shape only: 13 coefficients, 40 mel): args.chunk == args.frames_per_clip, args.stop set
+hipError_t launch_mfcc512_stop(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream);
 hipError_t launch_mfcc512_row(const Mfcc512Args &args, const RowTables512 *row_tables, int dct_split, int dct_len,
                               int gather, int blocks, hipStream_t stream);
 int mfcc512_row_blocks_per_cu(int dct_split, int dct_len, int gather, bool full);
@@ -65,8 +77,9 @@ int mfcc1024_blocks_per_cu(bool full);
 // register-resident wave-per-frame form (mfcc1024_wave_kernel.hip): tables->n_chunk_slots <= 3, chunk % 8 == 0
 struct PrefilterScan;   // tables.hpp
 // scan != nullptr: independent 1024-sample frames are band-pass filtered (PrefilterScan, tables.hpp) inside the kernel
+// scan_steps (host copy of PrefilterScan::c_steps, with scan): picks the instantiation whose compile-time step counts cover them
 hipError_t launch_mfcc1024_wave(const Mfcc512Args &args, const GenTables1024 *tables, int blocks, hipStream_t stream,
-                                const PrefilterScan *scan = nullptr);
+                                const PrefilterScan *scan = nullptr, const int *scan_steps = nullptr);
 int mfcc1024_wave_blocks_per_cu(bool full, bool prefilter = false);
 int mfcc512_lds_bytes_per_block(bool tile);
 // n_fft = 2048 (mfcc2048_kernel.hip); pool: the fused clip -> label form (args.chunk == args.frames_per_clip, args.pool set)

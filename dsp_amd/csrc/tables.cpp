@@ -295,6 +295,61 @@ bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &o
     double err = 0, top = 0;
     for (int n = 0; n < 1024; ++n) { err = std::max(err, std::fabs(y[n] - yref[n])); top = std::max(top, std::fabs(yref[n])); }
     if (!(err <= 1e-10 * top)) { why = "prefilter: the parallel form does not reproduce the direct form"; return false; }
+
+    // ---- cascade form (see tables.hpp) ---------------------------------------------------------------------------------
+    out.c_ok = 0;
+    {
+        const double g = b[0], pat[9] = {1, 0, -4, 0, 6, 0, -4, 0, 1};
+        bool binom = g != 0.0;
+        for (int k = 0; k < 9 && binom; ++k) binom = std::fabs(b[k] - g * pat[k]) <= 1e-12 * std::fabs(g);
+        if (binom) {
+            int order[4] = {0, 1, 2, 3};
+            std::sort(order, order + 4, [&](int p, int q) { return out.a2[p] < out.a2[q]; });       // a2 = |pole|^2
+            out.c_gain = g;
+            for (int s = 0; s < 4; ++s) {
+                const int src = order[s];
+                out.c_a1[s] = out.a1[src]; out.c_a2[s] = out.a2[src];
+                out.c_a1f[s] = (float)out.a1[src]; out.c_a2f[s] = (float)out.a2[src];
+                const double radius = std::sqrt(out.a2[src]), tol = s < 2 ? 1e-13 : 1e-9;
+                int D = 0;
+                while (D < 6 && std::pow(radius, 16.0 * (double)(1 << D)) >= tol) ++D;
+                out.c_steps[s] = D;
+                for (int d = 0; d < 6; ++d)
+                    for (int k = 0; k < 4; ++k) { out.c_pw[d][s][k] = out.pw[d][src][k]; out.c_pwf[d][s][k] = (float)out.pw[d][src][k]; }
+            }
+            // self-check of the cascade's algebra (all four sections in double, the kernel's lane structure) against the direct form
+            double u[1024];
+            for (int n = 0; n < 1024; ++n) u[n] = x[n];
+            for (int s = 0; s < 4; ++s) {
+                double T[64][2], v[1024];
+                for (int l = 0; l < 64; ++l) {
+                    double w1 = 0, w2 = 0;
+                    for (int i = 0; i < kScanChunk; ++i) { const double w0 = u[16 * l + i] - out.c_a1[s] * w1 - out.c_a2[s] * w2; w2 = w1; w1 = w0; }
+                    T[l][0] = w1; T[l][1] = w2;
+                }
+                for (int d = 0; d < out.c_steps[s]; ++d) {
+                    const double *m = out.c_pw[d][s];
+                    for (int l = 63; l >= (1 << d); --l) {
+                        const double u0 = T[l - (1 << d)][0], u1 = T[l - (1 << d)][1];
+                        T[l][0] += m[0] * u0 + m[1] * u1;
+                        T[l][1] += m[2] * u0 + m[3] * u1;
+                    }
+                }
+                for (int l = 0; l < 64; ++l) {
+                    double w1 = l ? T[l - 1][0] : 0.0, w2 = l ? T[l - 1][1] : 0.0;
+                    for (int i = 0; i < kScanChunk; ++i) {
+                        const double w0 = u[16 * l + i] - out.c_a1[s] * w1 - out.c_a2[s] * w2;
+                        v[16 * l + i] = w0 - w2;
+                        w2 = w1; w1 = w0;
+                    }
+                }
+                for (int n = 0; n < 1024; ++n) u[n] = v[n];
+            }
+            double cerr = 0;
+            for (int n = 0; n < 1024; ++n) cerr = std::max(cerr, std::fabs(g * u[n] - yref[n]));
+            out.c_ok = cerr <= 1e-9 * top ? 1 : 0;      // float64 scan steps stop at 1e-13 of the state: 1e-9 leaves room, a wrong table misses by orders
+        }
+    }
     return true;
 }
 

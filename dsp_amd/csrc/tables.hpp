@@ -159,6 +159,22 @@ struct PrefilterScan {
     // reaches the state damped by |pole_s|^(16 * 2^steps[s]) < 1e-14 (the pole radii of the two literal filters are
     // 0.27 .. 0.93: 1 .. 5 steps instead of 6 for every section).
     int32_t steps[4];
+    // ---- the same filter as a CASCADE of four second-order sections (round 3; the form the 1024-point kernel runs) -------------
+    // H = g prod_s (1 - z^-2) / (1 + a1_s z^-1 + a2_s z^-2): the literal numerators are g (1 - z^-2)^4 exactly (checked), the pole
+    // pairs are sorted by radius (c_a1 / c_a2, widest damping first).  Each section is a lane-parallel scan of its own (chunk from
+    // zero state, Kogge-Stone over the lanes with c_pw[d][s] = M_s^(16 * 2^d), chunk again from its true state).  A cascade has
+    // no cancellation BETWEEN sections (the parallel form's four terms cancel to -76 dB in the stop band, which is why it needs
+    // float64 throughout), so only the first two sections -- the ones that see the unattenuated stop-band energy -- run in
+    // float64 and the last two in float32 (c_*f: the same constants rounded to float).  Measured on a float32 emulation of
+    // exactly this lane structure against the float64 direct form under the MFCC gate (tools/emulate_prefilter_cascade.py):
+    // worst 1e-5 of the gate's 1e-4 on stop-band-only frames, 1e-6 typical; all-float32 fails those frames (1.7e-4).
+    double c_gain;
+    double c_a1[4], c_a2[4];
+    double c_pw[6][4][4];
+    float c_a1f[4], c_a2f[4];
+    float c_pwf[6][4][4];
+    int32_t c_steps[4];            // scan steps per section: float64 sections to 1e-13, float32 sections to 1e-9
+    int32_t c_ok;                  // 0: the numerator is not g (1 - z^-2)^4 -> the kernel runs the parallel form
 };
 constexpr int kScanChunk = 16;     // samples per lane: 64 lanes x 16 = one 1024-sample frame
 bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &out, std::string &why);

@@ -82,7 +82,8 @@ def test_lengths_sub_batches_and_the_device_entry_point(dsp):
     labels = dsp.classify_batch_f64(clips)
     for i in (0, 1, 6, 7, 2047, 2048, 2093, 2099):
         assert labels[i] == O.classify_f64(clips[i])[0], i
-    assert labels[::7].all() and not labels[1::7].any()
+    assert not labels[1::7].any() and labels[::7].sum() >= 290
+    assert labels[::7].tolist() == [O.classify_f64(c)[0] for c in clips[::7]]     # every clip with the call (one of the 300 misses the rule)
     dl = dsp.classify_device_f64(torch.from_numpy(clips).cuda())
     assert np.array_equal(dl.cpu().numpy(), labels)
     # a strided device batch (rows padded): same labels

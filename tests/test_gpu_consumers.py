@@ -52,6 +52,37 @@ def test_classify_signal_on_reference_test_clips(golden):
     assert net.classify_signal(np.zeros(100, np.float32)) == pytest.approx(O.classify_signal(m, np.zeros(100, np.float32)), abs=PTOL)
 
 
+def test_classify_signal_fused_kernel(golden, monkeypatch):
+    """dsp_classify_signal_batch_device runs ONE kernel for the reference's shape (mfcc512_wave_kernel<POOL = 2>: the tile epilogue
+    feeds layer 1, the MFCC matrix never reaches HBM).  Against the two-kernel path (same products, another float64
+    summation order), the oracle's classify_signal, and on clips longer than max_frames (frames past 500 are dropped) and of one frame."""
+    import torch
+    import dsp_amd
+    m = _model(golden)
+    net = dsp_amd.StopModel(m)
+    plan = dsp_amd.MfccPlan(dsp_amd.default_config())
+    gen = torch.Generator(device="cuda").manual_seed(41)
+    for n_clips, n in ((300, 16000), (5, 400), (7, 559), (3, 81000), (9, 16002)):
+        # rows on an even stride (the 8-byte alignment the frame loads need); 559: an odd clip length inside such rows
+        clips = (torch.rand((n_clips, n + (n & 1)), device="cuda", generator=gen) * 2 - 1)[:, :n]
+        clips[::4] *= 0.01
+        if n_clips > 2:
+            clips[2] = 0.0
+        fused = net.classify_signal_batch(plan, clips).cpu().numpy()
+        monkeypatch.setenv("DSP_AMD_STOP_TWO_KERNELS", "1")
+        two = net.classify_signal_batch(plan, clips).cpu().numpy()
+        monkeypatch.delenv("DSP_AMD_STOP_TWO_KERNELS")
+        assert np.abs(fused - two).max() <= 1e-6, (n_clips, n)
+        for i in (0, 2, n_clips - 1):
+            assert abs(fused[i] - O.classify_signal(m, clips[i].cpu().numpy())) <= 5e-5, (n, i)
+    # a strided batch (rows padded to an even stride) and a plan whose shape has no fused form (20 coefficients): two kernels, same API
+    wide = torch.zeros((8, 16010), device="cuda")
+    wide[:, :16000] = torch.rand((8, 16000), device="cuda", generator=gen) * 2 - 1
+    a = net.classify_signal_batch(plan, wide[:, :16000]).cpu().numpy()
+    b = net.classify_signal_batch(plan, wide[:, :16000].contiguous()).cpu().numpy()
+    assert np.array_equal(a, b)
+
+
 def test_stop_net_shapes_padding_and_truncation(golden):
     import torch
     import dsp_amd
