@@ -50,10 +50,19 @@ constexpr int kWaveZero = 192;                      // partial slot that always 
 //   PRE only: the mel weights (3 slots x 12 taps x 64 lanes) as float4 rows [slot][quad][lane] -- the PRE variant has no registers
 //   for them, and 36 dword re-reads per frame from L1 made the kernel's speed hang on how many of them hipcc kept in flight
 //   (2.58 .. 3.64 ms per 1 M frames between builds that differed in nothing else).
-constexpr int B_DCTA = 4 * W_WAVE_BYTES;
-constexpr int B_MELW = B_DCTA + kGenDctSteps * 64 * 4;
-constexpr int B_BYTES_PLAIN = B_MELW;
-constexpr int B_BYTES_PRE = B_MELW + kWaveSlots * kMelChunk * 64 * 4;
+// DSP_PRE_W3 = 1 (PRE variant, an experiment): THREE waves per SIMD -- <= 168 VGPRs (mel gather slots and window starts packed
+// into three registers, the window folded into the prefilter's output gain from a chunk-order table instead of living in 16
+// registers: still 14 spilled) and three blocks' LDS per CU (8-frame tiles: the MFMA epilogue then runs half empty, twice as
+// often).  Measured 2.55 ms against 2.44 at two waves (profiles/r03_config3_ab.txt): not adopted.
+#ifndef DSP_PRE_W3
+#define DSP_PRE_W3 0
+#endif
+constexpr int W_WAVE_BYTES_T8 = W_ETILE + 128 * 8 * 4;
+constexpr int wave_bytes(bool t8) { return t8 ? W_WAVE_BYTES_T8 : W_WAVE_BYTES; }
+constexpr int b_dcta(bool t8) { return 4 * wave_bytes(t8); }
+constexpr int b_melw(bool t8) { return b_dcta(t8) + kGenDctSteps * 64 * 4; }
+constexpr int B_BYTES_PLAIN = b_melw(false);
+constexpr int B_BYTES_PRE = b_melw(DSP_PRE_W3 != 0) + kWaveSlots * kMelChunk * 64 * 4;
 
 // forward radix-8 butterfly: u[q] = sum_a v[a] W8^(a q)
 __device__ __forceinline__ void radix8w(c32 (&v)[8])
@@ -201,8 +210,10 @@ __device__ __forceinline__ void cascade_section(T (&u)[kScanChunk], T a1, T a2, 
 #ifndef DSP_PRE_DIAG
 #define DSP_PRE_DIAG 0
 #endif
+// wc != nullptr: the lane's 16 window values in chunk order (GenTables1024::win_chunk), multiplied into the output here
 template <int S0, int S1, int S2, int S3>
-__device__ __forceinline__ void prefilter_cascade(const float (&x)[kScanChunk], float (&y)[kScanChunk], const PrefilterScan *__restrict__ S, int lane)
+__device__ __forceinline__ void prefilter_cascade(const float (&x)[kScanChunk], float (&y)[kScanChunk], const PrefilterScan *__restrict__ S, int lane,
+                                                  const float *__restrict__ wc = nullptr)
 {
 #if DSP_PRE_DIAG == 1
     for (int i = 0; i < kScanChunk; ++i) y[i] = x[i];
@@ -219,8 +230,16 @@ __device__ __forceinline__ void prefilter_cascade(const float (&x)[kScanChunk], 
     cascade_section<float, S2>(uf, S->c_a1f[2], S->c_a2f[2], S->c_pwf, 2, lane);
     cascade_section<float, S3>(uf, S->c_a1f[3], S->c_a2f[3], S->c_pwf, 3, lane);
     const float g = (float)S->c_gain;
+    if (wc) {
+        f4v w4[4];
 #pragma unroll
-    for (int i = 0; i < kScanChunk; ++i) y[i] = uf[i] * g;
+        for (int a = 0; a < 4; ++a) w4[a] = reinterpret_cast<const f4v *>(wc)[a];
+#pragma unroll
+        for (int i = 0; i < kScanChunk; ++i) y[i] = (uf[i] * g) * w4[i >> 2][i & 3];
+    } else {
+#pragma unroll
+        for (int i = 0; i < kScanChunk; ++i) y[i] = uf[i] * g;
+    }
 }
 
 }  // namespace
@@ -235,7 +254,7 @@ __device__ __forceinline__ void prefilter_cascade(const float (&x)[kScanChunk], 
 // Two waves per SIMD for every instantiation, stated: VGPRs + AGPRs share one 512-entry file per lane, and left alone hipcc
 // parks spills in AGPRs (a build with 256 VGPRs + 25 AGPRs ran at ONE wave per SIMD: 3.9 ms instead of 2.5 per 1 M config-3
 // frames; SQ_WAVES 1024 instead of 2048 was what gave it away).
-#define DSP_PRE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#define DSP_PRE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PRE && DSP_PRE_W3 ? 3 : 2, PRE && DSP_PRE_W3 ? 3 : 2)))
 // PS0..PS3 (PRE): scan steps of the four cascade sections (cascade_section)
 template <bool FULL, bool CLIPS, bool PRE = false, int PS0 = 6, int PS1 = 6, int PS2 = 6, int PS3 = 6>
 __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(const Mfcc512Args args, const GenTables1024 *__restrict__ G,
@@ -246,14 +265,16 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    char *wl = smem + wib * W_WAVE_BYTES;
+    constexpr bool W3 = PRE && DSP_PRE_W3 != 0;
+    constexpr int TF = W3 ? 8 : 16;                   // frames per tile
+    char *wl = smem + wib * wave_bytes(W3);
     float2 *zbuf = reinterpret_cast<float2 *>(wl + W_ZBUF);
     float *pbuf = reinterpret_cast<float *>(wl + W_ZBUF);
     float *part = reinterpret_cast<float *>(wl + W_PART);
     float *etile = reinterpret_cast<float *>(wl + W_ETILE);
 
-    float *dcta_lds = reinterpret_cast<float *>(smem + B_DCTA);
-    f4v *melw_lds = reinterpret_cast<f4v *>(smem + B_MELW);
+    float *dcta_lds = reinterpret_cast<float *>(smem + b_dcta(W3));
+    f4v *melw_lds = reinterpret_cast<f4v *>(smem + b_melw(W3));
     (void)melw_lds;
     for (int i = threadIdx.x; i < kGenDctSteps * 64; i += 256) dcta_lds[i] = (&G->dct_a[0][0])[i];
     if (PRE)
@@ -265,8 +286,10 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
 
     // ---- per-lane constants ------------------------------------------------------------------------------------
     float win[16];
+    if (!W3) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) win[i] = G->win[i][lane];
+        for (int i = 0; i < 16; ++i) win[i] = G->win[i][lane];
+    }
     c32 tw1[7], tw2[7], twp[4];
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
@@ -288,13 +311,23 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
         }
     }
     int gat[kGenMelsPerLane][kGenGather];           // partial slots of filters lane and lane + 64 (slots >= 128 read the zero slot)
+    unsigned gatp[kGenMelsPerLane][2] = {};          // W3: the same six slots (< 256 each) in two registers per filter
+    static_assert(kGenGather == 6 && kWaveZero < 256, "packed gather slots");
 #pragma unroll
     for (int i = 0; i < kGenMelsPerLane; ++i)
 #pragma unroll
         for (int g = 0; g < kGenGather; ++g) {
             const int sidx = G->mel_src[i][g][lane];
-            gat[i][g] = sidx < kWaveSlots * 64 ? sidx : kWaveZero;
+            const int v = sidx < kWaveSlots * 64 ? sidx : kWaveZero;
+            if (W3) gatp[i][g >> 2] |= (unsigned)v << (8 * (g & 3));
+            else gat[i][g] = v;
         }
+    unsigned k0p = 0;                                  // W3: the three window starts (< 1024 each) in one register
+    if (W3) {
+#pragma unroll
+        for (int c = 0; c < kWaveSlots; ++c) k0p |= (unsigned)mel_k0[c] << (10 * c);
+    }
+    (void)gatp; (void)k0p;
     const int n_mels = args.n_mels, n_mfcc = args.n_mfcc;
     const int l_hi = lane >> 3, l_lo = lane & 7;
     const int partner = ((64 - lane) & 63) << 2;     // byte index for ds_bpermute
@@ -351,7 +384,7 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
         const int n = lane & 15, q = lane >> 4;
         unsigned mx = amin_u;
 #pragma unroll 4
-        for (int s = 0; s < kGenDctSteps; ++s) mx = max(mx, __float_as_uint(etile[16 * (4 * s + q) + (n ^ ((2 * s + (q >> 1)) & 15))]));
+        for (int s = 0; s < kGenDctSteps; ++s) mx = max(mx, __float_as_uint(etile[TF * (4 * s + q) + ((n ^ (2 * s + (q >> 1))) & (TF - 1))]));
         {
             auto r = __builtin_amdgcn_permlane16_swap(mx, mx, false, false);
             mx = max(r[0], r[1]);
@@ -361,7 +394,7 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
         const float rinv = __builtin_amdgcn_rcpf(__uint_as_float(mx));
         f4v acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
         auto kstep = [&](int s, f4v &acc) {
-            const float e_s = etile[16 * (4 * s + q) + (n ^ ((2 * s + (q >> 1)) & 15))];
+            const float e_s = etile[TF * (4 * s + q) + ((n ^ (2 * s + (q >> 1))) & (TF - 1))];      // TF = 8: columns 8 .. 15 repeat 0 .. 7 and are not stored
             const float ec = __uint_as_float(max(__float_as_uint(e_s), amin_u));
             float db = 3.01029995663981195f * __builtin_amdgcn_logf(ec * rinv);
             db = __builtin_amdgcn_fmed3f(db, neg_top_db, 0.0f);
@@ -372,7 +405,7 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
         for (int s = 0; s < kGenDctSteps; s += 2) { kstep(s, acc0); kstep(s + 1, acc1); }
         const f4v d = acc0 + acc1;
         const long fl = (n < 8 ? fb0 : fb1 - 8) + n;
-        const bool ok = n < count && fl < n_frames;
+        const bool ok = n < count && n < TF && fl < n_frames;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = 4 * q + j;
@@ -396,7 +429,7 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
 #pragma unroll
         for (int a = 0; a < 8; ++a) { xs[2 * a] = nxt[a].x; xs[2 * a + 1] = nxt[a].y; }
 #if DSP_PRE_CASCADE
-        prefilter_cascade<PS0, PS1, PS2, PS3>(xs, out, S, lane);
+        prefilter_cascade<PS0, PS1, PS2, PS3>(xs, out, S, lane, W3 ? &G->win_chunk[lane][0] : nullptr);
 #else
         prefilter_scan(xs, out, S, lane);
 #endif
@@ -423,7 +456,8 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
 #pragma unroll
             for (int a = 0; a < 8; ++a) {
                 const float2 q = zbuf[lane + 64 * a];
-                v[a] = {q.x * win[2 * a], q.y * win[2 * a + 1]};
+                if (W3) v[a] = {q.x, q.y};                      // the window went in with the prefilter's gain
+                else v[a] = {q.x * win[2 * a], q.y * win[2 * a + 1]};
             }
             wave_lds_sync();
             // the next frame: its samples are in `nxt` (or nothing is left: then what `nxt` still holds is filtered for nobody);
@@ -515,7 +549,7 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
         if (PRE) asm volatile("" : "+v"(wl_lane));       // opaque per frame: the weight reads stay in the loop (not hoisted back into registers)
 #pragma unroll
         for (int c = 0; c < kWaveSlots; ++c) {
-            const float *rd = pbuf + mel_k0[c];
+            const float *rd = pbuf + (W3 ? (int)((k0p >> (10 * c)) & 1023u) : mel_k0[c]);
             float acc = 0.0f;
             if (PRE) {
 #pragma unroll
@@ -536,12 +570,12 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
         for (int i = 0; i < kGenMelsPerLane; ++i) {
             float s = 0.0f;
 #pragma unroll
-            for (int g = 0; g < kGenGather; ++g) s += part[gat[i][g]];
+            for (int g = 0; g < kGenGather; ++g) s += part[W3 ? (int)((gatp[i][g >> 2] >> (8 * (g & 3))) & 255u) : gat[i][g]];
             const int m = lane + 64 * i;
             if (m >= n_mels) s = 0.0f;
-            etile[16 * m + (slot ^ ((m >> 1) & 15))] = s;
+            etile[TF * m + ((slot ^ (m >> 1)) & (TF - 1))] = s;
         }
-        if (++slot == 16 || !more) { flush(slot); slot = 0; }
+        if (++slot == TF || !more) { flush(slot); slot = 0; }
         else wave_lds_sync();
         if (!more) return;
         if (PRE) {

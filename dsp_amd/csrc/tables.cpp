@@ -372,6 +372,8 @@ bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::st
             t.win[2 * a][l] = 0.5f * win[2 * n];
             t.win[2 * a + 1][l] = 0.5f * win[2 * n + 1];
         }
+    for (int l = 0; l < kLanes; ++l)
+        for (int i = 0; i < 16; ++i) t.win_chunk[l][i] = 0.5f * win[16 * l + i];
     for (int i = 0; i < 512; ++i) unit((double)i / 512.0, t.w512[0][i], t.w512[1][i]);
     for (int k = 0; k < 256; ++k) unit((double)k / 1024.0, t.w1024[0][k], t.w1024[1][k]);
 

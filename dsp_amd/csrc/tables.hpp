@@ -111,6 +111,7 @@ struct GenTables1024 {
     float tw2[14][kLanes];                 // W64^((l % 8) p),   p = 1..7: after the second stage
     float twp[8][kLanes];                  // W1024^(l + 64 t),  t = 0..3: untangling the packed real transform
     float dct_a[kGenDctSteps][kLanes];     // MFMA A operand of the tile epilogue: lane (c = l % 16, q = l / 16), step s: D[c][4 s + q]
+    float win_chunk[kLanes][16];           // the x0.5 window in the prefilter's chunk order: lane l, samples 16 l .. 16 l + 15 (full 1024-sample frames)
 };
 constexpr int kGenZeroSlot = kGenChunks * kLanes;   // partial slot that always reads 0
 bool build_gen_tables_1024(const dsp_mfcc_config &cfg, GenTables1024 &t, std::string &why);
