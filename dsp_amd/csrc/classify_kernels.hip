@@ -409,8 +409,19 @@ hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, cons
 //   wave 2: taps 1000-3000 Hz one tile behind (segment means, energy gate)
 // HBM traffic: x once + 71 x (32 + 32 + 4 + 4) B per 1 s clip.
 // ---------------------------------------------------------------------------------
-template <bool EVEN_B>
-__global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride,
+// DUAL (round 3, an experiment; default off): ONE wave runs both recurrences of its 64 clips as PACKED fp32 operations -- lane l
+// holds the pair (1000-3000 Hz, 3000-7500 Hz) of its clip's delay lines, and v = v - a[j] d[j-1] is one v_pk_mul_f32 + one
+// v_pk_add_f32 for both filters (component-wise IEEE multiply and add, no contraction: the same bits as two scalar chains; the 50
+// classify tests stay array_equal).  The block then has two waves (recurrences, taps) instead of three.  Measured on 49 152 clips
+// (tools/ab_classify.py, interleaved): three waves 2.58 ms, packed pair 2.79 ms, two SCALAR chains in one wave 2.85 ms.  What limits
+// a recurrence wave is how often ONE wave gets to issue (16 operations per ~110-cycle sample step, ~7 cycles apiece whatever their
+// dependencies); a packed operation issues for twice as long, so one wave doing both filters is slower than two waves doing one each.
+#ifndef DSP_CKPT_DUAL
+#define DSP_CKPT_DUAL 0
+#endif
+typedef float ck_f2 __attribute__((ext_vector_type(2)));
+template <bool EVEN_B, bool DUAL>
+__global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride,
                                                         const IirCoef c_bp, const IirCoef c_mp, float *__restrict__ ck_bp,
                                                         float *__restrict__ ck_mp, float *__restrict__ means_mp,
                                                         int *__restrict__ want_mp, const SpecTables *__restrict__ tab, int vec_ok)
@@ -419,9 +430,11 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
     __shared__ float vbuf[2][64 * IIR_LD];             // v tiles of the 1000-3000 Hz filter, [tile parity]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_r = wv < 2;
-    const IirCoef c = wv == 0 ? c_bp : c_mp;
-    float *__restrict__ ck = wv == 0 ? ck_bp : ck_mp;
+    const bool is_r = DUAL ? wv == 0 : wv < 2;          // runs a recurrence (DUAL: both)
+    const bool is_t = DUAL ? wv == 1 : wv == 2;         // runs the 1000-3000 Hz taps
+    const bool loader = DUAL ? true : wv < 2;           // the 128 threads that stage the x tiles
+    const IirCoef c = (DUAL || wv != 0) ? c_mp : c_bp;   // the wave's (second) filter: 1000-3000 Hz except for !DUAL wave 0
+    float *__restrict__ ck = (DUAL || wv != 0) ? ck_mp : ck_bp;
     const long clip0 = (long)blockIdx.x * 64;
     const int rows = (int)((n_clips - clip0) < 64 ? (n_clips - clip0) : 64);
     const int n_tiles = (n + IIR_TS - 1) / IIR_TS;
@@ -429,8 +442,12 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
     static_assert(kSpecHop % IIR_TS == 0 && kSpecSeg - kSpecHop == IIR_TS, "segments start on tile boundaries and overlap by one tile");
     constexpr int kTilesPerHop = kSpecHop / IIR_TS;
     float d[8];                                         // v[n-1] .. v[n-8] of this lane's clip
+    ck_f2 dp[8], ap[9];                                 // DUAL: (1000-3000 Hz, 3000-7500 Hz) pairs of delay line and a[j]
 #pragma unroll
-    for (int j = 0; j < 8; ++j) d[j] = 0.0f;
+    for (int j = 0; j < 8; ++j) { d[j] = 0.0f; dp[j] = ck_f2{0.0f, 0.0f}; }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) ap[j] = ck_f2{c_mp.a[j], c_bp.a[j]};
+    (void)dp; (void)ap;
     float cur = 0.0f, prev = 0.0f;
     const bool gating = tab->gate_ok != 0;
     float ea_cur = 0.0f, eb_cur = 0.0f, ea_prev = 0.0f, eb_prev = 0.0f;
@@ -463,26 +480,34 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
     };
     auto tile_cols = [&](int s) { const int t0 = s * IIR_TS; return n - t0 < IIR_TS ? n - t0 : IIR_TS; };
     auto fast = [&](int s) { return vec_ok && tile_cols(s) == IIR_TS; };
-    if (is_r) {                                                    // tile 0 into tin[0], tile 1 in flight
+    if (loader) {                                                  // tile 0 into tin[0], tile 1 in flight
         if (fast(0)) { issue(0); commit(tin[0]); } else load_scalar(0, tile_cols(0), tin[0]);
         if (n_tiles > 1 && fast(1)) issue(IIR_TS);
     }
     __syncthreads();
 
     for (int s = 0; s <= n_tiles; ++s) {
+        if (loader && s + 1 < n_tiles) {
+            // stage x tile s+1 for the next step, start the loads of tile s+2
+            if (fast(s + 1)) commit(tin[(s + 1) & 1]); else load_scalar((s + 1) * IIR_TS, tile_cols(s + 1), tin[(s + 1) & 1]);
+            if (s + 2 < n_tiles && fast(s + 2)) issue((s + 2) * IIR_TS);
+        }
         if (is_r) {
             if (s < n_tiles) {
-                // stage x tile s+1 for the next step, start the loads of tile s+2
-                if (s + 1 < n_tiles) {
-                    if (fast(s + 1)) commit(tin[(s + 1) & 1]); else load_scalar((s + 1) * IIR_TS, tile_cols(s + 1), tin[(s + 1) & 1]);
-                    if (s + 2 < n_tiles && fast(s + 2)) issue((s + 2) * IIR_TS);
-                }
                 // segment seg starts with this tile: its restart state is the delay line as it stands
                 const int seg = s / kTilesPerHop;
                 if (s % kTilesPerHop == 0 && seg < n_seg && lane < rows) {
                     float4 *dst = reinterpret_cast<float4 *>(ck + ((clip0 + lane) * n_seg + seg) * 8);
-                    dst[0] = make_float4(d[0], d[1], d[2], d[3]);
-                    dst[1] = make_float4(d[4], d[5], d[6], d[7]);
+                    if (DUAL) {
+                        float4 *dst2 = reinterpret_cast<float4 *>(ck_bp + ((clip0 + lane) * n_seg + seg) * 8);
+                        dst[0] = make_float4(dp[0].x, dp[1].x, dp[2].x, dp[3].x);
+                        dst[1] = make_float4(dp[4].x, dp[5].x, dp[6].x, dp[7].x);
+                        dst2[0] = make_float4(dp[0].y, dp[1].y, dp[2].y, dp[3].y);
+                        dst2[1] = make_float4(dp[4].y, dp[5].y, dp[6].y, dp[7].y);
+                    } else {
+                        dst[0] = make_float4(d[0], d[1], d[2], d[3]);
+                        dst[1] = make_float4(d[4], d[5], d[6], d[7]);
+                    }
                 }
                 const float *xin = tin[s & 1];
                 float *vo = vbuf[s & 1];
@@ -496,6 +521,17 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
                     d[0] = v;
                     return v;
                 };
+                auto recp = [&](float xv) {                          // DUAL: both filters on the sample, packed (x: 1000-3000 Hz, y: 3000-7500 Hz)
+#pragma clang fp contract(off)
+                    ck_f2 v = ck_f2{xv, xv};
+#pragma unroll
+                    for (int j = 1; j <= 8; ++j) v = v - ap[j] * dp[j - 1];
+#pragma unroll
+                    for (int j = 7; j > 0; --j) dp[j] = dp[j - 1];
+                    dp[0] = v;
+                    return v.x;
+                };
+                const bool keep_v = DUAL || wv == 1;                 // the 1000-3000 Hz v tiles go to the taps wave
                 if (lane < rows && cols == IIR_TS) {
 #pragma unroll
                     for (int h = 0; h < IIR_TS; h += IIR_BURST) {
@@ -503,17 +539,21 @@ __global__ __launch_bounds__(192) void iir2_ckpt_kernel(const float *__restrict_
 #pragma unroll
                         for (int i = 0; i < IIR_BURST; ++i) xr[i] = xin[lane * IIR_LD + h + i];
 #pragma unroll
-                        for (int i = 0; i < IIR_BURST; ++i) vr[i] = rec(xr[i]);
-                        if (wv == 1) {
+                        for (int i = 0; i < IIR_BURST; ++i) vr[i] = DUAL ? recp(xr[i]) : rec(xr[i]);
+                        if (keep_v) {
 #pragma unroll
                             for (int i = 0; i < IIR_BURST; ++i) vo[lane * IIR_LD + h + i] = vr[i];
                         }
                     }
                 } else if (lane < rows) {
-                    for (int i = 0; i < cols; ++i) { const float v = rec(xin[lane * IIR_LD + i]); if (wv == 1) vo[lane * IIR_LD + i] = v; }
+                    for (int i = 0; i < cols; ++i) {
+                        const float xv = xin[lane * IIR_LD + i];
+                        const float v = DUAL ? recp(xv) : rec(xv);
+                        if (keep_v) vo[lane * IIR_LD + i] = v;
+                    }
                 }
             }
-        } else if (s >= 1) {
+        } else if (is_t && s >= 1) {
             const int cols = tile_cols(s - 1);
             const float *vin = vbuf[(s - 1) & 1];
             auto taps = [&](float v) {                               // classifier.cpp:207-216
@@ -596,12 +636,13 @@ hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, co
     }
     const int blocks = (int)((n_clips + 63) / 64);
     const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    constexpr bool dual = DSP_CKPT_DUAL != 0;
     if (even_taps_only(c_mp))
-        hipLaunchKernelGGL(iir2_ckpt_kernel<true>, dim3(blocks), dim3(192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, means_mp, want_mp,
-                           tables, vec_ok);
+        hipLaunchKernelGGL((iir2_ckpt_kernel<true, dual>), dim3(blocks), dim3(dual ? 128 : 192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp,
+                           means_mp, want_mp, tables, vec_ok);
     else
-        hipLaunchKernelGGL(iir2_ckpt_kernel<false>, dim3(blocks), dim3(192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, means_mp, want_mp,
-                           tables, vec_ok);
+        hipLaunchKernelGGL((iir2_ckpt_kernel<false, dual>), dim3(blocks), dim3(dual ? 128 : 192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp,
+                           means_mp, want_mp, tables, vec_ok);
     return hipGetLastError();
 }
 

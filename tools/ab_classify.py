@@ -30,17 +30,13 @@ def main():
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     libs = []
     for v in args.variants:
-        L = C.CDLL(os.path.abspath(v.split(":")[0]))
+        L = C.CDLL(os.path.abspath(v))
         L.dsp_last_error.restype = C.c_char_p
         L.dsp_classify_batch_device.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_void_p, C.c_void_p]
         libs.append((v, L, torch.empty(n, dtype=torch.int32, device="cuda")))
 
     def run(i):
         v, L, lab = libs[i]
-        if ":" in v:                     # lib.so:N = N clips per block in iir2_ckpt_kernel (DSP_AMD_IIR_CLIPS_PER_BLOCK, read per launch)
-            os.environ["DSP_AMD_IIR_CLIPS_PER_BLOCK"] = v.split(":")[1]
-        else:
-            os.environ.pop("DSP_AMD_IIR_CLIPS_PER_BLOCK", None)
         rc = L.dsp_classify_batch_device(clips.data_ptr(), n, 16000, 16000, lab.data_ptr(), stream)
         assert rc == 0, L.dsp_last_error()
 
