@@ -11,7 +11,10 @@
 // Round 1: correct and batched, not yet tuned.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "classify_kernels.hpp"
 
@@ -494,12 +497,16 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float
         }
         if (is_r) {
             if (s < n_tiles) {
-                // segment seg starts with this tile: its restart state is the delay line as it stands
-                const int seg = s / kTilesPerHop;
-                if (s % kTilesPerHop == 0 && seg < n_seg && lane < rows) {
-                    float4 *dst = reinterpret_cast<float4 *>(ck + ((clip0 + lane) * n_seg + seg) * 8);
+                // segment seg starts with this tile (or, kCkPerSeg = 2, reaches its middle): its restart state is the delay line as it stands
+                const int seg = s / kTilesPerHop, seg_tile = s % kTilesPerHop;
+                constexpr int kMidTile = kSpecSeg / 2 / IIR_TS;
+                static_assert(kSpecSeg / 2 % IIR_TS == 0 && kMidTile < kTilesPerHop, "the segment's middle lies on a tile boundary");
+                const bool at_start = seg_tile == 0, at_mid = kCkPerSeg == 2 && seg_tile == kMidTile;
+                if ((at_start || at_mid) && seg < n_seg && lane < rows) {
+                    const long slot = (((clip0 + lane) * n_seg + seg) * kCkPerSeg + (at_mid ? 1 : 0)) * 8;
+                    float4 *dst = reinterpret_cast<float4 *>(ck + slot);
                     if (DUAL) {
-                        float4 *dst2 = reinterpret_cast<float4 *>(ck_bp + ((clip0 + lane) * n_seg + seg) * 8);
+                        float4 *dst2 = reinterpret_cast<float4 *>(ck_bp + slot);
                         dst[0] = make_float4(dp[0].x, dp[1].x, dp[2].x, dp[3].x);
                         dst[1] = make_float4(dp[4].x, dp[5].x, dp[6].x, dp[7].x);
                         dst2[0] = make_float4(dp[0].y, dp[1].y, dp[2].y, dp[3].y);
@@ -1011,6 +1018,12 @@ hipError_t read_rc_stamps(unsigned long long *host, int count)
 #define BD_STAMP(k) do { } while (0)
 #endif
 
+// Round 3: the block is PERSISTENT (grid = the blocks the chip holds; a block walks groups g, g + gridDim.x, ... of 60 frame slots) and
+// software-pipelined over its groups: while group g runs R .. F, the 60 KB of x rows of group g + 1, their restart states and (flags)
+// their segment means are already in flight into registers (8 float4 per thread), and the (clip, time bin) description of group g + 2
+// is being read from the work list -- phase L of a group is then only the LDS stores (in-kernel stamps of round 2: L took 9.6 k of a
+// block's 56 k cycles, plus the exposed latency of the restart-state loads inside R).  With kCkPerSeg = 2 phase R runs as two
+// 128-sample chains on waves 0 and 1 (restart states at the segment start and at its middle) instead of one 256-sample chain.
 template <int OUT, bool EVEN_B>
 __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void spec_from_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride, const IirCoef c,
                                                              const float *__restrict__ ck, const float *__restrict__ means,
@@ -1027,45 +1040,70 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     // frame slots of this launch: SPEC_FLAGS walks the work list of gated-in frames (wantlist[0] = count, then clip * T + t),
     // SPEC_FRAME_MAJOR every time bin of the clips on `hits` (hits[0] = count, then clip numbers)
     const long total = OUT == SPEC_FLAGS ? (long)wantlist[0] : (long)hits[0] * T;
-    const long gid0 = (long)blockIdx.x * RC_FRAMES;
-    if (gid0 >= total) return;
-    // every wave's lane l describes frame slot gid0 + l
-    const long gid = gid0 + lane;
-    const bool want = lane < RC_FRAMES && gid < total;
-    long clip = 0;
-    int t = 0;
-    if (want) {
-        if (OUT == SPEC_FLAGS) {
-            const int fr = wantlist[1 + gid];
-            clip = fr / T;
-            t = fr - (int)clip * T;
-        } else {
-            const long slotc = gid / T;
-            t = (int)(gid - slotc * T);
-            clip = (long)hits[1 + slotc];
-        }
-    }
-    const unsigned long long todo = __ballot(want);
-    RC_STAMP(0);
-    float *row = rows + (lane < RC_FRAMES ? lane : 0) * RC_ROW;
+    const long n_groups = (total + RC_FRAMES - 1) / RC_FRAMES;
+    long g = blockIdx.x;
+    if (g >= n_groups) return;
+    RC_STAMP(6);
 
-    // ---- L: the wanted segments of x into the rows.  Every load of the block is issued before the first LDS store (16
-    // float4 per thread in flight): loads inside the recurrence loop would each pay an HBM round trip that the serial
-    // arithmetic cannot cover.  One wave-instruction = one row = 1 KB contiguous.
-    {
-        constexpr int PER_ROW = kSpecSeg / 4, NL = (RC_FRAMES * PER_ROW + RC_THREADS - 1) / RC_THREADS;
-        static_assert(PER_ROW == 64, "one wave-instruction loads one row");
-        float4 v4[NL];
-        const unsigned clip_lo = (unsigned)clip, clip_hi = (unsigned)((unsigned long long)clip >> 32);
+    // every wave's lane l describes frame slot 60 g + l of group g: (clip, time bin); clip < 0 = no such slot
+    auto describe = [&](long grp, int &dclip, int &dt) {
+        const long gid = grp * RC_FRAMES + lane;
+        dclip = -1; dt = 0;
+        if (grp < n_groups && lane < RC_FRAMES && gid < total) {
+            if (OUT == SPEC_FLAGS) {
+                const int fr = wantlist[1 + gid];
+                dclip = fr / T;
+                dt = fr - dclip * T;
+            } else {
+                const long slotc = gid / T;
+                dt = (int)(gid - slotc * T);
+                dclip = hits[1 + slotc];
+            }
+        }
+    };
+    // the loads of a group: its x rows (one wave-instruction = one row = 1 KB contiguous; every load of the block in flight
+    // together), the restart states (waves 0 .. kCkPerSeg - 1, lane per frame) and the segment means (flags; wave 0)
+    constexpr int PER_ROW = kSpecSeg / 4, NL = (RC_FRAMES * PER_ROW + RC_THREADS - 1) / RC_THREADS;
+    static_assert(PER_ROW == 64, "one wave-instruction loads one row");
+    float4 v4[NL];
+    float4 ckv[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    float mean_pre = 0.0f;
+    // role: this wave's part of the serial phases (0 .. kCkPerSeg - 1: that part of R; 0 also M).  (Rotating the parts over the
+    // waves from group to group, so that both resident blocks of a CU do not keep R on the same SIMDs, was measured: no change.)
+    const int role = wib;
+    auto issue = [&](int iclip, int it) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int e = threadIdx.x + RC_THREADS * i, r = e / PER_ROW, c4 = (e % PER_ROW) * 4;      // r is wave-uniform
             if (r >= RC_FRAMES) { v4[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
-            const long rclip = (long)(((unsigned long long)__builtin_amdgcn_readlane(clip_hi, r) << 32) | __builtin_amdgcn_readlane(clip_lo, r));
-            const float *xs = x + rclip * stride + (long)__builtin_amdgcn_readlane(t, r) * kSpecHop + c4;     // unwanted slots: clip 0, t 0
+            const int rclip = __builtin_amdgcn_readlane(iclip, r);
+            const float *xs = x + (long)(rclip < 0 ? 0 : rclip) * stride + (long)__builtin_amdgcn_readlane(it, r) * kSpecHop + c4;     // unwanted slots: clip 0, t 0
             if (vec_ok) v4[i] = *reinterpret_cast<const float4 *>(xs);
             else v4[i] = make_float4(xs[0], xs[1], xs[2], xs[3]);
         }
+        if (role < kCkPerSeg && iclip >= 0) {
+            const float4 *src = reinterpret_cast<const float4 *>(ck + (((long)iclip * T + it) * kCkPerSeg + role) * 8);
+            ckv[0] = src[0]; ckv[1] = src[1];
+        }
+        if (means && role == 0 && iclip >= 0) mean_pre = means[(long)iclip * T + it];
+    };
+
+    int clip1, t1, clip2, t2;                       // descriptions of the next group and the one after it
+    describe(g, clip1, t1);
+    issue(clip1, t1);
+    describe(g + gridDim.x, clip2, t2);
+
+    const float U = tab->U, keep_min = tab->mp_keep_min;
+    const bool trivial01 = tab->trivial_first_levels != 0;
+    float2 *buf = fftbuf[wib];
+    float *row = rows + (lane < RC_FRAMES ? lane : 0) * RC_ROW;
+
+    for (; g < n_groups; g += gridDim.x) {
+        const int clip = clip1, t = t1;
+        const bool want = clip >= 0;
+        const unsigned long long todo = __ballot(want);
+        RC_STAMP(0);
+        // ---- L: the group's x rows from the registers into the LDS rows; its restart state and mean out of the prefetch registers
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int e = threadIdx.x + RC_THREADS * i, r = e / PER_ROW, c4 = (e % PER_ROW) * 4;
@@ -1073,24 +1111,27 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
             float *dst = rows + r * RC_ROW + 8 + c4;
             dst[0] = v4[i].x; dst[1] = v4[i].y; dst[2] = v4[i].z; dst[3] = v4[i].w;
         }
-    }
-    __syncthreads();
-    RC_STAMP(1);
+        float d[8] = {ckv[0].x, ckv[0].y, ckv[0].z, ckv[0].w, ckv[1].x, ckv[1].y, ckv[1].z, ckv[1].w};
+        const float mean_ck = mean_pre;
+        (void)mean_ck;
+        if (wib == 0) sflag[lane] = 0;
+        __syncthreads();
+        // the next group's loads go out now and land while this group computes; the description after that is requested too
+        clip1 = clip2; t1 = t2;
+        if (g + gridDim.x < n_groups) issue(clip1, t1);
+        describe(g + 2 * (long)gridDim.x, clip2, t2);
+        RC_STAMP(1);
 
-    // ---- R: v over the segment, from the stored delay line; v replaces x in the row
-    if (wib == 0) {
-        sflag[lane] = 0;
-        if (want) {
-            float d[8];
-            {
-                const float4 *src = reinterpret_cast<const float4 *>(ck + (clip * T + t) * 8);
-                const float4 a = src[0], b = src[1];
-                d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-            }
+        // ---- R: v over the segment, from the stored delay line(s); v replaces x in the row
+        if (role < kCkPerSeg && want) {
+            constexpr int RC_RQ = kSpecSeg / kCkPerSeg;
+            const int h0 = RC_RQ * role;
+            if (role == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) row[7 - j] = d[j];                   // row[8 + m] = v[m], m = -8 .. 255
+                for (int j = 0; j < 8; ++j) row[7 - j] = d[j];                   // row[8 + m] = v[m], m = -8 .. 255
+            }
 #pragma unroll 1
-            for (int h = 0; h < kSpecSeg; h += IIR_BURST) {
+            for (int h = h0; h < h0 + RC_RQ; h += IIR_BURST) {
                 float xr[IIR_BURST], vr[IIR_BURST];
 #pragma unroll
                 for (int i = 0; i < IIR_BURST; ++i) xr[i] = row[8 + h + i];
@@ -1108,101 +1149,120 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                 for (int i = 0; i < IIR_BURST; ++i) row[8 + h + i] = vr[i];
             }
         }
-    }
-    __syncthreads();
-    RC_STAMP(2);
-
-    // ---- T: output taps, wave w takes samples [RC_TQ w, RC_TQ (w + 1)) of every wanted frame; y replaces v
-    {
-        constexpr int RC_TQ = kSpecSeg / RC_WAVES;
-        const int n0 = RC_TQ * wib;
-        float d[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] = want ? row[8 + n0 - 1 - j] : 0.0f;       // v[n0-1] .. v[n0-8]
-        __syncthreads();                                                         // every history is read before any y lands
-        if (want) {
-#pragma unroll 1
-            for (int h = 0; h < RC_TQ; h += IIR_BURST) {
-                float vr[IIR_BURST], orr[IIR_BURST];
-#pragma unroll
-                for (int i = 0; i < IIR_BURST; ++i) vr[i] = row[8 + n0 + h + i];
-#pragma unroll
-                for (int i = 0; i < IIR_BURST; ++i) {                           // classifier.cpp:207-216
-                    float o = c.b[0] * vr[i];
-#pragma unroll
-                    for (int j = 1; j <= 8; ++j)
-                        if (!EVEN_B || j % 2 == 0) o = o + c.b[j] * d[j - 1];       // EVEN_B: see iir2_ckpt_kernel
-#pragma unroll
-                    for (int j = 7; j > 0; --j) d[j] = d[j - 1];
-                    d[0] = vr[i];
-                    orr[i] = o;
-                }
-#pragma unroll
-                for (int i = 0; i < IIR_BURST; ++i) row[8 + n0 + h + i] = orr[i];
-            }
-        }
-    }
-    __syncthreads();
-    RC_STAMP(3);
-
-    // ---- M: segment means (sequential sums, classifier.cpp:329-333)
-    if (wib == 0 && want) {
-        float mean;
-        if (means) {
-            mean = means[clip * T + t];                      // summed in the same order by iir2_ckpt_kernel's taps wave
-        } else {
-            float sum = 0.0f;
-#pragma unroll 1
-            for (int h = 0; h < kSpecSeg; h += IIR_BURST) {
-                float yr[IIR_BURST];
-#pragma unroll
-                for (int i = 0; i < IIR_BURST; ++i) yr[i] = row[8 + h + i];
-#pragma unroll
-                for (int i = 0; i < IIR_BURST; ++i) sum = sum + yr[i];
-            }
-            mean = sum / (float)kSpecSeg;
-        }
-        smean[lane] = mean;
-    }
-    __syncthreads();
-    RC_STAMP(4);
-
-    // ---- F: one frame at a time per wave
-    SpecLane K;
-    K.init(lane, tab);
-    const float U = tab->U, keep_min = tab->mp_keep_min;
-    const bool trivial01 = tab->trivial_first_levels != 0;
-    float2 *buf = fftbuf[wib];
-    const unsigned clip_lo = (unsigned)clip, clip_hi = (unsigned)((unsigned long long)clip >> 32);
-#pragma unroll 1
-    for (int f = wib; f < RC_FRAMES; f += RC_WAVES) {
-        if (!((todo >> f) & 1)) continue;
-        const float *fr = rows + f * RC_ROW + 8;
-        float cur[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cur[j] = fr[K.src[j]];
-        float p0, p1, p2;
-        K.psd(cur, smean[f], U, trivial01, buf, lane, p0, p1, p2);
-        if (OUT == SPEC_FLAGS) {
-            const bool loud = p0 >= keep_min || p1 >= keep_min || (lane == 0 && p2 >= keep_min);
-            if (__ballot(loud) != 0 && lane == 0) sflag[f] = 1;
-        } else {
-            const long fclip = (long)(((unsigned long long)__builtin_amdgcn_readlane(clip_hi, f) << 32) | __builtin_amdgcn_readlane(clip_lo, f));
-            const int ft = __builtin_amdgcn_readlane(t, f);
-            float *o = out + (fclip * T + ft) * (long)kSpecBins;
-            o[lane] = p0;
-            o[lane + 64] = p1;
-            if (lane == 0) o[128] = p2;
-        }
-    }
-#ifdef DSP_RC_STAMPS
-    __syncthreads();
-    RC_STAMP(5);
-#endif
-    if (OUT == SPEC_FLAGS) {
         __syncthreads();
-        if (wib == 0 && want) reinterpret_cast<int *>(out)[clip * T + t] = sflag[lane];      // the rest of loud[] was zeroed by the launcher
+        RC_STAMP(2);
+
+        // ---- T: output taps, wave w takes samples [RC_TQ w, RC_TQ (w + 1)) of every wanted frame; y replaces v
+        {
+            constexpr int RC_TQ = kSpecSeg / RC_WAVES;
+            const int n0 = RC_TQ * wib;
+            float dt[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dt[j] = want ? row[8 + n0 - 1 - j] : 0.0f;       // v[n0-1] .. v[n0-8]
+            __syncthreads();                                                         // every history is read before any y lands
+            if (want) {
+#pragma unroll 1
+                for (int h = 0; h < RC_TQ; h += IIR_BURST) {
+                    float vr[IIR_BURST], orr[IIR_BURST];
+#pragma unroll
+                    for (int i = 0; i < IIR_BURST; ++i) vr[i] = row[8 + n0 + h + i];
+#pragma unroll
+                    for (int i = 0; i < IIR_BURST; ++i) {                           // classifier.cpp:207-216
+                        float o = c.b[0] * vr[i];
+#pragma unroll
+                        for (int j = 1; j <= 8; ++j)
+                            if (!EVEN_B || j % 2 == 0) o = o + c.b[j] * dt[j - 1];      // EVEN_B: see iir2_ckpt_kernel
+#pragma unroll
+                        for (int j = 7; j > 0; --j) dt[j] = dt[j - 1];
+                        dt[0] = vr[i];
+                        orr[i] = o;
+                    }
+#pragma unroll
+                    for (int i = 0; i < IIR_BURST; ++i) row[8 + n0 + h + i] = orr[i];
+                }
+            }
+        }
+        __syncthreads();
+        RC_STAMP(3);
+        // the FFT's 48 per-lane constants are formed per group from an opaque copy of the lane number: held across the loop they
+        // (and the 32 prefetch registers) spilled 19 VGPRs; their L2-resident loads are in flight during M
+        SpecLane K;
+        {
+            int lane_k = lane;
+            asm volatile("" : "+v"(lane_k));
+            K.init(lane_k, tab);
+        }
+
+        // ---- M: segment means (sequential sums, classifier.cpp:329-333)
+        if (role == 0 && want) {
+            float mean;
+            if (means) {
+                mean = mean_ck;                                  // summed in the same order by iir2_ckpt_kernel's taps wave
+            } else {
+                float sum = 0.0f;
+#pragma unroll 1
+                for (int h = 0; h < kSpecSeg; h += IIR_BURST) {
+                    float yr[IIR_BURST];
+#pragma unroll
+                    for (int i = 0; i < IIR_BURST; ++i) yr[i] = row[8 + h + i];
+#pragma unroll
+                    for (int i = 0; i < IIR_BURST; ++i) sum = sum + yr[i];
+                }
+                mean = sum / (float)kSpecSeg;
+            }
+            smean[lane] = mean;
+        }
+        __syncthreads();
+        RC_STAMP(4);
+
+        // ---- F: one frame at a time per wave
+#pragma unroll 1
+        for (int f = wib; f < RC_FRAMES; f += RC_WAVES) {
+            if (!((todo >> f) & 1)) continue;
+            const float *fr = rows + f * RC_ROW + 8;
+            float cur[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[j] = fr[K.src[j]];
+            float p0, p1, p2;
+            K.psd(cur, smean[f], U, trivial01, buf, lane, p0, p1, p2);
+            if (OUT == SPEC_FLAGS) {
+                const bool loud = p0 >= keep_min || p1 >= keep_min || (lane == 0 && p2 >= keep_min);
+                if (__ballot(loud) != 0 && lane == 0) sflag[f] = 1;
+            } else {
+                const long fclip = (long)__builtin_amdgcn_readlane(clip, f);
+                const int ft = __builtin_amdgcn_readlane(t, f);
+                float *o = out + (fclip * T + ft) * (long)kSpecBins;
+                o[lane] = p0;
+                o[lane + 64] = p1;
+                if (lane == 0) o[128] = p2;
+            }
+        }
+#ifdef DSP_RC_STAMPS
+        __syncthreads();
+        RC_STAMP(5);
+#endif
+        if (OUT == SPEC_FLAGS) {
+            __syncthreads();
+            if (wib == 0 && want) reinterpret_cast<int *>(out)[(long)clip * T + t] = sflag[lane];      // the rest of loud[] was zeroed by the launcher
+        }
+        __syncthreads();                                     // rows, smean and sflag are reused by the next group
     }
+    RC_STAMP(7);
+}
+
+// resident 512-thread blocks of the chip for one instantiation (queried once per process)
+template <int OUT, bool EVEN_B>
+static int rc_resident_blocks()
+{
+    static int cached = 0;
+    if (cached > 0) return cached;
+    int per_cu = 0, dev = 0, n_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spec_from_ckpt_kernel<OUT, EVEN_B>, RC_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
+    if (const char *e = std::getenv("DSP_AMD_RC_BLOCKS_PER_CU")) { if (std::atoi(e) > 0) per_cu = std::atoi(e); }      // A/B runs
+    if (std::getenv("DSP_AMD_DEBUG")) fprintf(stderr, "[dsp_amd] spec_from_ckpt_kernel<%d,%d>: %d resident blocks per CU x %d CUs\n", OUT, (int)EVEN_B, per_cu, n_cu);
+    cached = per_cu * n_cu;
+    return cached;
 }
 
 hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
@@ -1210,25 +1270,22 @@ hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long strid
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0 || T <= 0) return hipSuccess;
-    const long total = n_clips * T;                       // the bound: blocks past the list's count exit at once
+    if (n_clips >= (1L << 31)) return hipErrorInvalidValue;      // clip numbers travel as ints
+    const long total = n_clips * T;                       // the bound: the work lists' counts are read on the device
     const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
-    const dim3 grid((unsigned)((total + RC_FRAMES - 1) / RC_FRAMES));
+    const long groups = (total + RC_FRAMES - 1) / RC_FRAMES;
+    auto launch = [&](auto kernel, int resident, const int *wl, const int *hl) {
+        const dim3 grid((unsigned)std::min<long>(groups, resident));
+        hipLaunchKernelGGL(kernel, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wl, hl, tables, out, T, vec_ok);
+    };
     if (flags) {
         hipError_t e = hipMemsetAsync(out, 0, (size_t)total * sizeof(int), stream);      // frames not on the list are not loud
         if (e != hipSuccess) return e;
-        if (even_taps_only(c))
-            hipLaunchKernelGGL((spec_from_ckpt_kernel<SPEC_FLAGS, true>), grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wantlist,
-                               (const int *)nullptr, tables, out, T, vec_ok);
-        else
-            hipLaunchKernelGGL((spec_from_ckpt_kernel<SPEC_FLAGS, false>), grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wantlist,
-                               (const int *)nullptr, tables, out, T, vec_ok);
+        if (even_taps_only(c)) launch(spec_from_ckpt_kernel<SPEC_FLAGS, true>, rc_resident_blocks<SPEC_FLAGS, true>(), wantlist, (const int *)nullptr);
+        else launch(spec_from_ckpt_kernel<SPEC_FLAGS, false>, rc_resident_blocks<SPEC_FLAGS, false>(), wantlist, (const int *)nullptr);
     } else {
-        if (even_taps_only(c))
-            hipLaunchKernelGGL((spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, true>), grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means,
-                               (const int *)nullptr, hits, tables, out, T, vec_ok);
-        else
-            hipLaunchKernelGGL((spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, false>), grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means,
-                               (const int *)nullptr, hits, tables, out, T, vec_ok);
+        if (even_taps_only(c)) launch(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, true>, rc_resident_blocks<SPEC_FRAME_MAJOR, true>(), (const int *)nullptr, hits);
+        else launch(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, false>, rc_resident_blocks<SPEC_FRAME_MAJOR, false>(), (const int *)nullptr, hits);
     }
     return hipGetLastError();
 }

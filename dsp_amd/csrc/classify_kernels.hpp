@@ -11,6 +11,13 @@ constexpr int kSpecSeg = 256;    // nperseg            classifier.cpp:223
 constexpr int kSpecHop = 224;    // nperseg - nperseg/8 classifier.cpp:224-225
 constexpr int kSpecBins = 129;   // nfft/2 + 1         classifier.cpp:235
 constexpr int kMaxMidpoints = 64;
+// Restart states (delay lines) iir2_ckpt_kernel stores per spectrogram segment and filter: 2 = at the segment start and at its
+// middle (sample 128), so the recompute of a segment runs as TWO 128-sample chains on two wavefronts instead of one 256-sample
+// chain on one (spec_from_ckpt_kernel, phase R); 1 = segment start only (round 2's form, kept for A/B builds).
+#ifndef DSP_CK_HALF
+#define DSP_CK_HALF 1
+#endif
+constexpr int kCkPerSeg = DSP_CK_HALF ? 2 : 1;
 
 struct SpecTables {
     float window[kSpecSeg];      // periodic Tukey(0.25), evaluated on the host like classifier.cpp:259-293
@@ -47,8 +54,8 @@ hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long strid
                                  hipStream_t stream);
 
 // classify()'s form of a9: both recurrences in one pass over x, no filtered signal written.  Per clip and spectrogram segment
-// k (n_seg = (n-256)/224+1): ck_bp / ck_mp [c][k][8] = the filter's delay line v[224k-1 .. 224k-8] (restart state of the
-// segment), means_mp[c][k] = mean of the 1000-3000 Hz output over the segment (classifier.cpp:329-333), want_mp = work list
+// k (n_seg = (n-256)/224+1): ck_bp / ck_mp [c][k][kCkPerSeg][8] = the filter's delay line v[224k-1 .. 224k-8] (restart state of
+// the segment) and, with kCkPerSeg = 2, v[224k+127 .. 224k+120] (restart state of its second half), means_mp[c][k] = mean of the 1000-3000 Hz output over the segment (classifier.cpp:329-333), want_mp = work list
 // (want_mp[0] = count, then frame numbers c * n_seg + k, 1 + n_clips * n_seg ints) of the segments whose energy does NOT prove
 // that every PSD cell stays below SpecTables::mp_keep_min -- the only ones the flag spectrogram has to transform.
 hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,

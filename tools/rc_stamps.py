@@ -26,6 +26,9 @@ buf = np.zeros(8 * 2048, np.uint64)
 L.dsp_debug_rc_stamps.argtypes = [C.c_void_p, C.c_int]
 assert L.dsp_debug_rc_stamps(buf.ctypes.data, buf.size) == 0
 st = buf.reshape(2048, 8).astype(np.int64)
+st = st[st[:, 0] != 0]                    # persistent kernel: only the resident blocks exist
+print(f"{len(st)} blocks stamped; whole kernel per block (stamp 6 -> 7): median {np.median(st[:, 7] - st[:, 6]):.0f}, "
+      f"min {np.min(st[:, 7] - st[:, 6])}, max {np.max(st[:, 7] - st[:, 6])} cycles; span over blocks {st[:, 7].max() - st[:, 6].min()}")
 d = np.diff(st[:, :6], axis=1)
 names = ["L (segment loads -> LDS)", "R (recurrence, one wave)", "T (taps, all waves)", "M (means, one wave)", "F (FFT + PSD out)"]
 print("ticks of s_memtime (100 MHz constant clock on gfx950: 1 tick = 10 ns), median / p90 over 2048 blocks")
