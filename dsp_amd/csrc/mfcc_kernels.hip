@@ -613,6 +613,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         swap_lane4(s[2].x, s[3].x); swap_lane4(s[2].y, s[3].y);
 #endif
         DSP_SETPRIO(DSP_PRIO_FFT, DSP_PRIO_FFT2);
+#ifdef DSP_DIAG_SNOPS      // timing-only probe: extra scalar / vector issue slots per frame (is the kernel bound by instruction issue?)
+#pragma unroll
+        for (int i_ = 0; i_ < DSP_DIAG_SNOPS; ++i_) asm volatile("s_nop 0");
+#endif
+#ifdef DSP_DIAG_VNOPS
+#pragma unroll
+        for (int i_ = 0; i_ < DSP_DIAG_VNOPS; ++i_) asm volatile("v_mov_b32 %0, %0" : "+v"(s[i_ & 3].x));
+#endif
         radix4(s);                                             // digit c (bits 3:2)
 #pragma unroll
         for (int q = 1; q < 4; ++q) s[q] = cmul(s[q], tw3[q - 1]);
