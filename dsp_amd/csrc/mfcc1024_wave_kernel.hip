@@ -164,6 +164,28 @@ __device__ __forceinline__ float shfl_lane<float>(float v, int byte_addr)
     return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
 }
 
+// lane l <- lane l - 1 (lane 0 <- 0) without the LDS crossbar: v_mov_b32_dpp wave_shr:1.  DSP_PRE_DPP1 = 1 uses it for the scan's
+// first step and for the final one-lane shift of every section (24 of the 44 ds_bpermute_b32 per frame).
+#ifndef DSP_PRE_DPP1
+#define DSP_PRE_DPP1 1
+#endif
+__device__ __forceinline__ int dpp_up1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false); }
+template <typename T>
+__device__ __forceinline__ T shfl_up1(T v);
+template <>
+__device__ __forceinline__ float shfl_up1<float>(float v) { return __int_as_float(dpp_up1(__float_as_int(v))); }
+template <>
+__device__ __forceinline__ double shfl_up1<double>(double v)
+{
+    const long long bits = __double_as_longlong(v);
+    const int lo = dpp_up1((int)bits), hi = dpp_up1((int)(bits >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
+// fused multiply-add in T (__builtin_fma alone is the float64 builtin: on float operands it converts, runs v_fma_f64 and converts back)
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // STEPS: scan steps of this section, a compile-time count (the two literal filters need 1 / 3 / 3 / 5 and 2 / 3 / 3 / 4: one kernel
 // instantiation each; more steps than the poles need multiply by matrices below the tolerance and are harmless): the section is
 // straight-line code without a branch, so that it can share a scheduling region with the transform of the previous frame.
@@ -174,7 +196,7 @@ __device__ __forceinline__ void cascade_section(T (&u)[kScanChunk], T a1, T a2, 
     T t0 = 0, t1 = 0;
 #pragma unroll
     for (int i = 0; i < kScanChunk; ++i) {
-        const T w0 = __builtin_fma(-a1, t0, __builtin_fma(-a2, t1, u[i]));      // the older state first: one dependent fma per sample
+        const T w0 = fma_t(-a1, t0, fma_t(-a2, t1, u[i]));      // the older state first: one dependent fma per sample
         t1 = t0;
         t0 = w0;
     }
@@ -183,23 +205,27 @@ __device__ __forceinline__ void cascade_section(T (&u)[kScanChunk], T a1, T a2, 
     for (int d = 0; d < STEPS; ++d) {
         const int from = ((lane - (1 << d)) & 63) << 2;
         const bool on = lane >= (1 << d);
-        const T u0 = shfl_lane<T>(t0, from), u1 = shfl_lane<T>(t1, from);
+        const T u0 = (DSP_PRE_DPP1 && d == 0) ? shfl_up1<T>(t0) : shfl_lane<T>(t0, from), u1 = (DSP_PRE_DPP1 && d == 0) ? shfl_up1<T>(t1) : shfl_lane<T>(t1, from);
         const T *m = pw[d][sc];
-        const T n0 = __builtin_fma(m[1], u1, __builtin_fma(m[0], u0, t0)), n1 = __builtin_fma(m[3], u1, __builtin_fma(m[2], u0, t1));
-        t0 = on ? n0 : t0;
-        t1 = on ? n1 : t1;
+        const T n0 = fma_t(m[1], u1, fma_t(m[0], u0, t0)), n1 = fma_t(m[3], u1, fma_t(m[2], u0, t1));
+        if (DSP_PRE_DPP1 && d == 0) {      // lane 0 received zeros (the DPP move's `old`): n0 = t0 + 0, n1 = t1 + 0 exactly, no select
+            t0 = n0; t1 = n1;
+        } else {
+            t0 = on ? n0 : t0;
+            t1 = on ? n1 : t1;
+        }
     }
     // a chunk starts from the scan value of the lane before it (zero for lane 0)
     {
         const int from = ((lane - 1) & 63) << 2;
-        const T u0 = shfl_lane<T>(t0, from), u1 = shfl_lane<T>(t1, from);
-        t0 = lane ? u0 : (T)0;
-        t1 = lane ? u1 : (T)0;
+        const T u0 = DSP_PRE_DPP1 ? shfl_up1<T>(t0) : shfl_lane<T>(t0, from), u1 = DSP_PRE_DPP1 ? shfl_up1<T>(t1) : shfl_lane<T>(t1, from);
+        t0 = (DSP_PRE_DPP1 || lane) ? u0 : (T)0;      // DPP: lane 0 already holds the move's `old` = 0
+        t1 = (DSP_PRE_DPP1 || lane) ? u1 : (T)0;
     }
     // pass 2: the chunk again from its true state, output y = w[n] - w[n-2]
 #pragma unroll
     for (int i = 0; i < kScanChunk; ++i) {
-        const T w0 = __builtin_fma(-a1, t0, __builtin_fma(-a2, t1, u[i]));
+        const T w0 = fma_t(-a1, t0, fma_t(-a2, t1, u[i]));
         u[i] = w0 - t1;
         t1 = t0;
         t0 = w0;
@@ -256,6 +282,10 @@ __device__ __forceinline__ void prefilter_cascade(const float (&x)[kScanChunk], 
 // frames; SQ_WAVES 1024 instead of 2048 was what gave it away).
 #define DSP_PRE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PRE && DSP_PRE_W3 ? 3 : 2, PRE && DSP_PRE_W3 ? 3 : 2)))
 // PS0..PS3 (PRE): scan steps of the four cascade sections (cascade_section)
+// PRE: mel weights in registers (1) like the plain kernel, or re-read per frame from the block-shared LDS copy (0)
+#ifndef DSP_PRE_MELW_REGS
+#define DSP_PRE_MELW_REGS 1
+#endif
 template <bool FULL, bool CLIPS, bool PRE = false, int PS0 = 6, int PS1 = 6, int PS2 = 6, int PS3 = 6>
 __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(const Mfcc512Args args, const GenTables1024 *__restrict__ G,
                                                             const PrefilterScan *__restrict__ S = nullptr)
@@ -305,7 +335,7 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
 #pragma unroll
     for (int c = 0; c < kWaveSlots; ++c) {
         mel_k0[c] = G->mel_k0[c][lane];
-        if (!PRE) {
+        if (!PRE || DSP_PRE_MELW_REGS) {
 #pragma unroll
             for (int i = 0; i < kMelChunk; ++i) melw[c][i] = G->mel_w[c][i][lane];
         }
@@ -551,7 +581,7 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
         for (int c = 0; c < kWaveSlots; ++c) {
             const float *rd = pbuf + (W3 ? (int)((k0p >> (10 * c)) & 1023u) : mel_k0[c]);
             float acc = 0.0f;
-            if (PRE) {
+            if (PRE && !DSP_PRE_MELW_REGS) {
 #pragma unroll
                 for (int qd = 0; qd < 3; ++qd) {
                     const f4v w = melw_lds[(c * 3 + qd) * 64 + wl_lane];
