@@ -630,7 +630,7 @@ struct ClassifyCtx {
     dsp::SpecTables *d_tab = nullptr;
     // workspace for one sub-batch
     float *d_x = nullptr, *d_sbp = nullptr;                // staged input (host entry points), 3000-7500 Hz PSD maps [clip][T][129]
-    float *d_ck_bp = nullptr, *d_ck_mp = nullptr;          // [clip][T][kCkPerSeg][8]: delay line of each filter at every segment start (and middle)
+    float *d_ck_bp = nullptr, *d_ck_mp = nullptr;          // [clip][T][kCkPerSegBp / Mp][8]: delay line of each filter at every segment start (3000-7500 Hz: and middle)
     float *d_mean_mp = nullptr;                            // [clip][T]: segment means of the 1000-3000 Hz output
     int *d_labels = nullptr, *d_hits = nullptr;            // d_hits: work list of clips with midpoints
     int *d_loud = nullptr;                                 // [clip][T]: time bins of the 1000-3000 Hz map above 70 dB
@@ -722,8 +722,8 @@ int cls_reserve(long clips, int n, bool need_x)
     const size_t T = (size_t)std::max(1, spec_bins(n));
     if (need_x) DSP_HIP(hipMalloc(&g_cls.d_x, (size_t)clips * cls_row(n) * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_sbp, (size_t)clips * dsp::kSpecBins * T * sizeof(float)));
-    DSP_HIP(hipMalloc(&g_cls.d_ck_bp, (size_t)clips * T * dsp::kCkPerSeg * 8 * sizeof(float)));
-    DSP_HIP(hipMalloc(&g_cls.d_ck_mp, (size_t)clips * T * dsp::kCkPerSeg * 8 * sizeof(float)));
+    DSP_HIP(hipMalloc(&g_cls.d_ck_bp, (size_t)clips * T * dsp::kCkPerSegBp * 8 * sizeof(float)));
+    DSP_HIP(hipMalloc(&g_cls.d_ck_mp, (size_t)clips * T * dsp::kCkPerSegMp * 8 * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_loud, (size_t)clips * T * sizeof(int)));
     DSP_HIP(hipMalloc(&g_cls.d_gate, ((size_t)clips * T + 1) * sizeof(int)));      // work list of gated-in frames: count + frame numbers
     DSP_HIP(hipMalloc(&g_cls.d_mean_mp, (size_t)clips * T * sizeof(float)));

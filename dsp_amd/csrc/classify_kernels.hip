@@ -431,6 +431,10 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float
 {
     __shared__ float tin[2][64 * IIR_LD];
     __shared__ float vbuf[2][64 * IIR_LD];             // v tiles of the 1000-3000 Hz filter, [tile parity]
+    // The 1000-3000 Hz restart states wait in LDS until the taps wave has the segment's energy gate: only the gated-in segments
+    // (8 % in the bench workload) are ever recomputed, so only their states go to HBM (4.1 of the 4.5 KB per clip and filter
+    // stay on chip).  Three entries are live at most: start of segment k (by parity), its middle, start of segment k + 1.
+    __shared__ float ckbuf[DUAL ? 1 : 3][8][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool is_r = DUAL ? wv == 0 : wv < 2;          // runs a recurrence (DUAL: both)
@@ -497,20 +501,30 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float
         }
         if (is_r) {
             if (s < n_tiles) {
-                // segment seg starts with this tile (or, kCkPerSeg = 2, reaches its middle): its restart state is the delay line as it stands
+                // segment seg starts with this tile (or reaches its middle, where the wave's filter keeps a second state): its restart
+                // state is the delay line as it stands
                 const int seg = s / kTilesPerHop, seg_tile = s % kTilesPerHop;
                 constexpr int kMidTile = kSpecSeg / 2 / IIR_TS;
                 static_assert(kSpecSeg / 2 % IIR_TS == 0 && kMidTile < kTilesPerHop, "the segment's middle lies on a tile boundary");
-                const bool at_start = seg_tile == 0, at_mid = kCkPerSeg == 2 && seg_tile == kMidTile;
+                const int ck_n = (DUAL || wv != 0) ? kCkPerSegMp : kCkPerSegBp;      // states per segment of `ck`
+                const bool at_start = seg_tile == 0, at_mid = seg_tile == kMidTile && (DUAL ? (kCkPerSegBp == 2 || kCkPerSegMp == 2) : ck_n == 2);
                 if ((at_start || at_mid) && seg < n_seg && lane < rows) {
-                    const long slot = (((clip0 + lane) * n_seg + seg) * kCkPerSeg + (at_mid ? 1 : 0)) * 8;
+                    const long slot = (((clip0 + lane) * n_seg + seg) * ck_n + (at_mid ? 1 : 0)) * 8;
                     float4 *dst = reinterpret_cast<float4 *>(ck + slot);
                     if (DUAL) {
-                        float4 *dst2 = reinterpret_cast<float4 *>(ck_bp + slot);
-                        dst[0] = make_float4(dp[0].x, dp[1].x, dp[2].x, dp[3].x);
-                        dst[1] = make_float4(dp[4].x, dp[5].x, dp[6].x, dp[7].x);
-                        dst2[0] = make_float4(dp[0].y, dp[1].y, dp[2].y, dp[3].y);
-                        dst2[1] = make_float4(dp[4].y, dp[5].y, dp[6].y, dp[7].y);
+                        float4 *dst2 = reinterpret_cast<float4 *>(ck_bp + (((clip0 + lane) * n_seg + seg) * kCkPerSegBp + (at_mid ? 1 : 0)) * 8);
+                        if (at_start || kCkPerSegMp == 2) {
+                            dst[0] = make_float4(dp[0].x, dp[1].x, dp[2].x, dp[3].x);
+                            dst[1] = make_float4(dp[4].x, dp[5].x, dp[6].x, dp[7].x);
+                        }
+                        if (at_start || kCkPerSegBp == 2) {
+                            dst2[0] = make_float4(dp[0].y, dp[1].y, dp[2].y, dp[3].y);
+                            dst2[1] = make_float4(dp[4].y, dp[5].y, dp[6].y, dp[7].y);
+                        }
+                    } else if (wv != 0) {                            // 1000-3000 Hz: parked in LDS for the taps wave's gate
+                        float (*e)[64] = ckbuf[at_mid ? 1 : (seg & 1) * 2];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) e[j][lane] = d[j];
                     } else {
                         dst[0] = make_float4(d[0], d[1], d[2], d[3]);
                         dst[1] = make_float4(d[4], d[5], d[6], d[7]);
@@ -619,7 +633,19 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float
                     }
                     // work list of the flag spectrogram: want_mp[0] = count, then frame numbers clip * T + t, in any order
                     // (hipcc turns the per-lane add into one atomic per wave)
-                    if (g) want_mp[1 + atomicAdd(want_mp, 1)] = (int)((clip0 + lane) * n_seg + seg_k - 1);
+                    if (g) {
+                        want_mp[1 + atomicAdd(want_mp, 1)] = (int)((clip0 + lane) * n_seg + seg_k - 1);
+                        if (!DUAL) {                                 // the segment will be recomputed: its restart states leave LDS
+                            const int sg = seg_k - 1;
+#pragma unroll
+                            for (int h = 0; h < kCkPerSegMp; ++h) {
+                                const float (*e)[64] = ckbuf[h ? 1 : (sg & 1) * 2];
+                                float4 *dst = reinterpret_cast<float4 *>(ck + (((clip0 + lane) * n_seg + sg) * kCkPerSegMp + h) * 8);
+                                dst[0] = make_float4(e[0][lane], e[1][lane], e[2][lane], e[3][lane]);
+                                dst[1] = make_float4(e[4][lane], e[5][lane], e[6][lane], e[7][lane]);
+                            }
+                        }
+                    }
                 }
             } else if (lane < rows) {
                 for (int i = 0; i < cols; ++i) (void)taps(vin[lane * IIR_LD + i]);    // a short last tile lies past every whole segment
@@ -1022,7 +1048,7 @@ hipError_t read_rc_stamps(unsigned long long *host, int count)
 // software-pipelined over its groups: while group g runs R .. F, the 60 KB of x rows of group g + 1, their restart states and (flags)
 // their segment means are already in flight into registers (8 float4 per thread), and the (clip, time bin) description of group g + 2
 // is being read from the work list -- phase L of a group is then only the LDS stores (in-kernel stamps of round 2: L took 9.6 k of a
-// block's 56 k cycles, plus the exposed latency of the restart-state loads inside R).  With kCkPerSeg = 2 phase R runs as two
+// block's 56 k cycles, plus the exposed latency of the restart-state loads inside R).  With two restart states per segment (kCkPerSegBp) phase R runs as two
 // 128-sample chains on waves 0 and 1 (restart states at the segment start and at its middle) instead of one 256-sample chain.
 template <int OUT, bool EVEN_B>
 __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void spec_from_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride, const IirCoef c,
@@ -1031,6 +1057,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                                                              const SpecTables *__restrict__ tab, float *__restrict__ out, int T, int vec_ok)
 {
     static_assert(OUT == SPEC_FLAGS || OUT == SPEC_FRAME_MAJOR, "flags or [time][bin]");
+    constexpr int kCkPerSeg = OUT == SPEC_FLAGS ? kCkPerSegMp : kCkPerSegBp;      // restart states per segment in `ck`
     __shared__ float rows[RC_FRAMES * RC_ROW];
     __shared__ float2 fftbuf[RC_WAVES][kSpecSeg];
     __shared__ float smean[64];

@@ -11,13 +11,19 @@ constexpr int kSpecSeg = 256;    // nperseg            classifier.cpp:223
 constexpr int kSpecHop = 224;    // nperseg - nperseg/8 classifier.cpp:224-225
 constexpr int kSpecBins = 129;   // nfft/2 + 1         classifier.cpp:235
 constexpr int kMaxMidpoints = 64;
-// Restart states (delay lines) iir2_ckpt_kernel stores per spectrogram segment and filter: 2 = at the segment start and at its
-// middle (sample 128), so the recompute of a segment runs as TWO 128-sample chains on two wavefronts instead of one 256-sample
-// chain on one (spec_from_ckpt_kernel, phase R); 1 = segment start only (round 2's form, kept for A/B builds).
+// Restart states (delay lines) iir2_ckpt_kernel stores per spectrogram segment and filter: at the segment start AND at its middle
+// (sample 128), so the recompute of a segment runs as TWO 128-sample chains on two wavefronts instead of one 256-sample chain on
+// one (spec_from_ckpt_kernel, phase R).  Per filter, measured on 49 152 clips (profiles/r03_classify_session2.txt): both filters
+// 2.485 ms, the 3000-7500 Hz filter only 2.521 ms, neither 2.586 ms; each second state is 2.3 KB more traffic per clip.
+// DSP_CK_HALF = 0 / DSP_CK_HALF_MP = 0: segment starts only (A/B builds).
 #ifndef DSP_CK_HALF
 #define DSP_CK_HALF 1
 #endif
-constexpr int kCkPerSeg = DSP_CK_HALF ? 2 : 1;
+#ifndef DSP_CK_HALF_MP
+#define DSP_CK_HALF_MP DSP_CK_HALF
+#endif
+constexpr int kCkPerSegBp = DSP_CK_HALF ? 2 : 1;       // 3000-7500 Hz (the map of the clips with midpoints)
+constexpr int kCkPerSegMp = DSP_CK_HALF_MP ? 2 : 1;    // 1000-3000 Hz (the flags of the gated-in frames)
 
 struct SpecTables {
     float window[kSpecSeg];      // periodic Tukey(0.25), evaluated on the host like classifier.cpp:259-293
@@ -54,13 +60,14 @@ hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long strid
                                  hipStream_t stream);
 
 // classify()'s form of a9: both recurrences in one pass over x, no filtered signal written.  Per clip and spectrogram segment
-// k (n_seg = (n-256)/224+1): ck_bp / ck_mp [c][k][kCkPerSeg][8] = the filter's delay line v[224k-1 .. 224k-8] (restart state of
-// the segment) and, with kCkPerSeg = 2, v[224k+127 .. 224k+120] (restart state of its second half), means_mp[c][k] = mean of the 1000-3000 Hz output over the segment (classifier.cpp:329-333), want_mp = work list
+// k (n_seg = (n-256)/224+1): ck_bp [c][k][kCkPerSegBp][8], ck_mp [c][k][kCkPerSegMp][8] = the filter's delay line v[224k-1 .. 224k-8] (restart state of
+// the segment) and, as the second entry, v[224k+127 .. 224k+120] (restart state of its second half), means_mp[c][k] = mean of the 1000-3000 Hz output over the segment (classifier.cpp:329-333), want_mp = work list
 // (want_mp[0] = count, then frame numbers c * n_seg + k, 1 + n_clips * n_seg ints) of the segments whose energy does NOT prove
 // that every PSD cell stays below SpecTables::mp_keep_min -- the only ones the flag spectrogram has to transform.
 hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
                             float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream);
-// Spectrogram of segments recomputed from those checkpoints (filter c, checkpoints ck).  flags = true: out = int loud[c][T]
+// Spectrogram of segments recomputed from those checkpoints (filter c, checkpoints ck: ck_mp's layout for flags = true, ck_bp's
+// otherwise).  flags = true: out = int loud[c][T]
 // (1 = some cell >= mp_keep_min; 0 for every segment not on `wantlist`), means = means_mp; flags = false: out = PSD
 // [c][T][129] of every segment of the clips on the work list `hits` (means computed here).
 hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
