@@ -634,6 +634,7 @@ struct ClassifyCtx {
     float *d_mean_mp = nullptr;                            // [clip][T]: segment means of the 1000-3000 Hz output
     int *d_labels = nullptr, *d_hits = nullptr;            // d_hits: work list of clips with midpoints
     int *d_loud = nullptr;                                 // [clip][T]: time bins of the 1000-3000 Hz map above 70 dB
+    int *d_simd = nullptr;                                 // iir2_ckpt_kernel's per-CU SIMD load table (launch_iir2_ckpt)
     int *d_gate = nullptr;                                 // work list of the segments whose energy does not rule a loud cell out (IIR kernel)
     dsp::ClassifyTrace *d_trace = nullptr;
     long cap_clips = 0;
@@ -697,11 +698,11 @@ long cls_row(int n) { return ((long)n + 3) & ~3L; }      // workspace row: n flo
 
 void cls_free_workspace()
 {
-    for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_sbp, (void *)g_cls.d_ck_bp, (void *)g_cls.d_ck_mp, (void *)g_cls.d_loud, (void *)g_cls.d_gate,
+    for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_sbp, (void *)g_cls.d_ck_bp, (void *)g_cls.d_ck_mp, (void *)g_cls.d_loud, (void *)g_cls.d_gate, (void *)g_cls.d_simd,
                     (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_hits, (void *)g_cls.d_trace})
         if (p) hipFree(p);
     g_cls.d_x = g_cls.d_sbp = g_cls.d_ck_bp = g_cls.d_ck_mp = g_cls.d_mean_mp = nullptr;
-    g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = g_cls.d_gate = nullptr; g_cls.d_trace = nullptr;
+    g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = g_cls.d_gate = g_cls.d_simd = nullptr; g_cls.d_trace = nullptr;
     g_cls.cap_clips = 0; g_cls.cap_n = 0; g_cls.cap_x = false;
 }
 
@@ -725,6 +726,7 @@ int cls_reserve(long clips, int n, bool need_x)
     DSP_HIP(hipMalloc(&g_cls.d_ck_bp, (size_t)clips * T * dsp::kCkPerSegBp * 8 * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_ck_mp, (size_t)clips * T * dsp::kCkPerSegMp * 8 * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_loud, (size_t)clips * T * sizeof(int)));
+    DSP_HIP(hipMalloc(&g_cls.d_simd, sizeof(int) * dsp::kSimdLoadCus * dsp::kSimdLoadStride));
     DSP_HIP(hipMalloc(&g_cls.d_gate, ((size_t)clips * T + 1) * sizeof(int)));      // work list of gated-in frames: count + frame numbers
     DSP_HIP(hipMalloc(&g_cls.d_mean_mp, (size_t)clips * T * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_labels, (size_t)clips * sizeof(int)));
@@ -755,7 +757,7 @@ int cls_run(const dsp_classify_config &cfg, const float *d_x, long clips, int n,
     const dsp::ClassifyRule rule{cfg.keep_lo, cfg.keep_hi, cfg.middle_max, cfg.above_min, cfg.below_min};
     // ONE pass over the clips: both recurrences, the delay lines at every segment start, the 1000-3000 Hz segment means and
     // the energy gate.  No filtered signal is written; the spectrogram kernels recompute the segments they transform.
-    DSP_HIP(dsp::launch_iir2_ckpt(d_x, clips, n, stride, bp, mp, g_cls.d_ck_bp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, g_cls.d_tab, st));
+    DSP_HIP(dsp::launch_iir2_ckpt(d_x, clips, n, stride, bp, mp, g_cls.d_ck_bp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, g_cls.d_tab, st, g_cls.d_simd));
     // midpoints first (1000-3000 Hz map, as flags, gated frames only); the 3000-7500 Hz spectrogram and its band sums only for
     // clips that have midpoints
     DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, mp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, nullptr, g_cls.d_tab,

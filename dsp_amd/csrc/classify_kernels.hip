@@ -427,7 +427,8 @@ template <bool EVEN_B, bool DUAL>
 __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride,
                                                         const IirCoef c_bp, const IirCoef c_mp, float *__restrict__ ck_bp,
                                                         float *__restrict__ ck_mp, float *__restrict__ means_mp,
-                                                        int *__restrict__ want_mp, const SpecTables *__restrict__ tab, int vec_ok)
+                                                        int *__restrict__ want_mp, const SpecTables *__restrict__ tab, int vec_ok, int *__restrict__ simd_load,
+                                                        int blocks_per_cu)
 {
     __shared__ float tin[2][64 * IIR_LD];
     __shared__ float vbuf[2][64 * IIR_LD];             // v tiles of the 1000-3000 Hz filter, [tile parity]
@@ -435,8 +436,44 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float
     // (8 % in the bench workload) are ever recomputed, so only their states go to HBM (4.1 of the 4.5 KB per clip and filter
     // stay on chip).  Three entries are live at most: start of segment k (by parity), its middle, start of segment k + 1.
     __shared__ float ckbuf[DUAL ? 1 : 3][8][64];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Which wave takes which part (wv: 0 = 3000-7500 Hz recurrence, 1 = 1000-3000 Hz recurrence, 2 = taps) follows the load of the
+    // SIMD it landed on.  49 152 clips are three 3-wave blocks per CU: nine waves on four SIMDs, 3/2/2/2, every block with one wave
+    // on the crowded SIMD -- and every block runs at that SIMD's pace (two recurrences and a taps wave there: 153 cycles per sample
+    // against ~115 for a recurrence wave with one neighbour).  The dispatcher places each wave on the least-loaded SIMD, so WHICH
+    // SIMD is crowded differs from CU to CU (tools/micro/hwid.hip): the waves of a launch count themselves into simd_load[CU][SIMD]
+    // (HW_ID / XCC_ID), wait until the CU's other blocks have done the same, and each block gives the TAPS -- a tile behind, the
+    // shorter dependent chains -- to its wave on the most loaded SIMD (ties go round by the block's arrival number), so a crowded
+    // SIMD holds taps waves and no recurrence wave has more than one neighbour.  Scheduling only: what a part computes does not
+    // depend on the wave that runs it, and a block that reads the table too early merely keeps a poorer choice.
+    int wv = wib;
+    if (!DUAL && simd_load != nullptr) {
+        __shared__ int s_simd[3], s_taps;
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;     // HW_ID, XCC_ID
+        int *row = simd_load + (((xcc << 8) | ((hw >> 8) & 0xFFu)) & (kSimdLoadCus - 1)) * kSimdLoadStride;       // (XCC, SE, SH, CU)
+        if (lane == 0) {
+            const int before = atomicAdd(row + ((hw >> 4) & 3u), 1);                // returning form: complete before the barrier below
+            s_simd[wib] = (int)((hw >> 4) & 3u) + (before & 0);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int arrival = atomicAdd(row + 4, 1);                               // every wave of this block is in the table
+            // wait until the CU's share of the launch has registered (blocks of a launch are dispatched within microseconds of each
+            // other and all fit: no block waits for one that cannot start), at most ~60 us; then decide
+            for (int i = 0; i < 64 && atomicAdd(row + 4, 0) < blocks_per_cu; ++i) __builtin_amdgcn_s_sleep(32);
+            int cnt[3], mx = -1, n_tied = 0;
+            for (int w = 0; w < 3; ++w) { cnt[w] = atomicAdd(row + s_simd[w], 0); mx = cnt[w] > mx ? cnt[w] : mx; }
+            for (int w = 0; w < 3; ++w) n_tied += cnt[w] == mx;
+            int pick = arrival % n_tied, tw = 2;
+            for (int w = 0; w < 3; ++w) if (cnt[w] == mx && pick-- == 0) tw = w;
+            s_taps = tw;
+        }
+        __syncthreads();
+        const int tw = s_taps;
+        wv = __builtin_amdgcn_readfirstlane(wib == tw ? 2 : (wib < tw ? wib : wib - 1));
+    }
+    const int tid = wv * 64 + lane;                     // thread number by part: the 128 recurrence threads stage the x tiles
     const bool is_r = DUAL ? wv == 0 : wv < 2;          // runs a recurrence (DUAL: both)
     const bool is_t = DUAL ? wv == 1 : wv == 2;         // runs the 1000-3000 Hz taps
     const bool loader = DUAL ? true : wv < 2;           // the 128 threads that stage the x tiles
@@ -658,8 +695,19 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float
 static bool even_taps_only(const IirCoef &c) { return c.b[1] == 0.0f && c.b[3] == 0.0f && c.b[5] == 0.0f && c.b[7] == 0.0f; }
 
 hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
-                            float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream)
+                            float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream,
+                            int *simd_load)
 {
+    static const bool simd_aware = [] { const char *e = std::getenv("DSP_AMD_CKPT_SIMD_AWARE"); return !e || std::atoi(e) != 0; }();      // 0: fixed parts (A/B runs)
+    const int blocks = (int)((n_clips + 63) / 64);
+    // worth its ~10 us (table reset, the blocks' wait) only when CUs hold three or more blocks: up to two blocks per CU every
+    // recurrence wave has at most one neighbour anyway (measured: 12 288 clips +0.03 ms, 24 576 +-0, 49 152 -0.13 ms, 131 072 -0.33 ms)
+    static const int n_cu = [] { int dev = 0, n = 0; return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256; }();
+    if (!simd_aware || blocks <= 2 * n_cu) simd_load = nullptr;
+    if (simd_load) {
+        hipError_t e = hipMemsetAsync(simd_load, 0, sizeof(int) * kSimdLoadCus * kSimdLoadStride, stream);
+        if (e != hipSuccess) return e;
+    }
     if (n_clips <= 0 || n <= 0) return hipSuccess;
     {
         const long n_seg = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
@@ -667,15 +715,14 @@ hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, co
         hipError_t e = hipMemsetAsync(want_mp, 0, sizeof(int), stream);
         if (e != hipSuccess) return e;
     }
-    const int blocks = (int)((n_clips + 63) / 64);
     const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
     constexpr bool dual = DSP_CKPT_DUAL != 0;
     if (even_taps_only(c_mp))
         hipLaunchKernelGGL((iir2_ckpt_kernel<true, dual>), dim3(blocks), dim3(dual ? 128 : 192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp,
-                           means_mp, want_mp, tables, vec_ok);
+                           means_mp, want_mp, tables, vec_ok, simd_load, blocks / n_cu);
     else
         hipLaunchKernelGGL((iir2_ckpt_kernel<false, dual>), dim3(blocks), dim3(dual ? 128 : 192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp,
-                           means_mp, want_mp, tables, vec_ok);
+                           means_mp, want_mp, tables, vec_ok, simd_load, blocks / n_cu);
     return hipGetLastError();
 }
 

@@ -64,8 +64,12 @@ hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long strid
 // the segment) and, as the second entry, v[224k+127 .. 224k+120] (restart state of its second half), means_mp[c][k] = mean of the 1000-3000 Hz output over the segment (classifier.cpp:329-333), want_mp = work list
 // (want_mp[0] = count, then frame numbers c * n_seg + k, 1 + n_clips * n_seg ints) of the segments whose energy does NOT prove
 // that every PSD cell stays below SpecTables::mp_keep_min -- the only ones the flag spectrogram has to transform.
+// simd_load (optional, kSimdLoadCus * kSimdLoadStride ints, zeroed by the launch): per (XCC, SE, SH, CU) the waves of this launch on
+// each SIMD + a block counter; lets every block put its taps wave on its CU's most loaded SIMD (scheduling only, see the kernel).
+constexpr int kSimdLoadCus = 4096, kSimdLoadStride = 8;
 hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
-                            float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream);
+                            float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream,
+                            int *simd_load = nullptr);
 // Spectrogram of segments recomputed from those checkpoints (filter c, checkpoints ck: ck_mp's layout for flags = true, ck_bp's
 // otherwise).  flags = true: out = int loud[c][T]
 // (1 = some cell >= mp_keep_min; 0 for every segment not on `wantlist`), means = means_mp; flags = false: out = PSD
