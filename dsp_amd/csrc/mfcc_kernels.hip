@@ -315,6 +315,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 #pragma unroll
             for (int j = 0; j < 4; ++j) etile[(16 * ct + 4 * q + j) * 16 + n] = d[ct][j];
         wave_lds_sync();
+#ifdef DSP_DIAG_NO_POOL     // timing-only probe: what the float64 pooling of a tile costs
+        if (count < 0)
+#endif
         if (lane < n_mfcc) {
 #pragma clang fp contract(off)
             double pool_s = pool_acc[2 * lane], pool_q = pool_acc[2 * lane + 1];
@@ -351,6 +354,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         }
         wave_lds_sync();
         float term = 0.0f;                                   // same arithmetic as svm_kernel (svm_kernels.hip)
+#ifdef DSP_DIAG_NO_SVM      // timing-only probe: what the per-clip support-vector loop costs
+        if (m.n_sv < 0)
+#endif
         for (int sidx = lane; sidx < m.n_sv; sidx += 64) {
             const float *sv = m.sv + (long)sidx * m.n_features;
             float d2 = 0.0f;
