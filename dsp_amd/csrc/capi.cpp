@@ -286,7 +286,7 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
                             cfg->prefilter == DSP_PREFILTER_BUTTER_1000_3000 ? 3000 : 7500, b, a);
         dsp::PrefilterScan sc;
         if (!dsp::build_prefilter_scan(b, a, sc, why)) { dsp_mfcc_plan_destroy(p); return fail(DSP_EINVAL, why); }
-        if (sc.c_ok) {      // the kernel runs the cascade form; coefficients without it (none of the two literal sets) take the two-pass path
+        if (sc.c_ok && (!DSP_PRE_ROWSCAN || sc.c_row_ok)) {      // the kernel runs the cascade form (its scan in row form); coefficients without it (none of the two literal sets) take the two-pass path
             e = hipMalloc(&p->d_scan, sizeof(sc));
             if (e == hipSuccess) e = hipMemcpy(p->d_scan, &sc, sizeof(sc), hipMemcpyHostToDevice);
             for (int k = 0; k < 4; ++k) p->scan_steps[k] = sc.c_steps[k];

@@ -169,7 +169,8 @@ __device__ __forceinline__ float shfl_lane<float>(float v, int byte_addr)
 #ifndef DSP_PRE_DPP1
 #define DSP_PRE_DPP1 1
 #endif
-__device__ __forceinline__ int dpp_up1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false); }
+// (bound_ctrl: lane 0, which has no source lane, reads 0 -- no v_mov of an `old` value in front of every move)
+__device__ __forceinline__ int dpp_up1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }
 template <typename T>
 __device__ __forceinline__ T shfl_up1(T v);
 template <>
@@ -182,6 +183,27 @@ __device__ __forceinline__ double shfl_up1<double>(double v)
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
+// DPP moves of a float / double: lanes without a source lane read 0 (bound_ctrl)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov0(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true)); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov0(double v)
+{
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, 0xF, 0xF, true);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+constexpr int kDppRowShr = 0x110;
+// lane 15 of every row to all lanes of the next row; row 0 reads 0 (row_mask 0xE over an `old` of 0: with all rows enabled, row 0
+// passes its own values through, bound_ctrl or not -- tools/micro/dpp_probe.hip)
+__device__ __forceinline__ float dpp_bcast15(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xE, 0xF, false)); }
+__device__ __forceinline__ double dpp_bcast15(double v)
+{
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, 0x142, 0xE, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), 0x142, 0xE, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
 // fused multiply-add in T (__builtin_fma alone is the float64 builtin: on float operands it converts, runs v_fma_f64 and converts back)
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -190,7 +212,7 @@ __device__ __forceinline__ float fma_t(float a, float b, float c) { return __bui
 // instantiation each; more steps than the poles need multiply by matrices below the tolerance and are harmless): the section is
 // straight-line code without a branch, so that it can share a scheduling region with the transform of the previous frame.
 template <typename T, int STEPS>
-__device__ __forceinline__ void cascade_section(T (&u)[kScanChunk], T a1, T a2, const T (*pw)[4][4], int sc, int lane)
+__device__ __forceinline__ void cascade_section(T (&u)[kScanChunk], T a1, T a2, const T (*pw)[4][4], int sc, int lane, const T (&rowm)[4])
 {
     // pass 1: the chunk from zero state -> its own contribution to the state (w[n-1], w[n-2]) at its end
     T t0 = 0, t1 = 0;
@@ -200,6 +222,29 @@ __device__ __forceinline__ void cascade_section(T (&u)[kScanChunk], T a1, T a2, 
         t1 = t0;
         t0 = w0;
     }
+#if DSP_PRE_ROWSCAN
+    // Row form of the inclusive scan (tables.hpp): Kogge-Stone inside each 16-lane row with DPP row_shr moves -- no LDS crossbar,
+    // no select (a lane without a source reads 0: n = t + 0 exactly) --, then lane (r, j) adds M^(16 (j + 1)) (rowm, per lane) times
+    // lane 15 of row r - 1 (DPP row_bcast:15; row 0 reads 0).  A second such step reaches two rows back (sections of 5 steps).
+    {
+        constexpr int RS = scan_row_steps(STEPS), RR = scan_row_rounds(STEPS);
+        auto step = [&](T u0, T u1, const T *m) {
+            t0 = fma_t(m[1], u1, fma_t(m[0], u0, t0));
+            t1 = fma_t(m[3], u1, fma_t(m[2], u0, t1));
+        };
+        if (RS > 0) step(dpp_mov0<kDppRowShr + 1>(t0), dpp_mov0<kDppRowShr + 1>(t1), pw[0][sc]);
+        if (RS > 1) step(dpp_mov0<kDppRowShr + 2>(t0), dpp_mov0<kDppRowShr + 2>(t1), pw[1][sc]);
+        if (RS > 2) step(dpp_mov0<kDppRowShr + 4>(t0), dpp_mov0<kDppRowShr + 4>(t1), pw[2][sc]);
+        if (RS > 3) step(dpp_mov0<kDppRowShr + 8>(t0), dpp_mov0<kDppRowShr + 8>(t1), pw[3][sc]);
+        const T w0 = t0, w1 = t1;                    // the lane's own row
+#pragma unroll
+        for (int r = 0; r < RR; ++r) {
+            const T c0 = dpp_bcast15(t0), c1 = dpp_bcast15(t1);
+            t0 = fma_t(rowm[1], c1, fma_t(rowm[0], c0, w0));
+            t1 = fma_t(rowm[3], c1, fma_t(rowm[2], c0, w1));
+        }
+    }
+#else
     // inclusive scan over the lanes
 #pragma unroll
     for (int d = 0; d < STEPS; ++d) {
@@ -215,6 +260,7 @@ __device__ __forceinline__ void cascade_section(T (&u)[kScanChunk], T a1, T a2, 
             t1 = on ? n1 : t1;
         }
     }
+#endif
     // a chunk starts from the scan value of the lane before it (zero for lane 0)
     {
         const int from = ((lane - 1) & 63) << 2;
@@ -237,9 +283,11 @@ __device__ __forceinline__ void cascade_section(T (&u)[kScanChunk], T a1, T a2, 
 #define DSP_PRE_DIAG 0
 #endif
 // wc != nullptr: the lane's 16 window values in chunk order (GenTables1024::win_chunk), multiplied into the output here
+// the per-lane matrices of the row form's cross-row step (PrefilterScan::c_rowm / c_rowmf at j = lane % 16): 24 VGPRs, loaded once
+struct RowMats { double d[2][4]; float f[2][4]; };
 template <int S0, int S1, int S2, int S3>
 __device__ __forceinline__ void prefilter_cascade(const float (&x)[kScanChunk], float (&y)[kScanChunk], const PrefilterScan *__restrict__ S, int lane,
-                                                  const float *__restrict__ wc = nullptr)
+                                                  const RowMats &rm, const float *__restrict__ wc = nullptr)
 {
 #if DSP_PRE_DIAG == 1
     for (int i = 0; i < kScanChunk; ++i) y[i] = x[i];
@@ -248,13 +296,13 @@ __device__ __forceinline__ void prefilter_cascade(const float (&x)[kScanChunk], 
     double ud[kScanChunk];
 #pragma unroll
     for (int i = 0; i < kScanChunk; ++i) ud[i] = (double)x[i];
-    cascade_section<double, S0>(ud, S->c_a1[0], S->c_a2[0], S->c_pw, 0, lane);
-    cascade_section<double, S1>(ud, S->c_a1[1], S->c_a2[1], S->c_pw, 1, lane);
+    cascade_section<double, S0>(ud, S->c_a1[0], S->c_a2[0], S->c_pw, 0, lane, rm.d[0]);
+    cascade_section<double, S1>(ud, S->c_a1[1], S->c_a2[1], S->c_pw, 1, lane, rm.d[1]);
     float uf[kScanChunk];
 #pragma unroll
     for (int i = 0; i < kScanChunk; ++i) uf[i] = (float)ud[i];
-    cascade_section<float, S2>(uf, S->c_a1f[2], S->c_a2f[2], S->c_pwf, 2, lane);
-    cascade_section<float, S3>(uf, S->c_a1f[3], S->c_a2f[3], S->c_pwf, 3, lane);
+    cascade_section<float, S2>(uf, S->c_a1f[2], S->c_a2f[2], S->c_pwf, 2, lane, rm.f[0]);
+    cascade_section<float, S3>(uf, S->c_a1f[3], S->c_a2f[3], S->c_pwf, 3, lane, rm.f[1]);
     const float g = (float)S->c_gain;
     if (wc) {
         f4v w4[4];
@@ -454,12 +502,20 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
 #endif
     float ys[kScanChunk];
     (void)ys;
+    RowMats rowm = {};
+    if (PRE && DSP_PRE_ROWSCAN) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rowm.d[0][k] = S->c_rowm[0][lane & 15][k]; rowm.d[1][k] = S->c_rowm[1][lane & 15][k];
+            rowm.f[0][k] = S->c_rowmf[2][lane & 15][k]; rowm.f[1][k] = S->c_rowmf[3][lane & 15][k];
+        }
+    }
     auto filter_next = [&](float (&out)[kScanChunk]) {
         float xs[kScanChunk];
 #pragma unroll
         for (int a = 0; a < 8; ++a) { xs[2 * a] = nxt[a].x; xs[2 * a + 1] = nxt[a].y; }
 #if DSP_PRE_CASCADE
-        prefilter_cascade<PS0, PS1, PS2, PS3>(xs, out, S, lane, W3 ? &G->win_chunk[lane][0] : nullptr);
+        prefilter_cascade<PS0, PS1, PS2, PS3>(xs, out, S, lane, rowm, W3 ? &G->win_chunk[lane][0] : nullptr);
 #else
         prefilter_scan(xs, out, S, lane);
 #endif

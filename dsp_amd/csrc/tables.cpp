@@ -298,6 +298,7 @@ bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &o
 
     // ---- cascade form (see tables.hpp) ---------------------------------------------------------------------------------
     out.c_ok = 0;
+    out.c_row_ok = 0;
     {
         const double g = b[0], pat[9] = {1, 0, -4, 0, 6, 0, -4, 0, 1};
         bool binom = g != 0.0;
@@ -348,6 +349,61 @@ bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &o
             double cerr = 0;
             for (int n = 0; n < 1024; ++n) cerr = std::max(cerr, std::fabs(g * u[n] - yref[n]));
             out.c_ok = cerr <= 1e-9 * top ? 1 : 0;      // float64 scan steps stop at 1e-13 of the state: 1e-9 leaves room, a wrong table misses by orders
+
+            // ---- row form of the scan: per-lane matrices M^(16 (j + 1)) and the same self-check ------------------------------
+            for (int s = 0; s < 4; ++s) {
+                double m16[4], pwr[4];
+                for (int k = 0; k < 4; ++k) m16[k] = pwr[k] = out.c_pw[0][s][k];                 // M^16
+                for (int j = 0; j < 16; ++j) {
+                    for (int k = 0; k < 4; ++k) { out.c_rowm[s][j][k] = pwr[k]; out.c_rowmf[s][j][k] = (float)pwr[k]; }
+                    const double t[4] = {pwr[0] * m16[0] + pwr[1] * m16[2], pwr[0] * m16[1] + pwr[1] * m16[3],
+                                         pwr[2] * m16[0] + pwr[3] * m16[2], pwr[2] * m16[1] + pwr[3] * m16[3]};
+                    for (int k = 0; k < 4; ++k) pwr[k] = t[k];
+                }
+            }
+            for (int n = 0; n < 1024; ++n) u[n] = x[n];
+            for (int s = 0; s < 4; ++s) {
+                double T[64][2], v[1024];
+                for (int l = 0; l < 64; ++l) {
+                    double w1 = 0, w2 = 0;
+                    for (int i = 0; i < kScanChunk; ++i) { const double w0 = u[16 * l + i] - out.c_a1[s] * w1 - out.c_a2[s] * w2; w2 = w1; w1 = w0; }
+                    T[l][0] = w1; T[l][1] = w2;
+                }
+                for (int d = 0; d < scan_row_steps(out.c_steps[s]); ++d) {                         // inside each row
+                    const double *m = out.c_pw[d][s];
+                    for (int l = 63; l >= 0; --l) {
+                        if ((l & 15) < (1 << d)) continue;
+                        const double u0 = T[l - (1 << d)][0], u1 = T[l - (1 << d)][1];
+                        T[l][0] += m[0] * u0 + m[1] * u1;
+                        T[l][1] += m[2] * u0 + m[3] * u1;
+                    }
+                }
+                double W[64][2], C[64][2];
+                for (int l = 0; l < 64; ++l) { W[l][0] = C[l][0] = T[l][0]; W[l][1] = C[l][1] = T[l][1]; }
+                for (int round = 0; round < scan_row_rounds(out.c_steps[s]); ++round) {           // across rows
+                    double N[64][2];
+                    for (int l = 0; l < 64; ++l) {
+                        const int r = l >> 4, j = l & 15;
+                        const double u0 = r ? C[16 * r - 1][0] : 0.0, u1 = r ? C[16 * r - 1][1] : 0.0;
+                        const double *m = out.c_rowm[s][j];
+                        N[l][0] = W[l][0] + m[0] * u0 + m[1] * u1;
+                        N[l][1] = W[l][1] + m[2] * u0 + m[3] * u1;
+                    }
+                    for (int l = 0; l < 64; ++l) { C[l][0] = N[l][0]; C[l][1] = N[l][1]; }
+                }
+                for (int l = 0; l < 64; ++l) {
+                    double w1 = l ? C[l - 1][0] : 0.0, w2 = l ? C[l - 1][1] : 0.0;
+                    for (int i = 0; i < kScanChunk; ++i) {
+                        const double w0 = u[16 * l + i] - out.c_a1[s] * w1 - out.c_a2[s] * w2;
+                        v[16 * l + i] = w0 - w2;
+                        w2 = w1; w1 = w0;
+                    }
+                }
+                for (int n = 0; n < 1024; ++n) u[n] = v[n];
+            }
+            double rerr = 0;
+            for (int n = 0; n < 1024; ++n) rerr = std::max(rerr, std::fabs(g * u[n] - yref[n]));
+            out.c_row_ok = rerr <= 1e-9 * top ? 1 : 0;
         }
     }
     return true;

@@ -176,7 +176,21 @@ struct PrefilterScan {
     float c_pwf[6][4][4];
     int32_t c_steps[4];            // scan steps per section: float64 sections to 1e-13, float32 sections to 1e-9
     int32_t c_ok;                  // 0: the numerator is not g (1 - z^-2)^4 -> the kernel runs the parallel form
+    // Row form of the same scan (the kernel's DSP_PRE_ROWSCAN): Kogge-Stone steps of 1, 2, 4, 8 lanes INSIDE each 16-lane row
+    // (DPP row_shr moves: no LDS crossbar, lanes without a source read 0), then one "cross-row" step per row that still matters:
+    // lane (r, j) adds c_rowm[s][j] = M_s^(16 (j + 1)) times the value of lane 15 of row r - 1 (DPP row_bcast:15).  After the first
+    // such step lane 15 of a row holds its row's total plus M^256 times the previous row's, so a second step reaches two rows back.
+    double c_rowm[4][16][4];
+    float c_rowmf[4][16][4];
+    int32_t c_row_ok;              // the row form reproduces the direct form (self-check of the algebra in double)
 };
+// 1: mfcc1024_wave_kernel<PRE> runs the row form (plans need c_row_ok); 0: the wave-wide Kogge-Stone scan (A/B builds)
+#ifndef DSP_PRE_ROWSCAN
+#define DSP_PRE_ROWSCAN 1
+#endif
+// steps inside a row and cross-row steps of the row form for a section whose lane scan needs `steps` Kogge-Stone steps
+constexpr int scan_row_steps(int steps) { return steps < 4 ? steps : 4; }
+constexpr int scan_row_rounds(int steps) { return steps <= 4 ? 1 : steps - 3; }      // 5 -> 2 (32 chunks back), 6 -> 3 (the whole wave)
 constexpr int kScanChunk = 16;     // samples per lane: 64 lanes x 16 = one 1024-sample frame
 bool build_prefilter_scan(const double b[9], const double a[9], PrefilterScan &out, std::string &why);
 
