@@ -504,6 +504,11 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float
     float cur = 0.0f, prev = 0.0f;
     const bool gating = tab->gate_ok != 0;
     float ea_cur = 0.0f, eb_cur = 0.0f, ea_prev = 0.0f, eb_prev = 0.0f;
+    // The gate's B = sum w^2 y of a segment: in the six tiles where the window is 1 it is the same sum as `cur`, so only the tapered
+    // first tile is accumulated (eb_cur) and the flat part is taken as cur - c_first when the segment closes (c_first = `cur` after
+    // the first tile): one instruction per sample less on the taps wave.  B only enters an upper bound with 1 % margin; the
+    // difference of two running sums is within a few ulp of sum |y| of the separately accumulated value.
+    float c_first = 0.0f;
 
     // x tiles: the 128 recurrence threads load them (4 float4 each per full tile), one tile ahead in registers.  (Two tiles
     // ahead in a second register set measured slower, 1.50 vs 1.34 ms per 49 152 clips: the kernel is bound by VALU issue --
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float
             const int ti = s - 1, seg_k = ti / kTilesPerHop;
             const bool seg_start = ti % kTilesPerHop == 0;
             const bool seg_both = seg_start && seg_k >= 1;           // the tile also closes segment seg_k - 1
-            if (seg_start) { prev = cur; cur = 0.0f; ea_prev = ea_cur; eb_prev = eb_cur; ea_cur = eb_cur = 0.0f; }
+            if (seg_start) { prev = cur; ea_prev = ea_cur; eb_prev = eb_cur + (cur - c_first); cur = 0.0f; ea_cur = eb_cur = 0.0f; }
             if (lane < rows && cols == IIR_TS) {
 #pragma unroll
                 for (int h = 0; h < IIR_TS; h += IIR_BURST) {
@@ -665,10 +670,11 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float
                             }
                         } else {                                     // the window is 1 here
 #pragma unroll
-                            for (int i = 0; i < IIR_BURST; ++i) { ea_cur = fmaf(orr[i], orr[i], ea_cur); eb_cur = eb_cur + orr[i]; }
+                            for (int i = 0; i < IIR_BURST; ++i) ea_cur = fmaf(orr[i], orr[i], ea_cur);
                         }
                     }
                 }
+                if (seg_start) c_first = cur;
                 if (seg_both && seg_k - 1 < n_seg) {
                     const float m = prev / (float)kSpecSeg;
                     means_mp[(clip0 + lane) * n_seg + seg_k - 1] = m;
@@ -707,12 +713,14 @@ hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, co
                             float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream,
                             int *simd_load)
 {
-    static const bool simd_aware = [] { const char *e = std::getenv("DSP_AMD_CKPT_SIMD_AWARE"); return !e || std::atoi(e) != 0; }();      // 0: fixed parts (A/B runs)
+    // DSP_AMD_CKPT_SIMD_AWARE: 0 = fixed parts (A/B runs), 2 = the table for every launch whatever its size (tests)
+    static const int simd_mode = [] { const char *e = std::getenv("DSP_AMD_CKPT_SIMD_AWARE"); return e ? std::atoi(e) : 1; }();
+    const bool simd_aware = simd_mode != 0;
     const int blocks = (int)((n_clips + 63) / 64);
     // worth its ~10 us (table reset, the blocks' wait) only when CUs hold three or more blocks: up to two blocks per CU every
     // recurrence wave has at most one neighbour anyway (measured: 12 288 clips +0.03 ms, 24 576 +-0, 49 152 -0.13 ms, 131 072 -0.33 ms)
     static const int n_cu = [] { int dev = 0, n = 0; return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256; }();
-    if (!simd_aware || blocks <= 2 * n_cu) simd_load = nullptr;
+    if (!simd_aware || (blocks <= 2 * n_cu && simd_mode != 2)) simd_load = nullptr;
     if (simd_load) {
         hipError_t e = hipMemsetAsync(simd_load, 0, sizeof(int) * kSimdLoadCus * kSimdLoadStride, stream);
         if (e != hipSuccess) return e;

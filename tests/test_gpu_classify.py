@@ -313,3 +313,39 @@ def test_donut_classifier_recordings(dsp, golden):
             labels, trace = dsp.classify_batch(x[None, :], with_trace=True, config=dsp.classify_config(getattr(dsp, cname)))
             olab, omids, osums = O.classify(x, getattr(O, cname))
             assert labels[0] == olab and np.array_equal(trace[0][0], omids) and np.array_equal(trace[0][1], osums), (n, cname)
+
+
+def test_simd_aware_parts_of_the_checkpoint_kernel_change_nothing(dsp, golden, tmp_path):
+    """iir2_ckpt_kernel gives the taps to whichever wave sits on its CU's most loaded SIMD (a table the launch fills itself;
+    launches of more than two blocks per CU only).  DSP_AMD_CKPT_SIMD_AWARE=2 forces the table for every launch: a child process
+    runs a shuffled batch that way, and labels, midpoints and band sums must equal this process's (fixed parts at this size)."""
+    import os
+    import subprocess
+    import sys
+    g = golden("classifier_ref.npz")
+    base = np.stack([g[f"{n}__input"] for n in CASES])
+    order = np.random.default_rng(5).integers(0, len(CASES), 700)            # 11 blocks of 64 clips
+    clips = base[order]
+    labels, trace = dsp.classify_batch(clips, with_trace=True)
+    src = tmp_path / "clips.npy"
+    out = tmp_path / "forced.npz"
+    np.save(src, clips)
+    code = (
+        "import sys, numpy as np\n"
+        "import dsp_amd\n"
+        f"clips = np.load({str(src)!r})\n"
+        "labels, trace = dsp_amd.classify_batch(clips, with_trace=True)\n"
+        "mids = np.concatenate([np.asarray(m, np.float32).ravel() for m, _ in trace] + [np.zeros(0, np.float32)])\n"
+        "sums = np.concatenate([np.asarray(s, np.float32).ravel() for _, s in trace] + [np.zeros(0, np.float32)])\n"
+        "counts = np.array([len(m) for m, _ in trace])\n"
+        f"np.savez({str(out)!r}, labels=labels, mids=mids, sums=sums, counts=counts)\n"
+    )
+    env = dict(os.environ, DSP_AMD_CKPT_SIMD_AWARE="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    f = np.load(out)
+    assert np.array_equal(f["labels"], labels) and set(labels) == {0, 1}
+    assert np.array_equal(f["counts"], np.array([len(m) for m, _ in trace]))
+    assert np.array_equal(f["mids"], np.concatenate([np.asarray(m, np.float32).ravel() for m, _ in trace]))
+    assert np.array_equal(f["sums"], np.concatenate([np.asarray(s, np.float32).ravel() for _, s in trace]))
