@@ -20,6 +20,9 @@
 #include "svm_kernels.hpp"
 #include "tables.hpp"
 
+#ifdef DSP_PF_STAMPS
+namespace dsp { hipError_t read_pf_stamps(unsigned long long *host, int count); }      // mfcc_kernels.hip, diagnostic builds
+#endif
 #ifdef DSP_RC_STAMPS
 namespace dsp { hipError_t read_rc_stamps(unsigned long long *host, int count); hipError_t read_bd_stamps(unsigned long long *host, int count); }      // classify_kernels.hip, diagnostic builds
 #endif
@@ -880,6 +883,14 @@ int dsp_compute_spectrogram_f64(const double *signal, int n, int fs, double *fre
     return T;
 }
 
+#ifdef DSP_PF_STAMPS
+__attribute__((visibility("default"))) int dsp_debug_pf_stamps(unsigned long long *out, int count)     // tools/pf_stamps.py
+{
+    DSP_HIP(hipDeviceSynchronize());
+    DSP_HIP(dsp::read_pf_stamps(out, count));
+    return DSP_OK;
+}
+#endif
 #ifdef DSP_RC_STAMPS
 __attribute__((visibility("default"))) int dsp_debug_rc_stamps(unsigned long long *out, int count)     // diagnostic builds only (tools/rc_stamps.py)
 {

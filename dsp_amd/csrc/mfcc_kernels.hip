@@ -77,6 +77,16 @@
 
 namespace dsp {
 
+// Diagnostic build only (-DDSP_PF_STAMPS, never shipped): s_memtime at the stations of the fused kernel's clip tail (pool_finish),
+// written by lane 0 of the first 1024 waves for their last clip; tools/pf_stamps.py prints the medians.
+#ifdef DSP_PF_STAMPS
+__device__ unsigned long long g_pf_stamps[8 * 1024];
+#define PF_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) g_pf_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+hipError_t read_pf_stamps(unsigned long long *host, int count) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pf_stamps), sizeof(unsigned long long) * (size_t)count); }
+#else
+#define PF_STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 // IN: element type of the input in HBM (SURVEY.md 8f-1, PCM16 ingestion on device):
@@ -141,6 +151,17 @@ __device__ __forceinline__ c32 unpack_pcm16(c32 raw)
 }
 
 }  // namespace
+
+// the kernel's argument struct where the hardware put it (the kernarg segment; Mfcc512Args is the only parameter): a pointer the
+// cold per-clip code reloads model fields through, instead of keeping them in SGPRs across the frame loop
+__device__ __forceinline__ const Mfcc512Args *kernarg_of_mfcc512()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (const Mfcc512Args *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return nullptr;      // host pass of the single-source compile: never called
+#endif
+}
 
 // DCT_SPLIT lanes per coefficient, DCT_LEN log-mel values per lane.  GATHER: partial
 // sums per mel filter.  FLEN: frame_length at compile time (512, the reference's 400) or 0 = run time (tail predicate on the loads).
@@ -290,6 +311,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
     // lane, and a dependent chain of global loads there would cost tens of microseconds per clip
     float *stop_small = reinterpret_cast<float *>(smem + 4 * WAVE_BYTES) + (TILE && !A_IN_REGS ? CT * KS * 64 : 0);
     (void)stop_small;
+    // POOL = 1: the Scaler's offset | scale and the SVM's coefficients in a block-shared LDS copy (the clip's tail read them with
+    // dependent global loads, each behind an s_waitcnt vmcnt(0) that also drained the frame prefetch ring: the fused kernel lost
+    // 13 % to pool_finish, of which the arithmetic -- support vectors and libsvm's tail -- was a quarter)
+    float *svm_small = stop_small;
+    (void)svm_small;
+    if (POOL == 1) {
+        const SvmModelDev &m = args.pool.svm;
+        for (int i = threadIdx.x; i < m.n_features; i += 256) { svm_small[i] = m.offset[i]; svm_small[m.n_features + i] = m.scale[i]; }
+        for (int i = threadIdx.x; i < m.n_sv; i += 256) svm_small[2 * m.n_features + i] = m.coef[i];
+        __syncthreads();
+    }
     if (POOL == 2) {
 #pragma unroll
         for (int j = 0; j < kStopFusedUnits; ++j) pool_acc[kStopFusedUnits * lane + j] = 0.0;
@@ -331,10 +363,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         pool_t += count;
         wave_lds_sync();
     };
+    // (Out of line as a __noinline__ function -- to take its 44 SGPRs, 9 of them spilled, and 1 300 cold instructions out of the
+    // frame loop -- the call's register saves went to scratch INSIDE the loop: 62 VGPRs spilled, 30 ms instead of 5.1.  It stays inline.)
     auto pool_finish = [&](long clip) {
 #pragma clang fp contract(off)
-        const SvmModelDev &m = args.pool.svm;
-        float *z = etile;                                    // 2 * n_mfcc standardised features
+        // the kernel arguments through an opaque pointer: the model's fields and the output pointers are (re)loaded HERE, once per
+        // clip -- hoisted to the kernel's entry they sat in 44 SGPRs across the frame loop, 9 of them spilled to VGPR lanes
+        // (the kernarg segment itself: taking &args would make the compiler copy the argument struct to scratch)
+        const Mfcc512Args *ap = kernarg_of_mfcc512();
+        asm volatile("" : "+s"(ap));
+        const PoolSvmArgs &pool = ap->pool;
+        const SvmModelDev &m = pool.svm;
+        PF_STAMP(0);
+        float *z = etile;                                        // 2 * n_mfcc standardised features
         // once per clip: every per-lane address below is formed HERE from an opaque copy of the lane number, so that the
         // compiler cannot hoist a dozen 64-bit addresses out of the frame loop and then spill them (it did: 12 VGPR spills)
         int lane = threadIdx.x & 63;
@@ -345,39 +386,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
             const double mean = pool_s / (double)pool_t;
             const double var = pool_q / (double)pool_t - mean * mean;
             const float f_mean = (float)mean, f_std = sqrtf((float)(var > 0 ? var : 0));
-            if (args.pool.feat) {
-                args.pool.feat[clip * 2L * n_mfcc + lane] = f_mean;
-                args.pool.feat[clip * 2L * n_mfcc + n_mfcc + lane] = f_std;
+            const float *off_l = svm_small, *scl_l = svm_small + m.n_features;
+            z[lane] = (f_mean - off_l[lane]) * scl_l[lane];
+            z[n_mfcc + lane] = (f_std - off_l[n_mfcc + lane]) * scl_l[n_mfcc + lane];
+            if (pool.feat) {                                     // stores last: nothing below waits for them
+                pool.feat[clip * 2L * n_mfcc + lane] = f_mean;
+                pool.feat[clip * 2L * n_mfcc + n_mfcc + lane] = f_std;
             }
-            z[lane] = (f_mean - m.offset[lane]) * m.scale[lane];
-            z[n_mfcc + lane] = (f_std - m.offset[n_mfcc + lane]) * m.scale[n_mfcc + lane];
         }
         wave_lds_sync();
-        float term = 0.0f;                                   // same arithmetic as svm_kernel (svm_kernels.hip)
+        PF_STAMP(1);
+        float term = 0.0f;                                       // same arithmetic as svm_kernel (svm_kernels.hip)
 #ifdef DSP_DIAG_NO_SVM      // timing-only probe: what the per-clip support-vector loop costs
         if (m.n_sv < 0)
 #endif
         for (int sidx = lane; sidx < m.n_sv; sidx += 64) {
             const float *sv = m.sv + (long)sidx * m.n_features;
             float d2 = 0.0f;
-            for (int j = 0; j < m.n_features; ++j) {
+            int j = 0;
+            for (; j + 8 <= m.n_features; j += 8) {              // eight loads in flight, then the same additions in the same order
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = sv[j + k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float dd = z[j + k] - v[k];
+                    d2 = d2 + dd * dd;
+                }
+            }
+            for (; j < m.n_features; ++j) {
                 const float dd = z[j] - sv[j];
                 d2 = d2 + dd * dd;
             }
-            term = term + m.coef[sidx] * expf(-m.gamma * d2);
+            term = term + svm_small[2 * m.n_features + sidx] * expf(-m.gamma * d2);
         }
+        PF_STAMP(2);
         for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o);
+        PF_STAMP(3);
         if (lane == 0) {
             const float score = term + m.rho;
             int label;
             float p1;
+#ifdef DSP_DIAG_NO_SVMTAIL      // timing-only probe: libsvm's label / probability tail on lane 0
+            label = score > 0; p1 = score;
+#else
             svm_binary_tail(score, m.prob_a, m.prob_b, label, p1);
-            args.pool.labels[clip] = label;
-            if (args.pool.decision) args.pool.decision[clip] = score;
-            if (args.pool.prob1) args.pool.prob1[clip] = p1;
+#endif
+            pool.labels[clip] = label;
+            if (pool.decision) pool.decision[clip] = score;
+            if (pool.prob1) pool.prob1[clip] = p1;
         }
-        pool_t = 0;
+        PF_STAMP(4);
         wave_lds_sync();
+        PF_STAMP(5);
+        pool_t = 0;
     };
     // ---- POOL = 2: the stop-word net's first layer accumulated tile by tile (audio_classifier_inference.c:18-36, 44-47) ----
     // lane (c = lane % 16, tq = lane / 16) takes coefficient c of the tile's frames 4 tq .. 4 tq + 3 -- input index
@@ -386,7 +448,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
     // division in the loop; the B terms of the live inputs are a per-T constant added at the end.  float64 sums: their order
     // shows at 1e-16; the folding moves a term by <= 1e-7 relative (the reference itself adds 6500 fp32 terms in sequence).
     auto stop_tile = [&](const f4v (&d)[CT], int count) {
-        const StopModelDev &m = args.stop.m;
+        const Mfcc512Args *ap = kernarg_of_mfcc512();          // the model's fields reloaded here, not held in SGPRs across the frame loop (pool_finish)
+        asm volatile("" : "+s"(ap));
+        const StopModelDev &m = ap->stop.m;
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));
         const int n = lane & 15, q = lane >> 4;
@@ -424,7 +488,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
     };
     auto stop_finish = [&](long clip) {
 #pragma clang fp contract(off)
-        const StopModelDev &m = args.stop.m;
+        const Mfcc512Args *ap = kernarg_of_mfcc512();
+        asm volatile("" : "+s"(ap));
+        const StopModelDev &m = ap->stop.m;
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));
         double acc[kStopFusedUnits];
@@ -459,7 +525,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
                 }
                 n_in = n_out;
             }
-            args.stop.prob[clip] = 1.0f / (1.0f + expf(-h[kStopMaxUnits]));     // :13-15 (layer 4's output sits in row 1)
+            ap->stop.prob[clip] = 1.0f / (1.0f + expf(-h[kStopMaxUnits]));     // :13-15 (layer 4's output sits in row 1)
         }
         pool_t = 0;
         wave_lds_sync();
@@ -525,6 +591,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) dd[ct] = acc[ct][0] + acc[ct][1];
             wave_lds_sync();                                 // every lane has read its tile column
+#ifdef DSP_DIAG_NO_POOLTILE     // timing-only probe: the walk and the tile epilogue of the fused kernel without its pooling
+            if (dd[0][0] == 123.456f) args.pool.labels[0] = 1;
+            return;
+#endif
             if (POOL == 2) { if constexpr (CT == 1) stop_tile(dd, count); }
             else pool_tile(dd, count);
             return;
@@ -714,8 +784,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
             if ((slot & 7) == 0) { if (slot == 0) fb0 = f; else fb1 = f; }
             etile[16 * lane + (slot ^ (lane >> 2))] = e;
             const bool clip_ends = POOL && last_f;
+            if (clip_ends) PF_STAMP(6);
             if (++slot == 16 || !more || clip_ends) { flush(slot); slot = 0; }
+#if !defined(DSP_DIAG_NO_POOLTILE) && !defined(DSP_DIAG_NO_POOLFINISH)
             if (clip_ends) { if (POOL == 2) stop_finish(clip_f); else pool_finish(clip_f); }
+#endif
             return more;
         }
 
@@ -792,7 +865,7 @@ static size_t lds_bytes(bool tile, int pool = 0, int stop_small_floats = 0)
 {
     constexpr int KS = S == 2 ? L / 2 : L, CT = S == 2 ? 2 : 1;
     return (size_t)4 * (LDS_WAVE_BYTES + (tile ? LDS_TILE_BYTES : 0) + (pool == 1 ? LDS_POOL_BYTES : (pool == 2 ? LDS_STOP_BYTES : 0))) +
-           (tile && (CT * KS > 10 || pool) ? (size_t)CT * KS * 64 * 4 : 0) + (pool == 2 ? (size_t)((stop_small_floats + 3) & ~3) * 4 : 0);
+           (tile && (CT * KS > 10 || pool) ? (size_t)CT * KS * 64 * 4 : 0) + (pool ? (size_t)((stop_small_floats + 3) & ~3) * 4 : 0);      // pool = 1: offset | scale | coef
 }
 
 static int stop_small_floats(const StopModelDev &m)
@@ -831,12 +904,12 @@ static hipError_t launch_one(const Mfcc512Args &args, bool clips, int blocks, hi
 hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream)
 {
     if (args.frames_per_clip <= 0 || args.chunk != args.frames_per_clip || args.log_mode != 0 || args.in_kind != 0 || !args.pool.labels ||
-        args.pool.svm.n_features != 2 * args.n_mfcc || args.pool.svm.n_features > 64)
+        args.pool.svm.n_features != 2 * args.n_mfcc || args.pool.svm.n_features > 64 || args.pool.svm.n_sv < 1 || args.pool.svm.n_sv > 2048)
         return hipErrorInvalidConfiguration;
     const dim3 g(blocks), b(256);
 #define DSP_LAUNCH_POOL(S, L, G)                                                                                            \
     if (dct_split == S && dct_len == L && gather == G) {                                                                    \
-        const size_t lds = lds_bytes<S, L>(true, 1);                                                                        \
+        const size_t lds = lds_bytes<S, L>(true, 1, 2 * args.pool.svm.n_features + args.pool.svm.n_sv);                    \
         const int flen = flen_of<S, L, G>(args.frame_len);                                                                  \
         if (flen == 512) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 512, 0, 1, true, 1>), g, b, lds, stream, args);   \
         else if (flen == 400) {                                                                                             \

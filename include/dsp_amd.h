@@ -285,7 +285,8 @@ int dsp_svm_predict_device(dsp_svm *svm, const float *d_feat, long n_clips, int 
 
 /* BASELINE config 5 in ONE kernel: clip -> MFCC(n_mfcc) -> mean | std -> Scaler -> RBF-SVM -> label, the MFCC
  * matrix never leaves the chip (one wavefront walks one clip; pooling in the kernel's tile epilogue).  The plan's
- * 2 * n_mfcc must equal the SVM's n_features (<= 64); equal results to dsp_mfcc_clips_device +
+ * 2 * n_mfcc must equal the SVM's n_features (<= 64) and, at n_fft = 512, the SVM may have at most 2048 support vectors (its
+ * coefficients ride in the kernel's LDS; larger models take the three calls); equal results to dsp_mfcc_clips_device +
  * dsp_mfcc_stats_device + dsp_svm_predict_device.  Plans with n_fft = 512 (BASELINE config 5) or n_fft = 2048 (the framing
  * of scrubjay_infer.c:10-14 itself: 2048 / 1024 / 40 filters / 20 coefficients).  d_decision, d_prob1, d_feat ([n_clips][2 n_mfcc]) may be NULL. */
 int dsp_scrubjay_fused_device(dsp_mfcc_plan *plan, dsp_svm *svm, const float *d_signal, long n_clips,
