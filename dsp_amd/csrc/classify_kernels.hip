@@ -1538,9 +1538,17 @@ __device__ float sum_intense_wave(float lower, float upper, float half_range, in
     const int lane = threadIdx.x & 63;
     const int W = t1 - t0 + 1, N = (f1 - f0 + 1) * W;
     float total = 0.0f;
-    auto chain = [&](float a) {                              // 64 adds in lane order
+    // 64 adds in lane order, total = ((total + a_0) + a_1) + ... + a_63, as a systolic chain over the lanes: lane 0 starts with
+    // total + a_0, and 63 times every lane adds its own a to the value of the lane before it (ONE instruction per add:
+    // v_add_f32_dpp wave_shr:1) -- after step k lane k holds the partial sum through a_k, the same additions in the same order as
+    // the reference's loop.  (64 x v_readlane + v_add took three to five instructions per add: the unrolled readlanes were hoisted
+    // into 64 SGPRs, 134 of which hipcc spilled back into VGPR lanes.)
+    auto chain = [&](float a) {
+        float s = lane == 0 ? total + a : a;
 #pragma unroll
-        for (int l = 0; l < 64; ++l) total = total + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), l));
+        for (int k = 1; k < 64; ++k)
+            s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x138, 0xF, 0xF, true)) + a;      // wave_shr:1; lane 0 reads 0
+        total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
     };
     auto wave_sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
