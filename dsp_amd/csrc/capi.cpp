@@ -215,6 +215,18 @@ int dsp_mfcc_tables(const dsp_mfcc_config *cfg, float *window, float *mel, float
     return DSP_OK;
 }
 
+int dsp_prefilter_scan_check(int prefilter, int *steps4)
+{
+    if (prefilter != DSP_PREFILTER_BUTTER_1000_3000 && prefilter != DSP_PREFILTER_BUTTER_3000_7500) return fail(DSP_EINVAL, "prefilter must name one of the two literal band-passes");
+    double b[9], a[9];
+    dsp_butter_bandpass(prefilter == DSP_PREFILTER_BUTTER_1000_3000 ? 1000 : 3000, prefilter == DSP_PREFILTER_BUTTER_1000_3000 ? 3000 : 7500, b, a);
+    dsp::PrefilterScan sc;
+    std::string why;
+    if (!dsp::build_prefilter_scan(b, a, sc, why)) return fail(DSP_EINVAL, why);
+    if (steps4) for (int k = 0; k < 4; ++k) steps4[k] = sc.c_steps[k];
+    return (sc.c_ok ? 1 : 0) | (sc.c_row_ok ? 2 : 0);
+}
+
 int dsp_mfcc_lane_tables(const dsp_mfcc_config *cfg, void *out, int size)
 {
     if (!cfg) return fail(DSP_EINVAL, "cfg is NULL");

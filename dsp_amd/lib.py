@@ -94,7 +94,7 @@ SYMBOLS = [
     "dsp_mfcc_stats_device", "dsp_svm_create", "dsp_svm_destroy", "dsp_svm_predict_device",
     "dsp_mfcc_default_config", "dsp_mfcc_scrubjay_infer_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
     "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",
-    "dsp_mfcc_clips_host", "dsp_mfcc_clips_pcm16_device", "dsp_mfcc_plan_set_launch", "dsp_mfcc_plan_set_kernel", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables",
+    "dsp_mfcc_clips_host", "dsp_mfcc_clips_pcm16_device", "dsp_mfcc_plan_set_launch", "dsp_mfcc_plan_set_kernel", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables", "dsp_prefilter_scan_check",
     "dsp_scrubjay_fused_device", "dsp_stop_model_create", "dsp_stop_model_destroy", "dsp_stop_predict_device", "dsp_classify_signal_batch_device",
     "dsp_classify_signal", "dsp_speaker_model_create", "dsp_speaker_model_destroy", "dsp_speaker_llr_device",
     "dsp_upsample_linear_device", "dsp_upsample_linear_host",

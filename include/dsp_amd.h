@@ -359,6 +359,12 @@ int dsp_mfcc_tables(const dsp_mfcc_config *cfg, float *window, float *mel, float
  * out is NULL).  Host-only introspection used by the CPU tests of the planner. */
 int dsp_mfcc_lane_tables(const dsp_mfcc_config *cfg, void *out, int size);
 
+/* The host planner's self-check of BASELINE config 3's fused prefilter (dsp_mfcc_config.prefilter, tables.hpp PrefilterScan): the
+ * literal band-pass as a cascade of four second-order sections run as lane scans.  Returns bit 0 = the cascade reproduces the
+ * direct-form recurrence (donut-classifier/classifier.c:420-446) on 1024 samples, bit 1 = so does the row form of its scan (the
+ * one the kernel runs); steps4 (may be NULL) receives the Kogge-Stone steps each section needs.  < 0: DSP_EINVAL.  Host only. */
+int dsp_prefilter_scan_check(int prefilter, int *steps4);
+
 /* --- misc -------------------------------------------------------------------- */
 const char *dsp_last_error(void);   /* thread-local, "" when none */
 int dsp_device_count(void);

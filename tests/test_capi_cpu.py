@@ -66,6 +66,16 @@ def test_butter_bandpass_tables_and_rejection():
     assert "invalid bandpass range" in dl.last_error()
 
 
+def test_config3_prefilter_planner_checks_itself_for_both_literal_filters():
+    """The fused prefilter of BASELINE config 3 (cascade of lane scans, its scan in row form) is checked by the planner against the
+    direct-form recurrence at plan creation; the same check is callable without a GPU."""
+    L = dsp_amd.load()
+    steps = (C.c_int * 4)()
+    assert L.dsp_prefilter_scan_check(1, steps) == 3 and list(steps) == [2, 3, 3, 4]          # 1000-3000 Hz
+    assert L.dsp_prefilter_scan_check(2, steps) == 3 and list(steps) == [1, 3, 3, 5]          # 3000-7500 Hz (config 3)
+    assert L.dsp_prefilter_scan_check(0, None) < 0 and "literal band-passes" in dl.last_error()
+
+
 def test_bad_configs_are_rejected_before_touching_a_device():
     L = dsp_amd.load()
     h = C.c_void_p()
