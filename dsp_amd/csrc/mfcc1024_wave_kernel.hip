@@ -311,8 +311,9 @@ __device__ __forceinline__ void prefilter_cascade(const float (&x)[kScanChunk], 
 #pragma unroll
         for (int i = 0; i < kScanChunk; ++i) y[i] = (uf[i] * g) * w4[i >> 2][i & 3];
     } else {
+        (void)g;                                     // the cascade's gain rides in the window the kernel multiplies with anyway (win[] below)
 #pragma unroll
-        for (int i = 0; i < kScanChunk; ++i) y[i] = uf[i] * g;
+        for (int i = 0; i < kScanChunk; ++i) y[i] = uf[i];
     }
 }
 
@@ -365,8 +366,10 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
     // ---- per-lane constants ------------------------------------------------------------------------------------
     float win[16];
     if (!W3) {
+        // PRE (cascade form): the filter's output gain g = b0 is folded into the window here, once per kernel, instead of 16 multiplies per frame
+        const float wg = (PRE && DSP_PRE_CASCADE) ? (float)S->c_gain : 1.0f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) win[i] = G->win[i][lane];
+        for (int i = 0; i < 16; ++i) win[i] = G->win[i][lane] * wg;
     }
     c32 tw1[7], tw2[7], twp[4];
 #pragma unroll
