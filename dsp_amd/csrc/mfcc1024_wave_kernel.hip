@@ -284,7 +284,12 @@ __device__ __forceinline__ void cascade_section(T (&u)[kScanChunk], T a1, T a2, 
 #endif
 // wc != nullptr: the lane's 16 window values in chunk order (GenTables1024::win_chunk), multiplied into the output here
 // the per-lane matrices of the row form's cross-row step (PrefilterScan::c_rowm / c_rowmf at j = lane % 16): 24 VGPRs, loaded once
-struct RowMats { double d[2][4]; float f[2][4]; };
+// DSP_PRE_F64_SECTIONS: cascade sections that run in float64 (2, the default: the two that see the unattenuated stop-band energy;
+// 1 is an A/B build: section 1 in float32 as well -- measured faster and closer to the gate, see profiles/r03_config3_ab.txt)
+#ifndef DSP_PRE_F64_SECTIONS
+#define DSP_PRE_F64_SECTIONS 2
+#endif
+struct RowMats { double d[2][4]; float f[2][4]; float f1[4]; };
 template <int S0, int S1, int S2, int S3>
 __device__ __forceinline__ void prefilter_cascade(const float (&x)[kScanChunk], float (&y)[kScanChunk], const PrefilterScan *__restrict__ S, int lane,
                                                   const RowMats &rm, const float *__restrict__ wc = nullptr)
@@ -297,10 +302,11 @@ __device__ __forceinline__ void prefilter_cascade(const float (&x)[kScanChunk], 
 #pragma unroll
     for (int i = 0; i < kScanChunk; ++i) ud[i] = (double)x[i];
     cascade_section<double, S0>(ud, S->c_a1[0], S->c_a2[0], S->c_pw, 0, lane, rm.d[0]);
-    cascade_section<double, S1>(ud, S->c_a1[1], S->c_a2[1], S->c_pw, 1, lane, rm.d[1]);
+    if (DSP_PRE_F64_SECTIONS >= 2) cascade_section<double, S1>(ud, S->c_a1[1], S->c_a2[1], S->c_pw, 1, lane, rm.d[1]);
     float uf[kScanChunk];
 #pragma unroll
     for (int i = 0; i < kScanChunk; ++i) uf[i] = (float)ud[i];
+    if (DSP_PRE_F64_SECTIONS < 2) cascade_section<float, S1>(uf, S->c_a1f[1], S->c_a2f[1], S->c_pwf, 1, lane, rm.f1);
     cascade_section<float, S2>(uf, S->c_a1f[2], S->c_a2f[2], S->c_pwf, 2, lane, rm.f[0]);
     cascade_section<float, S3>(uf, S->c_a1f[3], S->c_a2f[3], S->c_pwf, 3, lane, rm.f[1]);
     const float g = (float)S->c_gain;
@@ -511,6 +517,7 @@ __global__ __launch_bounds__(256) DSP_PRE_WAVES_ATTR void mfcc1024_wave_kernel(c
         for (int k = 0; k < 4; ++k) {
             rowm.d[0][k] = S->c_rowm[0][lane & 15][k]; rowm.d[1][k] = S->c_rowm[1][lane & 15][k];
             rowm.f[0][k] = S->c_rowmf[2][lane & 15][k]; rowm.f[1][k] = S->c_rowmf[3][lane & 15][k];
+            rowm.f1[k] = DSP_PRE_F64_SECTIONS < 2 ? S->c_rowmf[1][lane & 15][k] : 0.0f;
         }
     }
     auto filter_next = [&](float (&out)[kScanChunk]) {

@@ -243,6 +243,36 @@ def test_config3_1024_point_128_mel_with_prefilter(dsp, torch_cuda):
                 assert not out[1].any()                       # silent frame stays exactly zero through the filter
 
 
+def test_config3_prefilter_on_frames_that_live_in_the_stop_band(dsp, torch_cuda):
+    """The fused prefilter runs its last two cascade sections in float32; frames whose energy lies wholly in the stop band are where a
+    mixed-precision filter would show first (what is left after 76 dB of attenuation is the filter's own leakage): tones below and
+    above the band, DC, a step, an impulse, low-passed and high-passed noise -- each against the oracle's float64 direct form under
+    the same gate (the frames of tools/emulate_prefilter_cascade.py, which chose the precisions).  The yardstick is the oracle with
+    its float64 transform (fft_mode FFT_FLOAT64): the question is the FILTER's precision, and on these frames the reference-order
+    float32 FFT's own noise is of the gate's size (the impulse frame: 1.03e-4 against it, whatever the filter's precision)."""
+    from oracle import oracle as O
+    from scipy import signal as ss
+    torch = torch_cuda
+    over = dict(n_fft=1024, frame_length=1024, hop_length=1024, n_mels=128)
+    t = np.arange(1024) / 16000.0
+
+    def filtered_noise(order, wn, seed, scale=1.0, kind="low"):
+        bb, aa = ss.butter(order, wn, kind)
+        return (scale * ss.lfilter(bb, aa, np.random.default_rng(seed).standard_normal(4096))[-1024:]).astype(np.float32)
+    frames = {"tone 500 Hz": 0.5 * np.sin(2 * np.pi * 500 * t), "tone 1500 Hz": 0.5 * np.sin(2 * np.pi * 1500 * t),
+              "tone 7900 Hz": 0.5 * np.sin(2 * np.pi * 7900 * t), "chirp 200-7900 Hz": S.chirp(1024, 200.0, 7900.0),
+              "impulse": np.eye(1, 1024, 777)[0], "dc": np.full(1024, 0.7), "step": np.concatenate([np.zeros(500), np.ones(524)]),
+              "low-pass 0.1": filtered_noise(6, 0.1, 0), "low-pass 0.05": filtered_noise(8, 0.05, 1),
+              "low-pass 0.2 loud": filtered_noise(6, 0.2, 2, 5.0), "high-pass 0.97": filtered_noise(6, 0.97, 4, kind="high")}
+    fr = np.stack([np.asarray(v, np.float32) for v in frames.values()])
+    for pre in (2, 1):
+        plan = dsp.MfccPlan(dsp.default_config(prefilter=pre, **over))
+        out = plan.frames(torch.from_numpy(fr).cuda()).cpu().numpy()
+        ref = O.mfcc_frames(fr, O.default_cfg(prefilter=pre, fft_mode=O.FFT_FLOAT64, **over), threads=4)
+        for i, name in enumerate(frames):
+            gate(out[i:i + 1], ref[i:i + 1], f"config3 prefilter {pre} stop-band frame: {name}")
+
+
 def test_1024_general_fallback_kernel_agrees_with_the_wave_kernel(dsp, torch_cuda):
     """n_fft = 1024 has two kernels: the register-resident wave kernel (default) and the general Stockham kernel (fallback
     for filterbanks with more than three chunks per lane; forced here through set_kernel(1)).  Both against the oracle."""
