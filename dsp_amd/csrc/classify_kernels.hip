@@ -406,14 +406,15 @@ hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, cons
 // a9 for classify(), checkpoint form: ONE pass over x runs both band-pass recurrences and writes back NEITHER filtered
 // signal.  What classify() needs from the filtered signals are spectrogram segments (256 samples every 224), and a direct
 // form II filter can be restarted anywhere from its delay line v[n-1..n-8]: the kernel stores that state at every segment
-// start (32 bytes per segment and filter, 4.6 KB per 1 s clip instead of 128 KB of filtered samples), and the spectrogram
-// kernels recompute exactly the segments they transform -- same operations on the same values in the same order, so the
-// same bits (spec_from_ckpt_kernel).  For the 1000-3000 Hz filter the output taps run here as well, because its segments'
+// start and (round 3) at every segment's middle (32 bytes each; 9 KB per 1 s clip and filter at most, instead of 128 KB of
+// filtered samples), and the spectrogram kernels recompute exactly the segments they transform -- same operations on the same
+// values in the same order, so the same bits (spec_from_ckpt_kernel).  For the 1000-3000 Hz filter the output taps run here as well, because its segments'
 // sequential sums (classifier.cpp:329-333) and the energy gate (see iir2_split_kernel) come from every sample; the
 // 3000-7500 Hz filter needs its taps only for clips that turn out to have midpoints, so they wait for the recompute.
-//   wave 0: recurrence 3000-7500 Hz (checkpoints)      wave 1: recurrence 1000-3000 Hz (checkpoints, v tiles to LDS)
-//   wave 2: taps 1000-3000 Hz one tile behind (segment means, energy gate)
-// HBM traffic: x once + 71 x (32 + 32 + 4 + 4) B per 1 s clip.
+//   part 0: recurrence 3000-7500 Hz (checkpoints to HBM)   part 1: recurrence 1000-3000 Hz (checkpoints parked in LDS, v tiles to LDS)
+//   part 2: taps 1000-3000 Hz one tile behind (segment means, energy gate; writes the parked checkpoints of gated-in segments)
+// Which wave of the block runs which part follows the SIMD loads the launch measures itself (simd_load, below).
+// HBM traffic: x once + 71 x (64 + 4) B per 1 s clip + 64 + 4 B per gated-in segment.
 // ---------------------------------------------------------------------------------
 // DUAL (round 3, an experiment; default off): ONE wave runs both recurrences of its 64 clips as PACKED fp32 operations -- lane l
 // holds the pair (1000-3000 Hz, 3000-7500 Hz) of its clip's delay lines, and v = v - a[j] d[j-1] is one v_pk_mul_f32 + one
