@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -704,6 +705,18 @@ int cls_init(int device = -1)
     g_cls.gate_ok = t.gate_ok != 0;
     g_cls.keep_min_db = 70.0f;
     DSP_HIP(dsp::launch_spec_threshold(g_cls.d_tab, g_cls.keep_min_db, nullptr));
+    {   // the recompute kernel's three-instruction PSD division is switched on only after it has been checked against the real
+        // division on every float of its range, for this table's U, on this device (~1e9 values: a fraction of a millisecond)
+        unsigned long long *d_bad = nullptr, bad = 1;
+        DSP_HIP(hipMalloc(&d_bad, sizeof(bad)));
+        hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(bad), nullptr);
+        if (e == hipSuccess) e = dsp::launch_spec_div_verify(g_cls.d_tab, d_bad, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+        hipFree(d_bad);
+        if (e != hipSuccess) return fail(DSP_EHIP, hipGetErrorString(e));
+        const int on = bad == 0 && !std::getenv("DSP_AMD_SPEC_EXACT_DIV") ? 1 : 0;
+        DSP_HIP(hipMemcpy(reinterpret_cast<char *>(g_cls.d_tab) + offsetof(dsp::SpecTables, div_fast), &on, sizeof(on), hipMemcpyHostToDevice));
+    }
     DSP_HIP(hipStreamSynchronize(nullptr));
     return DSP_OK;
 }
@@ -789,6 +802,25 @@ constexpr long kClsSubBatch = 65536;
 }  // namespace
 
 extern "C" {
+
+int dsp_classify_division_check(long long *mismatches)
+{
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    int rc = cls_init();
+    if (rc < 0) return rc;
+    DSP_ON_DEVICE(g_cls.device);
+    unsigned long long *d_bad = nullptr, bad = 0;
+    int on = 0;
+    DSP_HIP(hipMalloc(&d_bad, sizeof(bad)));
+    hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(bad), nullptr);
+    if (e == hipSuccess) e = dsp::launch_spec_div_verify(g_cls.d_tab, d_bad, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&on, reinterpret_cast<const char *>(g_cls.d_tab) + offsetof(dsp::SpecTables, div_fast), sizeof(on), hipMemcpyDeviceToHost);
+    hipFree(d_bad);
+    if (e != hipSuccess) return fail(DSP_EHIP, hipGetErrorString(e));
+    if (mismatches) *mismatches = (long long)bad;
+    return on ? 1 : 0;
+}
 
 int dsp_butter_bandpass_filter_f32(const float *data, long n_clips, int n, long stride, const float *b,
                                    const float *a, float *output)

@@ -1021,6 +1021,32 @@ constexpr int RC_THREADS = 512, RC_WAVES = RC_THREADS / 64, RC_FRAMES = 60;
 static_assert((kSpecSeg / RC_WAVES) % IIR_BURST == 0 && RC_FRAMES <= 64, "taps split evenly over the waves; a frame per lane");
 constexpr int RC_ROW = 8 + kSpecSeg + 1;      // v[-8..-1] | 256 samples | pad: odd stride, lane l <-> row l is conflict free
 
+// p / U in three instructions (SpecTables::rU, div_fast): q = p rU, then one Newton step on the exact residual
+__device__ __forceinline__ float div_by_u_fast(float p, float U, float rU)
+{
+    const float q = p * rU;
+    return fmaf(fmaf(-q, U, p), rU, q);
+}
+
+__global__ __launch_bounds__(256) void spec_div_verify_kernel(const SpecTables *__restrict__ tab, unsigned long long *__restrict__ mismatches)
+{
+    const float U = tab->U, rU = tab->rU;
+    const unsigned lo = __float_as_uint(kDivFastLo), hi = __float_as_uint(kDivFastHi);
+    unsigned long long bad = 0;
+    for (unsigned long long b = lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += (unsigned long long)gridDim.x * blockDim.x) {
+        const float p = __uint_as_float((unsigned)b);
+        const float exact = p / U;
+        bad += __float_as_uint(div_by_u_fast(p, U, rU)) != __float_as_uint(exact);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+hipError_t launch_spec_div_verify(const SpecTables *tables, unsigned long long *mismatches, hipStream_t stream)
+{
+    hipLaunchKernelGGL(spec_div_verify_kernel, dim3(4096), dim3(256), 0, stream, tables, mismatches);
+    return hipGetLastError();
+}
+
 struct SpecLane {                             // per-lane constants of the 256-point FFT (see spectrogram_kernel)
     int pos[4][4];
     cpx ua[4], ub0[4], ub1[4];
@@ -1046,7 +1072,7 @@ struct SpecLane {                             // per-lane constants of the 256-p
     }
     // cur[j] = sample src[j] of the frame; returns the PSD cells lane, lane + 64 and (lane 0) 128
     __device__ __forceinline__ void psd(const float (&cur)[4], float mean_f, float U, bool trivial01, float2 *buf, int lane,
-                                        float &p0, float &p1, float &p2) const
+                                        float &p0, float &p1, float &p2, float rU = 0.0f, bool div_fast = false) const
     {
         cpx v[4];
 #pragma unroll
@@ -1077,11 +1103,21 @@ struct SpecLane {                             // per-lane constants of the 256-p
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
-        p0 = (v[0].x * v[0].x + v[0].y * v[0].y) / U;                                    // classifier.cpp:350-365
+        const float s0 = v[0].x * v[0].x + v[0].y * v[0].y, s1 = v[1].x * v[1].x + v[1].y * v[1].y, s2 = v[2].x * v[2].x + v[2].y * v[2].y;
+        // classifier.cpp:350-365.  A frame whose every cell lies in the verified range takes the three-instruction division (the
+        // same bits, SpecTables::div_fast); silent, denormal, huge or non-finite cells send the whole frame through the real one.
+        const bool in_range = fminf(fminf(s0, s1), s2) >= kDivFastLo && fmaxf(fmaxf(s0, s1), s2) <= kDivFastHi;
+        if (div_fast && __ballot(!in_range) == 0) {
+            p0 = div_by_u_fast(s0, U, rU);
+            p1 = div_by_u_fast(s1, U, rU);
+            p2 = div_by_u_fast(s2, U, rU);
+        } else {
+            p0 = s0 / U;
+            p1 = s1 / U;
+            p2 = s2 / U;
+        }
         if (lane >= 1) p0 = p0 * 2.0f;
-        p1 = (v[1].x * v[1].x + v[1].y * v[1].y) / U;
         p1 = p1 * 2.0f;
-        p2 = (v[2].x * v[2].x + v[2].y * v[2].y) / U;
         // the next frame's first butterfly level writes buf: order it behind this frame's last reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1185,8 +1221,8 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     issue(clip1, t1);
     describe(g + gridDim.x, clip2, t2);
 
-    const float U = tab->U, keep_min = tab->mp_keep_min;
-    const bool trivial01 = tab->trivial_first_levels != 0;
+    const float U = tab->U, keep_min = tab->mp_keep_min, rU = tab->rU;
+    const bool trivial01 = tab->trivial_first_levels != 0, div_fast = tab->div_fast != 0;
     float2 *buf = fftbuf[wib];
     float *row = rows + (lane < RC_FRAMES ? lane : 0) * RC_ROW;
 
@@ -1316,7 +1352,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
             for (int j = 0; j < 4; ++j) cur[j] = fr[K.src[j]];
             float p0, p1, p2;
-            K.psd(cur, smean[f], U, trivial01, buf, lane, p0, p1, p2);
+            K.psd(cur, smean[f], U, trivial01, buf, lane, p0, p1, p2, rU, div_fast);
             if (OUT == SPEC_FLAGS) {
                 const bool loud = p0 >= keep_min || p1 >= keep_min || (lane == 0 && p2 >= keep_min);
                 if (__ballot(loud) != 0 && lane == 0) sflag[f] = 1;
@@ -1933,6 +1969,14 @@ void build_spec_tables(int fs, SpecTables &t)
     float U = 0.0f;
     for (int i = 0; i < kSpecSeg; ++i) U = U + t.window[i] * t.window[i];
     t.U = U * (float)fs;
+    {   // the float nearest to 1 / U (long double: 64 mantissa bits, then the neighbours compared)
+        const long double inv = 1.0L / (long double)t.U;
+        float r = (float)inv;
+        const float cand[3] = {std::nextafterf(r, 0.0f), r, std::nextafterf(r, INFINITY)};
+        for (float cnd : cand) if (fabsl((long double)cnd - inv) < fabsl((long double)r - inv)) r = cnd;
+        t.rU = r;
+        t.div_fast = 0;       // set on the device table by the context after launch_spec_div_verify
+    }
     // PlainFFT.cpp:52-84: per level the running (u1,u2) starts at (1,0) and is advanced by
     // (c1,c2); between levels c2 = -sqrt((1-c1)/2), c1 = sqrt((1+c1)/2) in double, stored float
     float c1 = -1.0f, c2 = 0.0f;

@@ -38,7 +38,15 @@ struct SpecTables {
     float win2_in[kSpecSeg - kSpecHop], win2_out[kSpecSeg - kSpecHop];
     float win2_sum, gate_scale;
     int gate_ok;
+    // PSD = |X|^2 / U is an IEEE division in the reference (classifier.cpp:350-365), ten instructions on this hardware, three per
+    // transformed frame.  rU = the float nearest to 1 / U; div_fast = 1 when launch_spec_div_verify found q + fma(-q, U, p) rU with
+    // q = p rU equal to p / U, bit for bit, for EVERY float p in [kDivFastLo, kDivFastHi] (exhaustive: ~1e9 values, on the device,
+    // once per context) -- then the recompute kernel takes those three instructions for frames whose cells all lie in that range and
+    // the division for the others.  0 (tables built on the host, any table that was not verified): always the division.
+    float rU;
+    int div_fast;
 };
+constexpr float kDivFastLo = 8.673617379884035e-19f, kDivFastHi = 1.152921504606847e18f;      // 2^-60, 2^60
 
 struct IirCoef { float b[9], a[9]; };
 struct IirCoefD { double b[9], a[9]; };
@@ -114,6 +122,9 @@ hipError_t launch_classify_midpoints(const int *loud, long n_clips, int n, int f
 struct ClassifyRule { float keep_lo, keep_hi, middle_max, above_min, below_min; };
 hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, const int *hits,
                                  hipStream_t stream, const ClassifyRule &rule);
+// Counts, into *mismatches (device, zeroed by the caller), the floats p in [kDivFastLo, kDivFastHi] for which the three-instruction
+// form of p / tables->U (see SpecTables::rU) differs from the division: every bit pattern in the range is tried.
+hipError_t launch_spec_div_verify(const SpecTables *tables, unsigned long long *mismatches, hipStream_t stream);
 // fills tables->mp_keep_min for find_midpoints' lower_threshold_dB (classifier.cpp:436; once per context and threshold)
 hipError_t launch_spec_threshold(SpecTables *tables, float threshold_db, hipStream_t stream);
 

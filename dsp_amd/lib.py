@@ -90,7 +90,7 @@ SYMBOLS = [
     "dsp_classify_default_config_f64", "dsp_classify_batch_host_f64", "dsp_classify_batch_device_f64",
     "dsp_classify_default_config", "dsp_classify_batch_host_cfg", "dsp_classify_batch_device_cfg", "dsp_sum_intense_f32",
     "dsp_butter_bandpass_filter_f32", "dsp_butter_bandpass_filter_f64", "dsp_compute_spectrogram_f32", "dsp_compute_spectrogram_f64",
-    "dsp_classify_batch_host", "dsp_classify_batch_device", "dsp_find_midpoints",
+    "dsp_classify_batch_host", "dsp_classify_batch_device", "dsp_find_midpoints", "dsp_classify_division_check",
     "dsp_mfcc_stats_device", "dsp_svm_create", "dsp_svm_destroy", "dsp_svm_predict_device",
     "dsp_mfcc_default_config", "dsp_mfcc_scrubjay_infer_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
     "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",

@@ -359,6 +359,13 @@ int dsp_mfcc_tables(const dsp_mfcc_config *cfg, float *window, float *mel, float
  * out is NULL).  Host-only introspection used by the CPU tests of the planner. */
 int dsp_mfcc_lane_tables(const dsp_mfcc_config *cfg, void *out, int size);
 
+/* classify()'s spectrogram divides every PSD cell by U = fs * sum(window^2) (classifier.cpp:350-365).  The recompute kernel takes a
+ * three-instruction form of that division for cells in [2^-60, 2^60] -- but only after the classifier context has compared it with
+ * the real division on EVERY float of that range, on the device, for its U.  This call repeats the comparison: *mismatches = the
+ * floats on which the two differ (0 expected); returns 1 when the fast form is in use, 0 when not (a mismatch, or
+ * DSP_AMD_SPEC_EXACT_DIV set), < 0 on error.                                                                              */
+int dsp_classify_division_check(long long *mismatches);
+
 /* The host planner's self-check of BASELINE config 3's fused prefilter (dsp_mfcc_config.prefilter, tables.hpp PrefilterScan): the
  * literal band-pass as a cascade of four second-order sections run as lane scans.  Returns bit 0 = the cascade reproduces the
  * direct-form recurrence (donut-classifier/classifier.c:420-446) on 1024 samples, bit 1 = so does the row form of its scan (the

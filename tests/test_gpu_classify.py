@@ -349,3 +349,15 @@ def test_simd_aware_parts_of_the_checkpoint_kernel_change_nothing(dsp, golden, t
     assert np.array_equal(f["counts"], np.array([len(m) for m, _ in trace]))
     assert np.array_equal(f["mids"], np.concatenate([np.asarray(m, np.float32).ravel() for m, _ in trace]))
     assert np.array_equal(f["sums"], np.concatenate([np.asarray(s, np.float32).ravel() for _, s in trace]))
+
+
+def test_fast_psd_division_is_the_division_on_every_float_of_its_range(dsp):
+    """The recompute kernel divides PSD cells by U with three instructions instead of the ten-instruction IEEE division, for cells in
+    [2^-60, 2^60]: allowed only because the context compares the two on every float of that range at start-up (~1e9 values).  The
+    same exhaustive comparison, repeated here: zero mismatches, and the fast form in use."""
+    import ctypes as C
+    from dsp_amd import lib as dl
+    bad = C.c_longlong(-1)
+    rc = dl.load().dsp_classify_division_check(C.byref(bad))
+    assert rc == 1, dl.last_error()
+    assert bad.value == 0
