@@ -369,14 +369,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             pool_q = pool_q + cv * cv;
             ++pool_t;
             if (last_of_chunk) {
-                const SvmModelDev &sm = args.pool.svm;
+                // the model's fields and output pointers reloaded here through the kernarg segment, not held in SGPRs across the
+                // frame loop (mfcc_kernels.hip, pool_finish: 29 of this kernel's SGPRs were spilled)
+                const Mfcc512Args *ap = kernarg_of_mfcc512();
+                asm volatile("" : "+s"(ap));
+                const PoolSvmArgs &pool = ap->pool;
+                const SvmModelDev &sm = pool.svm;
                 if ((lane & 1) == 0 && c < n_mfcc) {
                     const double mean = pool_s / (double)pool_t;
                     const double var = pool_q / (double)pool_t - mean * mean;
                     const float f_mean = (float)mean, f_std = sqrtf((float)(var > 0 ? var : 0));
-                    if (args.pool.feat) {
-                        args.pool.feat[clip_f * 2L * n_mfcc + c] = f_mean;
-                        args.pool.feat[clip_f * 2L * n_mfcc + n_mfcc + c] = f_std;
+                    if (pool.feat) {
+                        pool.feat[clip_f * 2L * n_mfcc + c] = f_mean;
+                        pool.feat[clip_f * 2L * n_mfcc + n_mfcc + c] = f_std;
                     }
                     feat[c] = (f_mean - sm.offset[c]) * sm.scale[c];
                     feat[n_mfcc + c] = (f_std - sm.offset[n_mfcc + c]) * sm.scale[n_mfcc + c];
@@ -398,9 +403,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                     int label;
                     float p1;
                     svm_binary_tail(score, sm.prob_a, sm.prob_b, label, p1);
-                    args.pool.labels[clip_f] = label;
-                    if (args.pool.decision) args.pool.decision[clip_f] = score;
-                    if (args.pool.prob1) args.pool.prob1[clip_f] = p1;
+                    pool.labels[clip_f] = label;
+                    if (pool.decision) pool.decision[clip_f] = score;
+                    if (pool.prob1) pool.prob1[clip_f] = p1;
                 }
                 pool_s = 0.0; pool_q = 0.0; pool_t = 0;
                 wave_lds_sync();

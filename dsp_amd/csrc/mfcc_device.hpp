@@ -250,6 +250,17 @@ struct WaveCursor {
     }
 };
 
+// the kernel's argument struct where the hardware put it (the kernarg segment; Mfcc512Args is the FIRST parameter of every MFCC kernel): a pointer the
+// cold per-clip code reloads model fields through, instead of keeping them in SGPRs across the frame loop
+__device__ __forceinline__ const Mfcc512Args *kernarg_of_mfcc512()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (const Mfcc512Args *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return nullptr;      // host pass of the single-source compile: never called
+#endif
+}
+
 }  // namespace
 
 }  // namespace dsp

@@ -152,17 +152,6 @@ __device__ __forceinline__ c32 unpack_pcm16(c32 raw)
 
 }  // namespace
 
-// the kernel's argument struct where the hardware put it (the kernarg segment; Mfcc512Args is the only parameter): a pointer the
-// cold per-clip code reloads model fields through, instead of keeping them in SGPRs across the frame loop
-__device__ __forceinline__ const Mfcc512Args *kernarg_of_mfcc512()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (const Mfcc512Args *)__builtin_amdgcn_kernarg_segment_ptr();
-#else
-    return nullptr;      // host pass of the single-source compile: never called
-#endif
-}
-
 // DCT_SPLIT lanes per coefficient, DCT_LEN log-mel values per lane.  GATHER: partial
 // sums per mel filter.  FLEN: frame_length at compile time (512, the reference's 400) or 0 = run time (tail predicate on the loads).
 // IN: input element type (see load_frame).  CLIPS: frames overlap inside clips (hop < frame).
