@@ -302,6 +302,19 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         units, unit, bytes_per = n * 98, "frames/s", 64_000 + 98 * 52    # 69 096 B per clip
         what = f"BASELINE configs[3] per-GPU share: {n} x 1 s 16 kHz fp32 clips, frame 400 / hop 160 -> [98][13] per clip"
         kernel = "mfcc512_wave_kernel"
+    elif args.workload == "classify_f64":
+        # the float64 classifier of donut-classifier/classifier.c (parity path, untuned: lane-per-clip IIR, full maps in HBM)
+        n = args.clips or 8192
+        clips = (torch.rand((n, 16000), device=dev, generator=gen, dtype=torch.float64) * 2 - 1) * 0.05
+        from tests import signals as S
+        call = torch.from_numpy(S.classify_cases()["scrub_a"]).to(dev).double()
+        clips[::4] = call + clips[::4] * 0.01
+        labels = torch.empty(n, dtype=torch.int32, device=dev)
+        step = lambda: dsp_amd.classify_device_f64(clips, labels)   # noqa: E731
+        units, unit, bytes_per = n, "clips/s", 128_000 + 4
+        what = (f"{n} x 1 s 16 kHz float64 clips (25 % with a call-like burst pattern) through the float64 classify() of "
+                "donut-classifier/classifier.c")
+        kernel = "iir_kernel<double> x 2 + spectrogram_kernel<double> x 2 + classify_f64 tail kernels"
     else:
         n = args.clips or 49152
         clips = (torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1) * 0.05
@@ -326,7 +339,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    steps = max(1, args.steps // 10) if args.workload == "classify" else args.steps
+    steps = max(1, args.steps // 10) if args.workload in ("classify", "classify_f64") else args.steps
     s_before = sens.read() if sens else None
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
@@ -354,7 +367,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         print(json.dumps({
             "metric": f"{args.workload}: {unit}", "value": world * units * steps / elapsed, "unit": unit, "n_gpus": world,
             "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.workload == "classify_f64" else "f32", "data": "synthetic",
             "config": {"workload": what, "clock_settle_s": args.settle},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr["hbm_bytes_per_launch"] if tr else None,
@@ -475,7 +488,7 @@ def main():
                          "steps end before the GPU's clocks have ramped (first launches after idle run 0.6 ms); reported in config")
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="all-gather the per-rank features every step (RCCL)")
-    ap.add_argument("--workload", choices=["frames", "clips", "classify", "config3", "config5", "config5_2048", "pcm16", "stop"], default="frames",
+    ap.add_argument("--workload", choices=["frames", "clips", "classify", "classify_f64", "config3", "config5", "config5_2048", "pcm16", "stop"], default="frames",
                     help="frames = BASELINE configs[1] (the headline metric, default); clips = configs[3] per-GPU share "
                          "(12 500 x 1 s clips, reference framing 400/160); classify = the donut classifier on 1 s clips")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step for --workload clips / classify")

@@ -3,11 +3,14 @@
 //     butter_bandpass_filter (3000-7500 Hz and, inside find_midpoints, 1000-3000 Hz; :420-446)  iir_kernel<double>
 //     compute_spectrogram of both (:448-592)                                                     spectrogram_f64_kernel
 //     dB maps, 45 dB midpoints, normalisation, keep band, band sums, rule (:105-190, :594-830)   classify_f64_tail_kernel
-// Correctness first: sub-batches through a scratch workspace that lives for the call; not tuned.
+// Sub-batches of up to 65 536 clips (one recurrence wavefront per SIMD and filter) through a grow-only scratch workspace that
+// stays with the library, like the float32 classifier's (capi.cpp, ClassifyCtx).  DSP_AMD_F64_DFT=1 routes the batch through the
+// direct-DFT spectrogram ([129][T] maps) instead of the FFT kernel: the yardstick of tests/test_gpu_classify_f64.py.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 
 #include "capi_util.hpp"
@@ -17,21 +20,39 @@ static_assert(sizeof(dsp::ClassifyTraceD) == sizeof(dsp_classify_trace_f64), "tr
 
 namespace {
 
-constexpr long kSubBatch = 2048;           // clips per pass: ~0.9 GB of float64 scratch for 1 s clips
+constexpr long kSubBatchDefault = 65536;   // clips per pass: 402 KB of float64 scratch per 1 s clip (26 GB at the full sub-batch)
 constexpr int kMaxColumns = 957;           // as the float32 path (capi.cpp kMaxSpecColumns): at most 64 midpoints fit such a clip
 
 int columns(int n) { return n < dsp::kSpecSeg ? 0 : (n - dsp::kSpecSeg) / dsp::kSpecHop + 1; }
 
 struct Scratch {
+    int device = -1;
+    dsp::SpecTablesD *tab = nullptr;
     double *x = nullptr, *y_bp = nullptr, *y_mp = nullptr, *s_bp = nullptr, *s_mp = nullptr;
     int *labels = nullptr;
     dsp::ClassifyTraceD *trace = nullptr;
-    ~Scratch()
+    long cap_clips = 0, cap_row = 0;           // what the workspace holds: clips x row doubles (x only when cap_x)
+    int cap_T = 0;
+    bool cap_x = false;
+    std::mutex mu;
+    void drop()
     {
         for (void *p : {(void *)x, (void *)y_bp, (void *)y_mp, (void *)s_bp, (void *)s_mp, (void *)labels, (void *)trace})
             if (p) (void)hipFree(p);
+        x = y_bp = y_mp = s_bp = s_mp = nullptr; labels = nullptr; trace = nullptr;
+        cap_clips = cap_row = 0; cap_T = 0; cap_x = false;
     }
 };
+Scratch g_w;
+
+long sub_batch()                            // DSP_AMD_F64_SUB_BATCH: a smaller pass (tests: a batch that spans passes)
+{
+    const char *e = std::getenv("DSP_AMD_F64_SUB_BATCH");
+    const long v = e ? std::atol(e) : 0;
+    return v >= 64 ? std::min(v, kSubBatchDefault) : kSubBatchDefault;
+}
+long row_of(int n) { return ((long)n + 1) & ~1L; }      // workspace row: n doubles rounded up to 16 bytes
+bool use_dft() { const char *e = std::getenv("DSP_AMD_F64_DFT"); return e && std::atoi(e) != 0; }
 
 bool valid(const dsp_classify_config_f64 &c)
 {
@@ -42,24 +63,52 @@ bool valid(const dsp_classify_config_f64 &c)
 // one sub-batch resident at d_x (row stride `stride`): labels (+ trace) into the scratch arrays
 int run(const dsp_classify_config_f64 &cfg, Scratch &w, const double *d_x, long cnt, int n, long stride, bool want_trace, hipStream_t st)
 {
+    const long row = row_of(n);
     double b[9], a[9];
     dsp::IirCoefD c_bp, c_mp;
     dsp_butter_bandpass(3000.0, 7500.0, b, a);                       // classifier.c:86-91
     for (int i = 0; i < 9; ++i) { c_bp.b[i] = b[i]; c_bp.a[i] = a[i]; }
     dsp_butter_bandpass(1000.0, 3000.0, b, a);                       // :659-664
     for (int i = 0; i < 9; ++i) { c_mp.b[i] = b[i]; c_mp.a[i] = a[i]; }
-    DSP_CAPI_HIP(dsp::launch_iir_f64(d_x, cnt, n, stride, c_bp, w.y_bp, st));     // launch_iir_f64 writes y with the input's stride
-    DSP_CAPI_HIP(dsp::launch_iir_f64(d_x, cnt, n, stride, c_mp, w.y_mp, st));
-    DSP_CAPI_HIP(dsp::launch_spectrogram_f64(w.y_bp, cnt, n, stride, 16000, w.s_bp, st));
-    DSP_CAPI_HIP(dsp::launch_spectrogram_f64(w.y_mp, cnt, n, stride, 16000, w.s_mp, st));
+    DSP_CAPI_HIP(dsp::launch_iir2_f64(d_x, cnt, n, stride, row, c_bp, w.y_bp, c_mp, w.y_mp, st));
+    const bool dft = use_dft();
+    if (dft) {
+        DSP_CAPI_HIP(dsp::launch_spectrogram_f64(w.y_bp, cnt, n, row, 16000, w.s_bp, st));
+        DSP_CAPI_HIP(dsp::launch_spectrogram_f64(w.y_mp, cnt, n, row, 16000, w.s_mp, st));
+    } else {
+        DSP_CAPI_HIP(dsp::launch_spectrogram_f64_fft(w.y_bp, cnt, n, row, w.tab, w.s_bp, st));
+        DSP_CAPI_HIP(dsp::launch_spectrogram_f64_fft(w.y_mp, cnt, n, row, w.tab, w.s_mp, st));
+    }
     const dsp::ClassifyRuleD rule{cfg.keep_lo, cfg.keep_hi, cfg.midpoint_db, cfg.middle_max, cfg.above_min, cfg.below_min};
-    DSP_CAPI_HIP(dsp::launch_classify_f64_tail(w.s_bp, w.s_mp, cnt, n, 16000, rule, w.labels, want_trace ? w.trace : nullptr, st));
+    DSP_CAPI_HIP(dsp::launch_classify_f64_tail(w.s_bp, w.s_mp, cnt, n, 16000, rule, w.labels, want_trace ? w.trace : nullptr, st, !dft));
     return DSP_OK;
 }
 
-int reserve(Scratch &w, long clips, int n, long stride, bool need_x)
+// the workspace on `device` for sub-batches of `clips` clips of n samples; grows, never shrinks; moves with the device
+int reserve(Scratch &w, int device, long clips, int n, bool need_x)
 {
-    const size_t T = (size_t)columns(n), row = (size_t)stride;
+    const size_t T = (size_t)columns(n), row = (size_t)row_of(n);
+    if (w.device != device) {
+        if (w.device >= 0) {
+            dsp::DeviceScope on_old(w.device);
+            (void)hipDeviceSynchronize();
+            w.drop();
+            if (w.tab) (void)hipFree(w.tab);
+            w.tab = nullptr;
+        }
+        w.device = device;
+    }
+    if (!w.tab) {
+        dsp::SpecTablesD t;
+        dsp::build_spec_tables_f64(16000, t);
+        DSP_CAPI_HIP(hipMalloc(&w.tab, sizeof(t)));
+        DSP_CAPI_HIP(hipMemcpy(w.tab, &t, sizeof(t), hipMemcpyHostToDevice));
+    }
+    if (clips <= w.cap_clips && (long)row <= w.cap_row && (int)T <= w.cap_T && (!need_x || w.cap_x)) return DSP_OK;
+    (void)hipDeviceSynchronize();
+    need_x = need_x || w.cap_x;
+    clips = std::max(clips, w.cap_clips);
+    w.drop();
     if (need_x) DSP_CAPI_HIP(hipMalloc(&w.x, (size_t)clips * row * sizeof(double)));
     DSP_CAPI_HIP(hipMalloc(&w.y_bp, (size_t)clips * row * sizeof(double)));
     DSP_CAPI_HIP(hipMalloc(&w.y_mp, (size_t)clips * row * sizeof(double)));
@@ -67,6 +116,7 @@ int reserve(Scratch &w, long clips, int n, long stride, bool need_x)
     DSP_CAPI_HIP(hipMalloc(&w.s_mp, (size_t)clips * dsp::kSpecBins * T * sizeof(double)));
     DSP_CAPI_HIP(hipMalloc(&w.labels, (size_t)clips * sizeof(int)));
     DSP_CAPI_HIP(hipMalloc(&w.trace, (size_t)clips * sizeof(dsp::ClassifyTraceD)));
+    w.cap_clips = clips; w.cap_row = (long)row; w.cap_T = (int)T; w.cap_x = need_x;
     return DSP_OK;
 }
 
@@ -110,15 +160,17 @@ int dsp_classify_batch_device_f64(const dsp_classify_config_f64 *cfgp, const dou
         return DSP_OK;
     }
     if (n_clips == 1) stride = n;
-    Scratch w;
-    if ((rc = reserve(w, std::min(kSubBatch, n_clips), n, stride, false)) < 0) return rc;
+    std::lock_guard<std::mutex> lock(g_w.mu);
+    Scratch &w = g_w;
+    const long kSubBatch = sub_batch();
+    if ((rc = reserve(w, attr.device, std::min(kSubBatch, n_clips), n, false)) < 0) return rc;
     for (long c0 = 0; c0 < n_clips; c0 += kSubBatch) {
         const long cnt = std::min(kSubBatch, n_clips - c0);
         if ((rc = run(cfg, w, d_signal + c0 * stride, cnt, n, stride, d_trace != nullptr, st)) < 0) return rc;
         DSP_CAPI_HIP(hipMemcpyAsync(d_labels + c0, w.labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, st));
         if (d_trace) DSP_CAPI_HIP(hipMemcpyAsync(d_trace + c0, w.trace, (size_t)cnt * sizeof(dsp_classify_trace_f64), hipMemcpyDeviceToDevice, st));
     }
-    DSP_CAPI_HIP(hipStreamSynchronize(st));   // the scratch dies with this call
+    DSP_CAPI_HIP(hipStreamSynchronize(st));   // the workspace is free for the next call
     return DSP_OK;
 }
 
@@ -141,13 +193,16 @@ int dsp_classify_batch_host_f64(const dsp_classify_config_f64 *cfgp, const doubl
     if (device < 0 || device >= count) return dsp::capi_fail(DSP_EINVAL, "device index out of range");
     DSP_ON_DEVICE(device);
     if (n_clips == 1) stride = n;
-    Scratch w;
-    if ((rc = reserve(w, std::min(kSubBatch, n_clips), n, n, true)) < 0) return rc;
+    std::lock_guard<std::mutex> lock(g_w.mu);
+    Scratch &w = g_w;
+    const long kSubBatch = sub_batch();
+    if ((rc = reserve(w, device, std::min(kSubBatch, n_clips), n, true)) < 0) return rc;
+    const long row = row_of(n);
     for (long c0 = 0; c0 < n_clips; c0 += kSubBatch) {
         const long cnt = std::min(kSubBatch, n_clips - c0);
-        DSP_CAPI_HIP(hipMemcpy2D(w.x, (size_t)n * sizeof(double), signal + c0 * stride, (size_t)stride * sizeof(double), (size_t)n * sizeof(double),
+        DSP_CAPI_HIP(hipMemcpy2D(w.x, (size_t)row * sizeof(double), signal + c0 * stride, (size_t)stride * sizeof(double), (size_t)n * sizeof(double),
                                  (size_t)cnt, hipMemcpyHostToDevice));
-        if ((rc = run(cfg, w, w.x, cnt, n, n, trace != nullptr, nullptr)) < 0) return rc;
+        if ((rc = run(cfg, w, w.x, cnt, n, row, trace != nullptr, nullptr)) < 0) return rc;
         DSP_CAPI_HIP(hipMemcpy(labels + c0, w.labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost));
         if (trace) DSP_CAPI_HIP(hipMemcpy(trace + c0, w.trace, (size_t)cnt * sizeof(dsp_classify_trace_f64), hipMemcpyDeviceToHost));
     }

@@ -89,12 +89,15 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restri
     // hides the HBM latency even with one wave per SIMD.
     constexpr int PER = 16 / sizeof(TIO), CH = IIR_TS / PER;      // elements per vector, vectors per row
     constexpr int NV = 64 * CH / NTHR;                            // vectors per thread in the tile load
-    float4 pre[NV];
+    // (a vector of TIO, its elements taken by constant index: a float4 copied into double[2] made the compiler keep the prefetch
+    // in scratch memory, and a load parked in scratch is waited for on the spot -- the float64 kernel ran unpipelined)
+    typedef TIO VIO __attribute__((ext_vector_type(PER)));
+    VIO pre[NV];
     auto issue = [&](int t0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e = tid + NTHR * k, r = e / CH, cc = (e % CH) * PER;
-            pre[k] = r < rows ? *reinterpret_cast<const float4 *>(x + (clip0 + r) * stride + t0 + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pre[k] = r < rows ? *reinterpret_cast<const VIO *>(x + (clip0 + r) * stride + t0 + cc) : VIO(TIO(0));
         }
     };
     if (vec_ok && n >= IIR_TS) issue(0);
@@ -105,10 +108,8 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restri
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int e = tid + NTHR * k, r = e / CH, cc = (e % CH) * PER;
-                TIO tmp[PER];
-                __builtin_memcpy(tmp, &pre[k], 16);
 #pragma unroll
-                for (int i = 0; i < PER; ++i) tin[r * IIR_LD + cc + i] = tmp[i];
+                for (int i = 0; i < PER; ++i) tin[r * IIR_LD + cc + i] = pre[k][i];
             }
         } else
         for (int e = tid; e < 64 * IIR_TS; e += NTHR) {
@@ -160,12 +161,10 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restri
             for (int e = lane; e < 64 * CH; e += 64) {
                 const int r = e / CH, cc = (e % CH) * PER;
                 if (r < rows) {
-                    TIO tmp[PER];
-                    f4nt q;
+                    VIO q;
 #pragma unroll
-                    for (int i = 0; i < PER; ++i) tmp[i] = to[r * IIR_LD + cc + i];
-                    __builtin_memcpy(&q, tmp, 16);
-                    *reinterpret_cast<f4nt *>(y + (clip0 + r) * ystride + t0 + cc) = q;
+                    for (int i = 0; i < PER; ++i) q[i] = to[r * IIR_LD + cc + i];
+                    __builtin_nontemporal_store(q, reinterpret_cast<VIO *>(y + (clip0 + r) * ystride + t0 + cc));
                 }
             }
         } else
@@ -1415,6 +1414,15 @@ hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long strid
         if (even_taps_only(c)) launch(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, true>, rc_resident_blocks<SPEC_FRAME_MAJOR, true>(), (const int *)nullptr, hits);
         else launch(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, false>, rc_resident_blocks<SPEC_FRAME_MAJOR, false>(), (const int *)nullptr, hits);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_iir2_f64(const double *x, long n_clips, int n, long stride, long ystride, const IirCoefD &c1, double *y1,
+                           const IirCoefD &c2, double *y2, hipStream_t stream)
+{
+    if (n_clips <= 0 || n <= 0) return hipSuccess;
+    const int blocks = (int)((n_clips + 63) / 64);
+    hipLaunchKernelGGL((iir_kernel<double, IirCoefD, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, ystride, c1, y1, c2, y2, nullptr, nullptr);
     return hipGetLastError();
 }
 

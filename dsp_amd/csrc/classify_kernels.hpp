@@ -64,6 +64,9 @@ hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, cons
 hipError_t launch_iir_f64(const double *x, long n_clips, int n, long stride, const IirCoefD &c, double *y,
                           hipStream_t stream);
 // float rows, recurrence in double, one rounding on store (per-frame prefilter of BASELINE config 3)
+// both band-pass filters of the float64 classifier over one read of x: one wavefront per filter and 64 clips (rows of y1 / y2: ystride doubles)
+hipError_t launch_iir2_f64(const double *x, long n_clips, int n, long stride, long ystride, const IirCoefD &c1, double *y1,
+                           const IirCoefD &c2, double *y2, hipStream_t stream);
 hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long stride, const IirCoefD &c, float *y,
                                  hipStream_t stream);
 
@@ -140,10 +143,23 @@ struct ClassifyTraceD {
     double midpoints[kMaxMidpoints];
     double sums[kMaxMidpoints][3];
 };
-// sxx_bp / sxx_mp: [c][129][T] float64 PSD maps of the 3000-7500 Hz / 1000-3000 Hz filtered clips (launch_spectrogram_f64);
+// Host-built constants of the float64 spectrogram (classifier.c:484-530): the periodic Tukey(0.25) window and U = fs sum win^2,
+// evaluated on the host in double in the reference's order; exp(-2 pi i k / 256) for the transform.
+struct SpecTablesD {
+    double win[kSpecSeg];
+    double w_re[kSpecSeg / 2], w_im[kSpecSeg / 2];
+    double U;
+};
+void build_spec_tables_f64(int fs, SpecTablesD &t);
+// compute_spectrogram (classifier.c:448-592) of a batch for the classifier: one wavefront per frame, 256-point real transform as a
+// 128-point complex Stockham FFT through LDS; maps FRAME-major, sxx[c][t][129] (launch_spectrogram_f64 is the [129][T] direct DFT
+// behind dsp_compute_spectrogram_f64 and the yardstick of this one in the tests).  y rows must be 16-byte aligned (stride even).
+hipError_t launch_spectrogram_f64_fft(const double *y, long n_clips, int n, long stride, const SpecTablesD *tables, double *sxx, hipStream_t stream);
+// sxx_bp / sxx_mp: float64 PSD maps of the 3000-7500 Hz / 1000-3000 Hz filtered clips, [c][129][T] (launch_spectrogram_f64) or,
+// frame_major, [c][T][129] (launch_spectrogram_f64_fft);
 // labels[c] = the rule's verdict (classifier.c:184), trace (optional): midpoints and band sums per clip
 hipError_t launch_classify_f64_tail(const double *sxx_bp, const double *sxx_mp, long n_clips, int n, int fs, const ClassifyRuleD &rule,
-                                    int *labels, ClassifyTraceD *trace, hipStream_t stream);
+                                    int *labels, ClassifyTraceD *trace, hipStream_t stream, bool frame_major = false);
 
 void build_spec_tables(int fs, SpecTables &t);
 

@@ -65,7 +65,7 @@ constexpr int Q_W1024 = 4 * Q_WAVE_BYTES;          // block-shared: W1024^i, i <
 constexpr int Q_W2048 = Q_W1024 + 1024 * 8;        // block-shared: W2048^k, k < 512
 constexpr int Q_WIN = Q_W2048 + 512 * 8;           // block-shared: window pairs (win[2a][l], win[2a+1][l]) at [a][l]
 constexpr int Q_DCT = Q_WIN + 16 * 64 * 8;         // block-shared: dct_t[i][lane], i < ceil(n_mels / 2)
-constexpr int Q_BLOCK_BYTES = Q_DCT;               // + 256 B per DCT row, added by the launcher
+constexpr int Q_BLOCK_BYTES = Q_DCT;               // + 256 B per DCT row (+ POOL: 2 x 64 floats, the Scaler's offset | scale), added by the launcher
 
 }  // namespace
 
@@ -104,6 +104,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     constexpr bool WIN_LDS = POOL;
     if (WIN_LDS)
         for (int i = threadIdx.x; i < 16 * 64; i += 256) win2[i] = make_float2(G->win[2 * (i >> 6)][i & 63], G->win[2 * (i >> 6) + 1][i & 63]);
+    // POOL: the Scaler's offset | scale in a block-shared LDS copy behind the DCT rows (the clip's tail read them with dependent
+    // global loads, each behind an s_waitcnt that also drains the frame's loads; mfcc_kernels.hip, svm_small)
+    float *scaler = dct_t + half * 64;
+    (void)scaler;
+    if (POOL)
+        for (int i = threadIdx.x; i < 2 * n_mfcc; i += 256) { scaler[i] = args.pool.svm.offset[i]; scaler[64 + i] = args.pool.svm.scale[i]; }
     if (lane == 0) part[k2048SegZero] = 0.0f;
     __syncthreads();
 
@@ -383,19 +389,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                         pool.feat[clip_f * 2L * n_mfcc + c] = f_mean;
                         pool.feat[clip_f * 2L * n_mfcc + n_mfcc + c] = f_std;
                     }
-                    feat[c] = (f_mean - sm.offset[c]) * sm.scale[c];
-                    feat[n_mfcc + c] = (f_std - sm.offset[n_mfcc + c]) * sm.scale[n_mfcc + c];
+                    feat[c] = (f_mean - scaler[c]) * scaler[64 + c];
+                    feat[n_mfcc + c] = (f_std - scaler[n_mfcc + c]) * scaler[64 + n_mfcc + c];
                 }
                 wave_lds_sync();
                 float term = 0.0f;                               // same arithmetic as svm_kernel (svm_kernels.hip)
                 for (int sidx = lane; sidx < sm.n_sv; sidx += 64) {
                     const float *sv = sm.sv + (long)sidx * sm.n_features;
+                    const float cf = sm.coef[sidx];
                     float d2 = 0.0f;
-                    for (int j = 0; j < sm.n_features; ++j) {
+                    int j = 0;
+                    for (; j + 8 <= sm.n_features; j += 8) {     // eight loads in flight, then the same additions in the same order
+                        float v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = sv[j + k];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float dd = feat[j + k] - v[k];
+                            d2 = d2 + dd * dd;
+                        }
+                    }
+                    for (; j < sm.n_features; ++j) {
                         const float dd = feat[j] - sv[j];
                         d2 = d2 + dd * dd;
                     }
-                    term = term + sm.coef[sidx] * expf(-sm.gamma * d2);
+                    term = term + cf * expf(-sm.gamma * d2);
                 }
                 for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o);
                 if (lane == 0) {
@@ -414,13 +432,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     }
 }
 
-static size_t lds_bytes_2048(int n_mels) { return (size_t)Q_BLOCK_BYTES + (size_t)((n_mels + 1) / 2) * 256; }
+static size_t lds_bytes_2048(int n_mels, bool pool) { return (size_t)Q_BLOCK_BYTES + (size_t)((n_mels + 1) / 2) * 256 + (pool ? 128 * 4 : 0); }
 
 hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables, int blocks, hipStream_t stream, bool pool)
 {
     const bool clips = args.frames_per_clip > 0;
     const dim3 g(blocks), b(256);
-    const size_t Q_BLOCK_BYTES = lds_bytes_2048(args.n_mels);
+    const size_t Q_BLOCK_BYTES = lds_bytes_2048(args.n_mels, pool);
     const bool aub = args.spectrum != 0 || args.log_mode == 2 || args.stream_framing != 0;
     if (args.stream_framing && (!clips || args.samples_per_clip <= 0 || args.hop > args.frame_len)) return hipErrorInvalidConfiguration;
     if (pool) {
@@ -442,8 +460,8 @@ hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables,
 int mfcc2048_blocks_per_cu(int n_mels, bool pool)
 {
     int n = 0;
-    hipError_t e = pool ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<true, true>, 256, lds_bytes_2048(n_mels))
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<false, false>, 256, lds_bytes_2048(n_mels));
+    hipError_t e = pool ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<true, true>, 256, lds_bytes_2048(n_mels, true))
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<false, false>, 256, lds_bytes_2048(n_mels, false));
     return e == hipSuccess && n > 0 ? n : 2;
 }
 

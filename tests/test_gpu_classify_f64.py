@@ -1,7 +1,10 @@
 """GPU: the float64 classifier of donut-classifier/classifier.c (dsp_classify_batch_*_f64: both Butterworth filters, both
 spectrograms, dB maps, 45 dB midpoints, normalisation, keep band, band sums and rule in double) against the oracle's float64
 restatement (oracle/classify_f64_oracle.c).  The reference transforms with FFTW (unvendored): the GPU spectrogram is a float64
-DFT, so the bar is tolerance -- labels and midpoint counts equal, midpoints to 1e-12 s, band sums to 1e-8 relative."""
+transform of its own (batches: a 128-point complex FFT per wavefront; DSP_AMD_F64_DFT=1: the direct DFT), so the bar is tolerance
+-- labels and midpoint counts equal, midpoints to 1e-12 s, band sums to 1e-8 relative."""
+import os
+
 import numpy as np
 import pytest
 
@@ -74,12 +77,19 @@ def test_lengths_sub_batches_and_the_device_entry_point(dsp):
         x = S.uniform_pm1(n, 40 + n).astype(np.float64)[None, :] * 0.3
         labels, trace = dsp.classify_batch_f64(x, with_trace=True)
         _check(labels[0], trace[0], x[0], what=f"len{n}")
-    # more clips than one scratch pass (2048): every clip is its own problem, whatever its place in the batch
+    # more clips than one scratch pass (the library reads DSP_AMD_F64_SUB_BATCH per call; default 65 536): every clip is its own
+    # problem, whatever its place in the batch
     call = S.classify_cases()["scrub_a"].astype(np.float64)
     rng = np.random.default_rng(5)
     clips = rng.uniform(-0.05, 0.05, (2100, 16000))
     clips[::7] = clips[::7] * 0.01 + call                          # the call over a quiet floor: label 1
-    labels = dsp.classify_batch_f64(clips)
+    os.environ["DSP_AMD_F64_SUB_BATCH"] = "2048"
+    try:
+        labels = dsp.classify_batch_f64(clips)
+        assert np.array_equal(dsp.classify_device_f64(torch.from_numpy(clips).cuda()).cpu().numpy(), labels)
+    finally:
+        del os.environ["DSP_AMD_F64_SUB_BATCH"]
+    assert np.array_equal(dsp.classify_batch_f64(clips), labels)   # one pass: the same labels
     for i in (0, 1, 6, 7, 2047, 2048, 2093, 2099):
         assert labels[i] == O.classify_f64(clips[i])[0], i
     assert not labels[1::7].any() and labels[::7].sum() >= 290
@@ -90,3 +100,39 @@ def test_lengths_sub_batches_and_the_device_entry_point(dsp):
     padded = torch.zeros((64, 16016), dtype=torch.float64, device="cuda")
     padded[:, :16000] = torch.from_numpy(clips[:64]).cuda()
     assert np.array_equal(dsp.classify_device_f64(padded[:, :16000]).cpu().numpy(), labels[:64])
+
+
+def test_fft_spectrogram_path_against_the_direct_dft_path(dsp):
+    """The batch path's spectrogram is a 128-point complex FFT per wavefront (frame-major maps); DSP_AMD_F64_DFT=1 (read per call)
+    routes the same batch through the direct 256-point DFT ([129][T] maps) -- two independent transforms and two map layouts under
+    the same tail: labels and midpoints equal, band sums to 1e-10 relative."""
+    cases = S.classify_cases()
+    rng = np.random.default_rng(11)
+    clips = np.concatenate([np.stack([c.astype(np.float64) for c in cases.values()]),
+                            rng.uniform(-0.3, 0.3, (40, 16000)),
+                            rng.uniform(-0.01, 0.01, (20, 16000)) + cases["scrub_a"].astype(np.float64)])
+    labels, trace = dsp.classify_batch_f64(clips, with_trace=True)
+    os.environ["DSP_AMD_F64_DFT"] = "1"
+    try:
+        labels_d, trace_d = dsp.classify_batch_f64(clips, with_trace=True)
+    finally:
+        del os.environ["DSP_AMD_F64_DFT"]
+    assert np.array_equal(labels, labels_d) and labels.any() and not labels.all()
+    n_mid = 0
+    for (m, s), (md, sd) in zip(trace, trace_d):
+        assert m.shape == md.shape and np.array_equal(m, md)
+        assert np.allclose(s, sd, rtol=1e-10, atol=1e-10)
+        n_mid += len(m)
+    assert n_mid >= 25
+    # odd lengths (rows of the workspace are padded to 16 bytes) and a single segment
+    for n in (256, 479, 5001):
+        x = rng.uniform(-0.3, 0.3, (3, n))
+        a = dsp.classify_batch_f64(x, with_trace=True)
+        os.environ["DSP_AMD_F64_DFT"] = "1"
+        try:
+            b = dsp.classify_batch_f64(x, with_trace=True)
+        finally:
+            del os.environ["DSP_AMD_F64_DFT"]
+        assert np.array_equal(a[0], b[0])
+        for (m, s), (md, sd) in zip(a[1], b[1]):
+            assert np.array_equal(m, md) and np.allclose(s, sd, rtol=1e-10, atol=1e-10)

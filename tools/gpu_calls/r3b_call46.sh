@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out/r3b
+timeout -k 10 900 python -m pytest tests/test_gpu_classify_f64.py -m gpu -x -q > gpurun_out/r3b/tests46.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -3 gpurun_out/r3b/tests46.log | cut -c1-300
+[ $rc -eq 0 ] || { tail -40 gpurun_out/r3b/tests46.log; exit 1; }
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r3b/f64_prof4 -- python3 $GRAFT_REPO_ROOT/bench.py --workload classify_f64 --clips 49152 --no-cpu-baseline --steps 30 --settle 0 > $GRAFT_REPO_ROOT/gpurun_out/r3b/f64_prof4.json 2>/dev/null; echo "prof rc=$?"
+find $GRAFT_REPO_ROOT/gpurun_out/r3b/f64_prof4 -name "*kernel_stats.csv" | head -1 | xargs -r head -4 | cut -c1-60,150-260
