@@ -303,18 +303,21 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         what = f"BASELINE configs[3] per-GPU share: {n} x 1 s 16 kHz fp32 clips, frame 400 / hop 160 -> [98][13] per clip"
         kernel = "mfcc512_wave_kernel"
     elif args.workload == "classify_f64":
-        # the float64 classifier of donut-classifier/classifier.c (parity path, untuned: lane-per-clip IIR, full maps in HBM)
-        n = args.clips or 8192
-        clips = (torch.rand((n, 16000), device=dev, generator=gen, dtype=torch.float64) * 2 - 1) * 0.05
+        # the float64 classifier of donut-classifier/classifier.c
+        n = args.clips or 49152
+        # this classifier's midpoint threshold is 45 dB (classifier.c:660; classifier.cpp's is 70): noise of amplitude 0.05 has
+        # loud bins in every frame and a midpoint in every clip; 0.005 stays below, so that -- as in the float32 workload --
+        # every fourth clip (the call) reaches the spectrogram of the second filter and the band sums
+        clips = (torch.rand((n, 16000), device=dev, generator=gen, dtype=torch.float64) * 2 - 1) * 0.005
         from tests import signals as S
         call = torch.from_numpy(S.classify_cases()["scrub_a"]).to(dev).double()
-        clips[::4] = call + clips[::4] * 0.01
+        clips[::4] = call + clips[::4] * 0.1
         labels = torch.empty(n, dtype=torch.int32, device=dev)
         step = lambda: dsp_amd.classify_device_f64(clips, labels)   # noqa: E731
         units, unit, bytes_per = n, "clips/s", 128_000 + 4
         what = (f"{n} x 1 s 16 kHz float64 clips (25 % with a call-like burst pattern) through the float64 classify() of "
                 "donut-classifier/classifier.c")
-        kernel = "iir_kernel<double> x 2 + spectrogram_kernel<double> x 2 + classify_f64 tail kernels"
+        kernel = "iir_kernel<double, two filters> + spectrogram_f64_fft_kernel<flags> + classify_f64_midpoints_kernel + spectrogram_f64_fft_kernel<maps> + classify_f64_bands_kernel"
     else:
         n = args.clips or 49152
         clips = (torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1) * 0.05

@@ -1,8 +1,10 @@
 // capi_classify_f64.cpp -- C ABI of the float64 classifier (include/dsp_amd.h: dsp_classify_batch_*_f64), the whole
 // per-clip chain of donut-classifier/classifier.c:83-192 on the GPU in double:
-//     butter_bandpass_filter (3000-7500 Hz and, inside find_midpoints, 1000-3000 Hz; :420-446)  iir_kernel<double>
-//     compute_spectrogram of both (:448-592)                                                     spectrogram_f64_kernel
-//     dB maps, 45 dB midpoints, normalisation, keep band, band sums, rule (:105-190, :594-830)   classify_f64_tail_kernel
+//     butter_bandpass_filter (3000-7500 Hz and, inside find_midpoints, 1000-3000 Hz; :420-446)  iir_kernel<double>, both filters in one launch
+//     compute_spectrogram of the 1000-3000 Hz output (:448-592) -> loud time bins (:679-745)     spectrogram_f64_fft_kernel<flags>
+//     clusters -> midpoints (:747-800), work list of the clips that have any                     classify_f64_midpoints_kernel
+//     compute_spectrogram of the 3000-7500 Hz output, listed clips only                          spectrogram_f64_fft_kernel<maps>
+//     dB map, normalisation, keep band, band sums, rule (:105-190, :594-653)                     classify_f64_bands_kernel
 // Sub-batches of up to 65 536 clips (one recurrence wavefront per SIMD and filter) through a grow-only scratch workspace that
 // stays with the library, like the float32 classifier's (capi.cpp, ClassifyCtx).  DSP_AMD_F64_DFT=1 routes the batch through the
 // direct-DFT spectrogram ([129][T] maps) instead of the FFT kernel: the yardstick of tests/test_gpu_classify_f64.py.
@@ -20,7 +22,7 @@ static_assert(sizeof(dsp::ClassifyTraceD) == sizeof(dsp_classify_trace_f64), "tr
 
 namespace {
 
-constexpr long kSubBatchDefault = 65536;   // clips per pass: 402 KB of float64 scratch per 1 s clip (26 GB at the full sub-batch)
+constexpr long kSubBatchDefault = 65536;   // clips per pass: 330 KB of float64 scratch per 1 s clip (22 GB at the full sub-batch)
 constexpr int kMaxColumns = 957;           // as the float32 path (capi.cpp kMaxSpecColumns): at most 64 midpoints fit such a clip
 
 int columns(int n) { return n < dsp::kSpecSeg ? 0 : (n - dsp::kSpecSeg) / dsp::kSpecHop + 1; }
@@ -28,8 +30,9 @@ int columns(int n) { return n < dsp::kSpecSeg ? 0 : (n - dsp::kSpecSeg) / dsp::k
 struct Scratch {
     int device = -1;
     dsp::SpecTablesD *tab = nullptr;
-    double *x = nullptr, *y_bp = nullptr, *y_mp = nullptr, *s_bp = nullptr, *s_mp = nullptr;
-    int *labels = nullptr;
+    double U = 0.0;                            // SpecTablesD::U of tab
+    double *x = nullptr, *y_bp = nullptr, *y_mp = nullptr, *s_bp = nullptr, *s_mp = nullptr, *mids = nullptr;      // s_mp: DSP_AMD_F64_DFT only
+    int *labels = nullptr, *loud = nullptr, *n_mids = nullptr, *hits = nullptr;
     dsp::ClassifyTraceD *trace = nullptr;
     long cap_clips = 0, cap_row = 0;           // what the workspace holds: clips x row doubles (x only when cap_x)
     int cap_T = 0;
@@ -37,9 +40,10 @@ struct Scratch {
     std::mutex mu;
     void drop()
     {
-        for (void *p : {(void *)x, (void *)y_bp, (void *)y_mp, (void *)s_bp, (void *)s_mp, (void *)labels, (void *)trace})
+        for (void *p : {(void *)x, (void *)y_bp, (void *)y_mp, (void *)s_bp, (void *)s_mp, (void *)mids, (void *)labels, (void *)loud, (void *)n_mids,
+                        (void *)hits, (void *)trace})
             if (p) (void)hipFree(p);
-        x = y_bp = y_mp = s_bp = s_mp = nullptr; labels = nullptr; trace = nullptr;
+        x = y_bp = y_mp = s_bp = s_mp = mids = nullptr; labels = loud = n_mids = hits = nullptr; trace = nullptr;
         cap_clips = cap_row = 0; cap_T = 0; cap_x = false;
     }
 };
@@ -71,16 +75,19 @@ int run(const dsp_classify_config_f64 &cfg, Scratch &w, const double *d_x, long 
     dsp_butter_bandpass(1000.0, 3000.0, b, a);                       // :659-664
     for (int i = 0; i < 9; ++i) { c_mp.b[i] = b[i]; c_mp.a[i] = a[i]; }
     DSP_CAPI_HIP(dsp::launch_iir2_f64(d_x, cnt, n, stride, row, c_bp, w.y_bp, c_mp, w.y_mp, st));
-    const bool dft = use_dft();
-    if (dft) {
+    const dsp::ClassifyRuleD rule{cfg.keep_lo, cfg.keep_hi, cfg.midpoint_db, cfg.middle_max, cfg.above_min, cfg.below_min};
+    dsp::ClassifyTraceD *tr = want_trace ? w.trace : nullptr;
+    if (use_dft()) {                          // the yardstick: direct DFT, [129][T] maps of both outputs, one tail kernel per clip
+        if (!w.s_mp) DSP_CAPI_HIP(hipMalloc(&w.s_mp, (size_t)w.cap_clips * dsp::kSpecBins * (size_t)w.cap_T * sizeof(double)));
         DSP_CAPI_HIP(dsp::launch_spectrogram_f64(w.y_bp, cnt, n, row, 16000, w.s_bp, st));
         DSP_CAPI_HIP(dsp::launch_spectrogram_f64(w.y_mp, cnt, n, row, 16000, w.s_mp, st));
-    } else {
-        DSP_CAPI_HIP(dsp::launch_spectrogram_f64_fft(w.y_bp, cnt, n, row, w.tab, w.s_bp, st));
-        DSP_CAPI_HIP(dsp::launch_spectrogram_f64_fft(w.y_mp, cnt, n, row, w.tab, w.s_mp, st));
+        DSP_CAPI_HIP(dsp::launch_classify_f64_tail(w.s_bp, w.s_mp, cnt, n, 16000, rule, w.labels, tr, st));
+        return DSP_OK;
     }
-    const dsp::ClassifyRuleD rule{cfg.keep_lo, cfg.keep_hi, cfg.midpoint_db, cfg.middle_max, cfg.above_min, cfg.below_min};
-    DSP_CAPI_HIP(dsp::launch_classify_f64_tail(w.s_bp, w.s_mp, cnt, n, 16000, rule, w.labels, want_trace ? w.trace : nullptr, st, !dft));
+    DSP_CAPI_HIP(dsp::launch_spectrogram_f64_flags(w.y_mp, cnt, n, row, w.tab, cfg.midpoint_db, w.loud, st));
+    DSP_CAPI_HIP(dsp::launch_classify_f64_midpoints(w.loud, cnt, n, 16000, w.mids, w.n_mids, w.hits, w.labels, tr, st));
+    DSP_CAPI_HIP(dsp::launch_spectrogram_f64_listed(w.y_bp, cnt, n, row, w.tab, w.hits, w.s_bp, st));
+    DSP_CAPI_HIP(dsp::launch_classify_f64_bands(w.s_bp, w.hits, cnt, n, 16000, w.U, rule, w.mids, w.n_mids, w.labels, tr, st));
     return DSP_OK;
 }
 
@@ -103,6 +110,7 @@ int reserve(Scratch &w, int device, long clips, int n, bool need_x)
         dsp::build_spec_tables_f64(16000, t);
         DSP_CAPI_HIP(hipMalloc(&w.tab, sizeof(t)));
         DSP_CAPI_HIP(hipMemcpy(w.tab, &t, sizeof(t), hipMemcpyHostToDevice));
+        w.U = t.U;
     }
     if (clips <= w.cap_clips && (long)row <= w.cap_row && (int)T <= w.cap_T && (!need_x || w.cap_x)) return DSP_OK;
     (void)hipDeviceSynchronize();
@@ -113,7 +121,10 @@ int reserve(Scratch &w, int device, long clips, int n, bool need_x)
     DSP_CAPI_HIP(hipMalloc(&w.y_bp, (size_t)clips * row * sizeof(double)));
     DSP_CAPI_HIP(hipMalloc(&w.y_mp, (size_t)clips * row * sizeof(double)));
     DSP_CAPI_HIP(hipMalloc(&w.s_bp, (size_t)clips * dsp::kSpecBins * T * sizeof(double)));
-    DSP_CAPI_HIP(hipMalloc(&w.s_mp, (size_t)clips * dsp::kSpecBins * T * sizeof(double)));
+    DSP_CAPI_HIP(hipMalloc(&w.mids, (size_t)clips * dsp::kMaxMidpoints * sizeof(double)));
+    DSP_CAPI_HIP(hipMalloc(&w.loud, (size_t)clips * T * sizeof(int)));
+    DSP_CAPI_HIP(hipMalloc(&w.n_mids, (size_t)clips * sizeof(int)));
+    DSP_CAPI_HIP(hipMalloc(&w.hits, ((size_t)clips + 1) * sizeof(int)));
     DSP_CAPI_HIP(hipMalloc(&w.labels, (size_t)clips * sizeof(int)));
     DSP_CAPI_HIP(hipMalloc(&w.trace, (size_t)clips * sizeof(dsp::ClassifyTraceD)));
     w.cap_clips = clips; w.cap_row = (long)row; w.cap_T = (int)T; w.cap_x = need_x;

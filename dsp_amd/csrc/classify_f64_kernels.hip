@@ -1,23 +1,26 @@
 // classify_f64_kernels.hip -- the float64 scrub-jay classifier of donut-classifier/classifier.c (main's per-file body :83-192,
-// sum_intense :594-653, find_midpoints :655-830) after its two band-pass filters and spectrograms (iir_kernel<double>,
-// spectrogram_f64_kernel in classify_kernels.hip): dB maps, 45 dB midpoints, clip-global normalisation, keep band, three
-// band sums per midpoint, rule.  One 256-thread block per clip, everything in double.
+// sum_intense :594-653, find_midpoints :655-830) after its two band-pass filters (iir_kernel<double>, classify_kernels.hip).
+// A batch runs as
+//   spectrogram_f64_fft_kernel<flags>   1000-3000 Hz output: a wavefront per frame (128-point complex Stockham FFT through LDS); only
+//                                       "a cell of this time bin is above the midpoint threshold" leaves the kernel (:679-745)
+//   classify_f64_midpoints_kernel       a thread per clip clusters the flagged bins and averages them in the reference's order
+//                                       (:747-800); clips with midpoints go on a work list, the others are label 0
+//   spectrogram_f64_fft_kernel<maps>    3000-7500 Hz output of the listed clips only: PSD maps, frame-major [entry][t][129]
+//   classify_f64_bands_kernel           a block per listed clip: minimum / maximum dB of the map (:105-125), then per midpoint, until
+//                                       the rule fires, the three band sums (:170-190): the band window = the reference's index
+//                                       searches (:597-639; the frequency rows are the same for every clip and come from the host,
+//                                       the time columns are counted in parallel over the monotonic bin times), its kept cells
+//                                       staged into LDS by all threads, then ONE wave adds them row by row, column by column, NaN
+//                                       cells skipped -- the order of a float64 sum is part of its value (:643-651)
+// and, as the yardstick of that pipeline in the tests (DSP_AMD_F64_DFT=1), over the [129][T] maps of the direct DFT
+// (spectrogram_f64_kernel, classify_kernels.hip, the transform behind dsp_compute_spectrogram_f64) as ONE kernel per clip,
+// classify_f64_tail_kernel: flags, midpoints, minimum / maximum, band sums, rule.
 //
-//   phase A  1000-3000 Hz map: time bins with a cell above the threshold (any order: a flag per column)
-//   phase B  one thread clusters the blob times and averages them in the reference's order (:747-800)
-//   phase C  3000-7500 Hz map: minimum / maximum of the dB values over the clip (order-independent, exact)
-//   phase D  per midpoint, until the rule fires: the band window = the reference's index searches (:597-639; the frequency rows are
-//            the same for every clip and come from the host, the time columns are counted in parallel over the monotonic bin
-//            times: the first bin not below t - half = the number of bins below it), its kept cells staged into LDS by all
-//            threads, then ONE thread adds them row by row, column by column, NaN cells skipped -- the order of a float64 sum is
-//            part of its value (:643-651)
-//
-// FFTW (the reference's transform) is unvendored, so the spectrogram is a float64 transform checked by tolerance -- for batches
-// spectrogram_f64_fft_kernel below (a wavefront per frame, 128-point complex Stockham FFT through LDS, maps frame-major), for
-// dsp_compute_spectrogram_f64 the direct DFT of classify_kernels.hip; from there on every operation is the reference's, and what can
-// differ is the last bit of log10 (ocml vs glibc).  Two shortcuts that cannot change a decision: a cell's "dB above the midpoint
-// threshold" is decided by comparing the cell with the threshold's power unless it lies within 1e-9 relative of it (then the
-// reference's expression is evaluated), and the clip's minimum / maximum dB are the dB of its smallest / largest positive cell.
+// FFTW (the reference's transform) is unvendored, so the spectrogram is a float64 transform checked by tolerance; from there on every
+// operation is the reference's, and what can differ is the last bit of log10 (ocml vs glibc).  Two shortcuts that cannot change a
+// decision: a cell's "dB above the midpoint threshold" is decided by comparing the cell with the threshold's power unless it lies
+// within 1e-9 relative of it (then the reference's expression is evaluated), and the clip's minimum / maximum dB are the dB of its
+// smallest / largest positive cell.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -43,6 +46,14 @@ __device__ __forceinline__ void wave_sync_lds()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// find_midpoints' "10 log10(s / 1e-12) > midpoint_db" (:688-745).  A cell well above / below the threshold's power mid_power =
+// 1e-12 * 10^(midpoint_db / 10) is decided by a comparison; within 1e-9 relative of it (4e-9 dB, against the ~1e-14 dB the
+// expression's roundings can move) the reference's expression decides
+__device__ __forceinline__ bool is_loud(double s, double mid_power, double midpoint_db)
+{
+    return s > mid_power * (1.0 + 1e-9) || (s >= mid_power * (1.0 - 1e-9) && s > 0 && to_db64(s) > midpoint_db);
+}
+
 struct cd { double re, im; };
 __device__ __forceinline__ cd operator+(cd a, cd b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cd operator-(cd a, cd b) { return {a.re - b.re, a.im - b.im}; }
@@ -55,10 +66,15 @@ __device__ __forceinline__ cd cmul(cd a, double wr, double wi) { return {a.re * 
 // from a wave reduction, the detrended windowed samples are packed as z[n] = x[2 n] + i x[2 n + 1] and go through a radix-2 Stockham
 // FFT of 128 points (seven stages, two points per lane, ping-pong through 4 KB of LDS per wave, the window and the per-stage twiddles
 // in registers), then the real spectrum X[k] = E[k] + W256^k O[k] is taken from Z[k] and conj(Z[128 - k]), and
-// |X|^2 / U (doubled for 0 < k < 128) is stored at sxx[frame][k].
-__global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *__restrict__ y, long total, int T, long stride,
-                                                                  const SpecTablesD *__restrict__ tab, double *__restrict__ sxx)
+// |X|^2 / U (doubled for 0 < k < 128) is the PSD cell of bin k (:574-592).
+//   MAPS = false  every frame of every clip: loud[frame] = one of its 129 cells is above the midpoint threshold (no map leaves the kernel)
+//   MAPS = true   the frames of the clips on the work list hits (hits[0] entries, clip numbers from hits[1]): sxx[entry][t][k] = U * PSD
+template <bool MAPS>
+__global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *__restrict__ y, long n_clips, int T, long stride,
+                                                                  const SpecTablesD *__restrict__ tab, const int *__restrict__ hits,
+                                                                  double *__restrict__ sxx, int *__restrict__ loud, double mid_power, double midpoint_db)
 {
+    const long total = (MAPS ? (long)hits[0] : n_clips) * T;
     __shared__ __attribute__((aligned(16))) cd buf[4][2][kSpecSeg / 2];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     cd *cur = buf[wib][0], *nxt = buf[wib][1];
@@ -73,12 +89,14 @@ __global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *
         jout[s] = ((lane - k) << 1) + k;
     }
     const double pr0 = tab->w_re[lane], pi0 = tab->w_im[lane], pr1 = tab->w_re[lane + 64], pi1 = tab->w_im[lane + 64];
-    const double U = tab->U;
+    const double U = tab->U, mid_power_u = mid_power * U;
+    (void)mid_power_u;
     const long wave = (long)blockIdx.x * 4 + wib, n_waves = (long)gridDim.x * 4;
     typedef double d2 __attribute__((ext_vector_type(2)));
     auto src_of = [&](long f) {
-        const long clip = f / T;
-        return y + clip * stride + (f - clip * T) * (long)kSpecHop + 2 * lane;
+        const long e = f / T;
+        const long clip = MAPS ? (long)hits[1 + e] : e;
+        return y + clip * stride + (f - e * T) * (long)kSpecHop + 2 * lane;
     };
     d2 na = {0, 0}, nb = {0, 0};
     if (wave < total) {
@@ -111,24 +129,38 @@ __global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *
             cd *t = cur; cur = nxt; nxt = t;
         }
         // Z in natural order in cur.  X[k] = (A + B) / 2 + W256^k (A - B) / (2 i), A = Z[k], B = conj(Z[128 - k])
+        // |X[k]|^2, doubled for the one-sided spectrum (:574-592): the cell is this over U.  The division is left to whoever needs
+        // the cell's value: x / U is monotonic in x and commutes with the doubling, so the map kernel stores U * PSD and the band
+        // kernel divides the cells it uses, and the flags compare against U * threshold unless the cell is within 2e-9 of it
         auto bin = [&](int k, double wr, double wi) {
             const cd A = cur[k & 127], Zb = cur[(128 - k) & 127];
             const cd e2 = {A.re + Zb.re, A.im - Zb.im}, d = {A.re - Zb.re, A.im + Zb.im};
             const cd o2 = {d.im, -d.re};
             const cd x2 = e2 + cmul(o2, wr, wi);
             const double re = 0.5 * x2.re, im = 0.5 * x2.im;
-            return (re * re + im * im) / U;                              // :574-586
+            return re * re + im * im;
         };
-        double p0 = bin(lane, pr0, pi0);
-        const double p1 = bin(lane + 64, pr1, pi1) * 2.0;
-        if (lane > 0) p0 *= 2.0;
-        double *out = sxx + f * (long)kSpecBins;
-        out[lane] = p0;
-        out[lane + 64] = p1;
-        if (lane == 0) {
-            const cd Z0 = cur[0];
-            const double r = Z0.re - Z0.im;                              // X[128] = E[0] - O[0]
-            out[128] = (r * r) / U;
+        double m0 = bin(lane, pr0, pi0);
+        const double m1 = bin(lane + 64, pr1, pi1) * 2.0;
+        if (lane > 0) m0 *= 2.0;
+        const cd Z0 = cur[0];
+        const double r128 = Z0.re - Z0.im;                               // X[128] = E[0] - O[0]
+        const double m128 = r128 * r128;
+        if (MAPS) {
+            double *out = sxx + f * (long)kSpecBins;
+            out[lane] = m0;
+            out[lane + 64] = m1;
+            if (lane == 0) out[128] = m128;
+        } else {
+            auto loud_cell = [&](double m) {
+                if (m > mid_power_u * (1.0 + 2e-9)) return true;
+                if (m < mid_power_u * (1.0 - 2e-9)) return false;
+                return is_loud(m / U, mid_power, midpoint_db);
+            };
+            bool any = loud_cell(m0) || loud_cell(m1);
+            if (lane == 0) any = any || loud_cell(m128);
+            const bool hit = __ballot(any) != 0;
+            if (lane == 0) loud[f] = hit;
         }
         wave_sync_lds();                                                 // the next frame's stage 0 overwrites what bin() read (six swaps: cur is buf[wib][0] again)
     }
@@ -155,114 +187,112 @@ void build_spec_tables_f64(int fs, SpecTablesD &t)
     }
 }
 
-hipError_t launch_spectrogram_f64_fft(const double *y, long n_clips, int n, long stride, const SpecTablesD *tables, double *sxx, hipStream_t stream)
+namespace {
+
+template <bool MAPS>
+int fft_resident_blocks()                     // blocks that fit the GPU at once: the waves walk the frames from there
 {
-    const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
-    if (n_clips <= 0 || T <= 0) return hipSuccess;
-    if (stride % 2 != 0 || reinterpret_cast<uintptr_t>(y) % 16 != 0) return hipErrorInvalidValue;
-    const long total = n_clips * T;
-    static int resident = 0;                  // blocks that fit the GPU at once: the waves walk the frames from there
+    static int resident = 0;
     if (resident == 0) {
         int dev = 0, cus = 0, per = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, spectrogram_f64_fft_kernel, 256, 0) != hipSuccess || cus <= 0 || per <= 0) {
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, spectrogram_f64_fft_kernel<MAPS>, 256, 0) != hipSuccess || cus <= 0 || per <= 0) {
             (void)hipGetLastError();
             cus = 256; per = 2;
         }
         resident = cus * per;
     }
-    const long blocks = std::min<long>((total + 3) / 4, resident);
-    hipLaunchKernelGGL(spectrogram_f64_fft_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, y, total, T, stride, tables, sxx);
+    return resident;
+}
+
+int columns_of(int n) { return n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1; }
+
+}  // namespace
+
+hipError_t launch_spectrogram_f64_flags(const double *y, long n_clips, int n, long stride, const SpecTablesD *tables, double midpoint_db,
+                                        int *loud, hipStream_t stream)
+{
+    const int T = columns_of(n);
+    if (n_clips <= 0 || T <= 0) return hipSuccess;
+    if (stride % 2 != 0 || reinterpret_cast<uintptr_t>(y) % 16 != 0) return hipErrorInvalidValue;
+    const long blocks = std::min<long>((n_clips * T + 3) / 4, fft_resident_blocks<false>());
+    const double mid_power = 1e-12 * std::pow(10.0, midpoint_db / 10.0);
+    hipLaunchKernelGGL(spectrogram_f64_fft_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, y, n_clips, T, stride, tables,
+                       (const int *)nullptr, (double *)nullptr, loud, mid_power, midpoint_db);
+    return hipGetLastError();
+}
+
+hipError_t launch_spectrogram_f64_listed(const double *y, long n_clips, int n, long stride, const SpecTablesD *tables, const int *hits,
+                                         double *sxx, hipStream_t stream)
+{
+    const int T = columns_of(n);
+    if (n_clips <= 0 || T <= 0) return hipSuccess;
+    if (stride % 2 != 0 || reinterpret_cast<uintptr_t>(y) % 16 != 0) return hipErrorInvalidValue;
+    const long blocks = std::min<long>((n_clips * T + 3) / 4, fft_resident_blocks<true>());      // the bound: the list's count is read on the device
+    hipLaunchKernelGGL(spectrogram_f64_fft_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, y, n_clips, T, stride, tables, hits, sxx,
+                       (int *)nullptr, 0.0, 0.0);
     return hipGetLastError();
 }
 
 struct BandRows { int f0[3], f1[3]; };       // sum_intense's frequency rows of the three bands (classifier.c:597-617), the same for every clip
 
-template <bool FM>
-__global__ __launch_bounds__(256) void classify_f64_tail_kernel(const double *__restrict__ sxx_bp, const double *__restrict__ sxx_mp, long n_clips,
-                                                                int T, int fs, ClassifyRuleD rule, double mid_power, BandRows bands,
-                                                                int *__restrict__ labels, ClassifyTraceD *__restrict__ trace)
-{
-    __shared__ double times[kMaxColsF64];
-    __shared__ int flags[kMaxColsF64];
-    __shared__ double red_lo[256], red_hi[256];
-    __shared__ double mids[kMaxMidpoints];
-    __shared__ double win[kWinCells];
-    __shared__ int sh_i[8];                 // n_mid, f0, f1, t0, t1, staged, hit
-    const int tid = threadIdx.x;
-    const long clip = blockIdx.x;
-    if (clip >= n_clips) return;
-    const double *mp = sxx_mp + clip * (long)kSpecBins * T;
-    const double *bp = sxx_bp + clip * (long)kSpecBins * T;
-    const int cells = kSpecBins * T;
-    auto time_of = [&](int j) { return times[j]; };      // classifier.c compute_spectrogram (:478-481): segment centres
+namespace {
 
-    // ---- phase A: find_midpoints' mask (:679-745) ------------------------------------------------------------------------
-    for (int j = tid; j < T; j += 256) { flags[j] = 0; times[j] = (double)(j * kSpecHop + kSpecSeg / 2) / (double)fs; }
-    __syncthreads();
-    // a cell well above / below the threshold's power mid_power = 1e-12 * 10^(midpoint_db / 10) is decided by a comparison; within
-    // 1e-9 relative of it (4e-9 dB, against the ~1e-14 dB the expression's roundings can move) the reference's expression decides
-    const double mid_hi = mid_power * (1.0 + 1e-9), mid_lo = mid_power * (1.0 - 1e-9);
-    for (int base = tid; base < cells; base += 256 * kTailLoads) {
-        double v[kTailLoads];
-#pragma unroll
-        for (int u = 0; u < kTailLoads; ++u) v[u] = base + 256 * u < cells ? __builtin_nontemporal_load(mp + base + 256 * u) : 0.0;
-#pragma unroll
-        for (int u = 0; u < kTailLoads; ++u) {
-            const int idx = base + 256 * u;
-            const double s = v[u];
-            const bool loud = s > mid_hi || (s >= mid_lo && s > 0 && to_db64(s) > rule.midpoint_db);
-            if (loud) flags[FM ? idx / kSpecBins : idx % T] = 1;
+// the centre time of spectrogram column j (classifier.c:478-481)
+__device__ __forceinline__ double column_time(int j, int fs) { return (double)(j * kSpecHop + kSpecSeg / 2) / (double)fs; }
+
+// find_midpoints' clusters (:747-800) on ONE thread, the reference's order of additions: consecutive blob times (flagged columns)
+// whose gaps stay <= 0.05 s, kept when they span >= 0.15 s; mids[] takes the first kMaxMidpoints cluster means.  Returns their number.
+template <typename Flag>
+__device__ __forceinline__ int cluster_midpoints(Flag flag, const double *times, int T, double *mids)
+{
+    const double tol = 0.05, min_dur = 0.15;
+    int count = 0, j = 0;
+    while (j < T) {
+        while (j < T && !flag(j)) ++j;
+        if (j >= T) break;
+        int first = j, last = j, members = 1;
+        double sum = times[j];
+        int k = j + 1;
+        while (true) {
+            while (k < T && !flag(k)) ++k;
+            if (k >= T || !((times[k] - times[last]) <= tol)) break;
+            sum += times[k];
+            last = k; ++members; ++k;
         }
-    }
-    __syncthreads();
-    // ---- phase B: clusters -> midpoints (:747-800), one thread, the reference's order of additions ------------------------------
-    if (tid == 0) {
-        const double tol = 0.05, min_dur = 0.15;
-        int count = 0, j = 0;
-        while (j < T) {
-            while (j < T && !flags[j]) ++j;
-            if (j >= T) break;
-            // a cluster: consecutive BLOB times (flagged columns) whose gaps stay <= tol
-            int first = j, last = j, members = 1;
-            double sum = time_of(j);
-            int k = j + 1;
-            while (true) {
-                while (k < T && !flags[k]) ++k;
-                if (k >= T || !((time_of(k) - time_of(last)) <= tol)) break;
-                sum += time_of(k);
-                last = k; ++members; ++k;
-            }
-            if (time_of(last) - time_of(first) >= min_dur) {
-                if (count < kMaxMidpoints) mids[count] = sum / (double)members;
-                ++count;
-            }
-            j = k;
+        if (times[last] - times[first] >= min_dur) {
+            if (count < kMaxMidpoints) mids[count] = sum / (double)members;
+            ++count;
         }
-        sh_i[0] = count < kMaxMidpoints ? count : kMaxMidpoints;
-        sh_i[6] = 0;
+        j = k;
     }
-    __syncthreads();
-    const int n_mid = sh_i[0];
-    ClassifyTraceD *tr = trace ? trace + clip : nullptr;
-    if (tr) {
-        for (int i = tid; i < kMaxMidpoints; i += 256) {
-            tr->midpoints[i] = i < n_mid ? mids[i] : 0.0;
-            tr->sums[i][0] = tr->sums[i][1] = tr->sums[i][2] = 0.0;
-        }
-        if (tid == 0) tr->n_midpoints = n_mid;
-    }
-    if (n_mid == 0) {
-        if (tid == 0) labels[clip] = 0;
-        return;
-    }
-    // ---- phase C: clip-global minimum / maximum of the dB map (:105-125) -----------------------------------------------------
-    // (the dB of the smallest / largest positive cell: to_db64 is monotonic, and one log10 per clip instead of one per cell)
+    return count < kMaxMidpoints ? count : kMaxMidpoints;
+}
+
+// LDS of the band sums: a 256-thread block works on one clip
+struct BandShared {
+    double red_lo[256], red_hi[256];
+    double win[kWinCells];
+    int cnt[2], hit;
+};
+
+// main's per-file body after find_midpoints (:105-190) for one clip, by a whole block: bp = the clip's 3000-7500 Hz PSD map,
+// [129][T] or (FM) [T][129]; times[] / mids[] in LDS.  Returns the label (every thread).
+// FM: the map holds U * PSD (spectrogram_f64_fft_kernel<maps>): a cell is divided by U where its value is used, the minimum and
+// the maximum after they are found (x / U is monotonic)
+template <bool FM>
+__device__ __forceinline__ int band_sums_and_rule(const double *__restrict__ bp, int T, const ClassifyRuleD &rule, const BandRows &bands,
+                                                  const double *times, const double *mids, int n_mid, ClassifyTraceD *tr, BandShared &sh, double U)
+{
+    const int tid = threadIdx.x;
+    const int cells = kSpecBins * T;
+    // ---- clip-global minimum / maximum of the dB map (:105-125): the dB of the smallest / largest positive cell (to_db64 is
+    // monotonic: one log10 per clip instead of one per cell) ----
     double lo = 1.7976931348623157e308, hi = -1.7976931348623157e308;
     for (int base = tid; base < cells; base += 256 * kTailLoads) {
         double v[kTailLoads];
 #pragma unroll
-        for (int u = 0; u < kTailLoads; ++u) v[u] = base + 256 * u < cells ? bp[base + 256 * u] : 0.0;      // (cacheable: phase D reads the windows again)
+        for (int u = 0; u < kTailLoads; ++u) v[u] = base + 256 * u < cells ? bp[base + 256 * u] : 0.0;      // (cacheable: the windows are read again)
 #pragma unroll
         for (int u = 0; u < kTailLoads; ++u) {
             const double s = v[u];
@@ -272,48 +302,51 @@ __global__ __launch_bounds__(256) void classify_f64_tail_kernel(const double *__
             }
         }
     }
-    red_lo[tid] = lo; red_hi[tid] = hi;
+    sh.red_lo[tid] = lo; sh.red_hi[tid] = hi;
+    if (tid == 0) sh.hit = 0;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (tid < o) {
-            red_lo[tid] = red_lo[tid + o] < red_lo[tid] ? red_lo[tid + o] : red_lo[tid];
-            red_hi[tid] = red_hi[tid + o] > red_hi[tid] ? red_hi[tid + o] : red_hi[tid];
+            sh.red_lo[tid] = sh.red_lo[tid + o] < sh.red_lo[tid] ? sh.red_lo[tid + o] : sh.red_lo[tid];
+            sh.red_hi[tid] = sh.red_hi[tid + o] > sh.red_hi[tid] ? sh.red_hi[tid + o] : sh.red_hi[tid];
         }
         __syncthreads();
     }
-    const bool any_cell = red_hi[0] > 0;
-    const double mn = any_cell ? to_db64(red_lo[0]) : red_lo[0], mx = any_cell ? to_db64(red_hi[0]) : red_hi[0];
+    const bool any_cell = sh.red_hi[0] > 0;
+    const double mn = any_cell ? to_db64(FM ? sh.red_lo[0] / U : sh.red_lo[0]) : sh.red_lo[0];
+    const double mx = any_cell ? to_db64(FM ? sh.red_hi[0] / U : sh.red_hi[0]) : sh.red_hi[0];
     // the kept, normalised value of a cell or NaN (:130-157)
-    auto kept = [&](double s) {
+    auto kept = [&](double cell) {
+        const double s = FM ? cell / U : cell;
         if (!(s > 0)) return (double)NAN;
         const double v = (to_db64(s) - mn) / (mx - mn);
         return (v > rule.keep_lo && v < rule.keep_hi) ? v : (double)NAN;
     };
-    // ---- phase D: the three band sums per midpoint and the rule (:170-190) --------------------------------------------------------
-    const double band_lo[3] = {5000, 2500, 500}, band_hi[3] = {7000, 5000, 2500}, band_half[3] = {0.18, 0.05, 0.18};
+    // ---- the three band sums per midpoint and the rule (:170-190) ----
+    const double band_half[3] = {0.18, 0.05, 0.18};
     for (int k = 0; k < n_mid; ++k) {
         double sums[3] = {0, 0, 0};
         for (int bnd = 0; bnd < 3; ++bnd) {
-            if (tid == 0) { sh_i[3] = 0; sh_i[4] = 0; }
+            if (tid == 0) { sh.cnt[0] = 0; sh.cnt[1] = 0; }
             __syncthreads();
             {
                 const double midpoint = mids[k], lo_t = midpoint - band_half[bnd], hi_t = midpoint + band_half[bnd];
                 int below = 0, above = 0;
                 for (int j = tid; j < T; j += 256) { below += times[j] < lo_t; above += times[j] > hi_t; }
                 for (int o = 32; o > 0; o >>= 1) { below += __shfl_xor(below, o); above += __shfl_xor(above, o); }
-                if ((tid & 63) == 0) { atomicAdd(&sh_i[3], below); atomicAdd(&sh_i[4], above); }
+                if ((tid & 63) == 0) { atomicAdd(&sh.cnt[0], below); atomicAdd(&sh.cnt[1], above); }
             }
             __syncthreads();
             const int f0 = bands.f0[bnd], f1 = bands.f1[bnd];
-            int t0 = sh_i[3], t1 = T - 1 - sh_i[4];                          // :619-639 on monotonic times
+            int t0 = sh.cnt[0], t1 = T - 1 - sh.cnt[1];                      // :619-639 on monotonic times
             if (t0 >= T) t0 = T - 1;
             if (t1 < 0) t1 = 0;
             if (t0 > t1) { const int t = t0; t0 = t1; t1 = t; }
             const int cols = t1 - t0 + 1, rows = f1 - f0 + 1;
             const bool staged = rows * cols <= kWinCells;
             if (staged) {
-                if (FM) for (int idx = tid; idx < rows * cols; idx += 256) win[(idx % rows) * cols + idx / rows] = kept(bp[(long)(t0 + idx / rows) * kSpecBins + f0 + idx % rows]);
-                else for (int idx = tid; idx < rows * cols; idx += 256) win[idx] = kept(bp[(long)(f0 + idx / cols) * T + t0 + idx % cols]);
+                if (FM) for (int idx = tid; idx < rows * cols; idx += 256) sh.win[(idx % rows) * cols + idx / rows] = kept(bp[(long)(t0 + idx / rows) * kSpecBins + f0 + idx % rows]);
+                else for (int idx = tid; idx < rows * cols; idx += 256) sh.win[idx] = kept(bp[(long)(f0 + idx / cols) * T + t0 + idx % cols]);
             }
             __syncthreads();
             if (staged) {
@@ -324,12 +357,12 @@ __global__ __launch_bounds__(256) void classify_f64_tail_kernel(const double *__
                     const int n_cells = rows * cols;
                     double total = 0.0;
                     for (int c0 = 0; c0 < n_cells; c0 += 64) {
-                        double v = c0 + tid < n_cells ? win[c0 + tid] : 0.0;
+                        double v = c0 + tid < n_cells ? sh.win[c0 + tid] : 0.0;
                         v = v != v ? 0.0 : v;
-                        const int lo = __double2loint(v), hi = __double2hiint(v);
+                        const int vlo = __double2loint(v), vhi = __double2hiint(v);
 #pragma unroll
                         for (int l = 0; l < 64; ++l)
-                            total = total + __hiloint2double(__builtin_amdgcn_readlane(hi, l), __builtin_amdgcn_readlane(lo, l));
+                            total = total + __hiloint2double(__builtin_amdgcn_readlane(vhi, l), __builtin_amdgcn_readlane(vlo, l));
                     }
                     sums[bnd] = total;
                 }
@@ -346,21 +379,18 @@ __global__ __launch_bounds__(256) void classify_f64_tail_kernel(const double *__
         }
         if (tid == 0) {
             if (tr) { tr->sums[k][0] = sums[0]; tr->sums[k][1] = sums[1]; tr->sums[k][2] = sums[2]; }
-            if (sums[1] < rule.middle_max && sums[0] > rule.above_min && sums[2] > rule.below_min) sh_i[6] = 1;
+            if (sums[1] < rule.middle_max && sums[0] > rule.above_min && sums[2] > rule.below_min) sh.hit = 1;
         }
         __syncthreads();
-        if (sh_i[6]) break;
+        if (sh.hit) break;
     }
-    if (tid == 0) labels[clip] = sh_i[6];
+    const int label = sh.hit;
+    __syncthreads();                                                         // (a caller that loops over clips resets sh.hit next)
+    return label;
 }
 
-hipError_t launch_classify_f64_tail(const double *sxx_bp, const double *sxx_mp, long n_clips, int n, int fs, const ClassifyRuleD &rule,
-                                    int *labels, ClassifyTraceD *trace, hipStream_t stream, bool frame_major)
+BandRows band_rows(int fs)
 {
-    const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
-    if (n_clips <= 0) return hipSuccess;
-    if (T <= 0 || T > kMaxColsF64 || n_clips >= (1L << 31)) return hipErrorInvalidValue;
-    const double mid_power = 1e-12 * std::pow(10.0, rule.midpoint_db / 10.0);
     // sum_intense's frequency searches (classifier.c:597-617), once for all clips: the bins' frequencies in the reference's expression
     const double band_lo[3] = {5000, 2500, 500}, band_hi[3] = {7000, 5000, 2500};
     auto freq_of = [&](int i) { return (double)i * (double)fs / (double)kSpecSeg; };
@@ -375,8 +405,151 @@ hipError_t launch_classify_f64_tail(const double *sxx_bp, const double *sxx_mp, 
         if (f0 > f1) std::swap(f0, f1);
         bands.f0[bnd] = f0; bands.f1[bnd] = f1;
     }
-    if (frame_major) hipLaunchKernelGGL(classify_f64_tail_kernel<true>, dim3((unsigned)n_clips), dim3(256), 0, stream, sxx_bp, sxx_mp, n_clips, T, fs, rule, mid_power, bands, labels, trace);
-    else hipLaunchKernelGGL(classify_f64_tail_kernel<false>, dim3((unsigned)n_clips), dim3(256), 0, stream, sxx_bp, sxx_mp, n_clips, T, fs, rule, mid_power, bands, labels, trace);
+    return bands;
+}
+
+}  // namespace
+
+// The whole tail of one clip over [129][T] maps (the direct-DFT yardstick path): flags, midpoints, band sums, rule.
+__global__ __launch_bounds__(256) void classify_f64_tail_kernel(const double *__restrict__ sxx_bp, const double *__restrict__ sxx_mp, long n_clips,
+                                                                int T, int fs, ClassifyRuleD rule, double mid_power, BandRows bands,
+                                                                int *__restrict__ labels, ClassifyTraceD *__restrict__ trace)
+{
+    __shared__ double times[kMaxColsF64];
+    __shared__ int flags[kMaxColsF64];
+    __shared__ double mids[kMaxMidpoints];
+    __shared__ BandShared sh;
+    __shared__ int n_mid_sh;
+    const int tid = threadIdx.x;
+    const long clip = blockIdx.x;
+    if (clip >= n_clips) return;
+    const double *mp = sxx_mp + clip * (long)kSpecBins * T;
+    const double *bp = sxx_bp + clip * (long)kSpecBins * T;
+    const int cells = kSpecBins * T;
+    for (int j = tid; j < T; j += 256) { flags[j] = 0; times[j] = column_time(j, fs); }
+    __syncthreads();
+    for (int base = tid; base < cells; base += 256 * kTailLoads) {           // find_midpoints' mask (:679-745)
+        double v[kTailLoads];
+#pragma unroll
+        for (int u = 0; u < kTailLoads; ++u) v[u] = base + 256 * u < cells ? __builtin_nontemporal_load(mp + base + 256 * u) : 0.0;
+#pragma unroll
+        for (int u = 0; u < kTailLoads; ++u)
+            if (is_loud(v[u], mid_power, rule.midpoint_db)) flags[(base + 256 * u) % T] = 1;
+    }
+    __syncthreads();
+    if (tid == 0) n_mid_sh = cluster_midpoints([&](int j) { return flags[j] != 0; }, times, T, mids);
+    __syncthreads();
+    const int n_mid = n_mid_sh;
+    ClassifyTraceD *tr = trace ? trace + clip : nullptr;
+    if (tr) {
+        for (int i = tid; i < kMaxMidpoints; i += 256) {
+            tr->midpoints[i] = i < n_mid ? mids[i] : 0.0;
+            tr->sums[i][0] = tr->sums[i][1] = tr->sums[i][2] = 0.0;
+        }
+        if (tid == 0) tr->n_midpoints = n_mid;
+    }
+    if (n_mid == 0) {
+        if (tid == 0) labels[clip] = 0;
+        return;
+    }
+    const int label = band_sums_and_rule<false>(bp, T, rule, bands, times, mids, n_mid, tr, sh, 1.0);
+    if (tid == 0) labels[clip] = label;
+}
+
+// find_midpoints' clusters for a batch: a thread per clip reads its row of loud[] (spectrogram_f64_fft_kernel<flags>).  Clips with
+// midpoints go on the work list hits (hits[0] = count, then clip numbers; the order is whatever the atomics give, each clip's
+// results do not depend on it), mids[clip][] / n_mids[clip] carry them to classify_f64_bands_kernel; the others are label 0.
+__global__ __launch_bounds__(256) void classify_f64_midpoints_kernel(const int *__restrict__ loud, long n_clips, int T, int fs, double *__restrict__ mids,
+                                                                     int *__restrict__ n_mids, int *__restrict__ hits, int *__restrict__ labels,
+                                                                     ClassifyTraceD *__restrict__ trace)
+{
+    __shared__ double times[kMaxColsF64];
+    for (int j = threadIdx.x; j < T; j += 256) times[j] = column_time(j, fs);
+    __syncthreads();
+    const long clip = (long)blockIdx.x * 256 + threadIdx.x;
+    if (clip >= n_clips) return;
+    const int *fl = loud + clip * T;
+    double *m = mids + clip * kMaxMidpoints;
+    const int n_mid = cluster_midpoints([&](int j) { return fl[j] != 0; }, times, T, m);
+    n_mids[clip] = n_mid;
+    if (trace) {
+        ClassifyTraceD *tr = trace + clip;
+        tr->n_midpoints = n_mid;
+        for (int i = 0; i < kMaxMidpoints; ++i) {
+            tr->midpoints[i] = i < n_mid ? m[i] : 0.0;
+            tr->sums[i][0] = tr->sums[i][1] = tr->sums[i][2] = 0.0;
+        }
+    }
+    if (n_mid == 0) labels[clip] = 0;
+    else hits[1 + atomicAdd(hits, 1)] = (int)clip;
+}
+
+// Band sums and rule of the listed clips: block b takes entries b, b + gridDim.x, ... of the work list; entry e's map is
+// sxx[e][T][129] = U * PSD (spectrogram_f64_fft_kernel<maps> walked the same list).
+__global__ __launch_bounds__(256) void classify_f64_bands_kernel(const double *__restrict__ sxx, const int *__restrict__ hits, int T, int fs, double U,
+                                                                 ClassifyRuleD rule, BandRows bands, const double *__restrict__ mids_all,
+                                                                 const int *__restrict__ n_mids, int *__restrict__ labels, ClassifyTraceD *__restrict__ trace)
+{
+    __shared__ double times[kMaxColsF64];
+    __shared__ double mids[kMaxMidpoints];
+    __shared__ BandShared sh;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < T; j += 256) times[j] = column_time(j, fs);
+    const int n_hits = hits[0];
+    for (int e = blockIdx.x; e < n_hits; e += gridDim.x) {
+        const long clip = hits[1 + e];
+        const int n_mid = n_mids[clip];
+        __syncthreads();                                                     // times[] written; the previous entry's mids[] read
+        if (tid < n_mid) mids[tid] = mids_all[clip * kMaxMidpoints + tid];
+        __syncthreads();
+        const int label = band_sums_and_rule<true>(sxx + (long)e * T * kSpecBins, T, rule, bands, times, mids, n_mid, trace ? trace + clip : nullptr, sh, U);
+        if (tid == 0) labels[clip] = label;
+    }
+}
+
+hipError_t launch_classify_f64_tail(const double *sxx_bp, const double *sxx_mp, long n_clips, int n, int fs, const ClassifyRuleD &rule,
+                                    int *labels, ClassifyTraceD *trace, hipStream_t stream)
+{
+    const int T = columns_of(n);
+    if (n_clips <= 0) return hipSuccess;
+    if (T <= 0 || T > kMaxColsF64 || n_clips >= (1L << 31)) return hipErrorInvalidValue;
+    const double mid_power = 1e-12 * std::pow(10.0, rule.midpoint_db / 10.0);
+    hipLaunchKernelGGL(classify_f64_tail_kernel, dim3((unsigned)n_clips), dim3(256), 0, stream, sxx_bp, sxx_mp, n_clips, T, fs, rule, mid_power,
+                       band_rows(fs), labels, trace);
+    return hipGetLastError();
+}
+
+hipError_t launch_classify_f64_midpoints(const int *loud, long n_clips, int n, int fs, double *mids, int *n_mids, int *hits, int *labels,
+                                         ClassifyTraceD *trace, hipStream_t stream)
+{
+    const int T = columns_of(n);
+    if (n_clips <= 0) return hipSuccess;
+    if (T <= 0 || T > kMaxColsF64 || n_clips >= (1L << 31)) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(hits, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(classify_f64_midpoints_kernel, dim3((unsigned)((n_clips + 255) / 256)), dim3(256), 0, stream, loud, n_clips, T, fs, mids, n_mids,
+                       hits, labels, trace);
+    return hipGetLastError();
+}
+
+hipError_t launch_classify_f64_bands(const double *sxx, const int *hits, long n_clips, int n, int fs, double U, const ClassifyRuleD &rule, const double *mids,
+                                     const int *n_mids, int *labels, ClassifyTraceD *trace, hipStream_t stream)
+{
+    const int T = columns_of(n);
+    if (n_clips <= 0) return hipSuccess;
+    if (T <= 0 || T > kMaxColsF64) return hipErrorInvalidValue;
+    static int resident = 0;
+    if (resident == 0) {
+        int dev = 0, cus = 0, per = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, classify_f64_bands_kernel, 256, 0) != hipSuccess || cus <= 0 || per <= 0) {
+            (void)hipGetLastError();
+            cus = 256; per = 2;
+        }
+        resident = cus * per;
+    }
+    const long blocks = std::min<long>(n_clips, 4L * resident);              // the bound: the list's count is read on the device
+    hipLaunchKernelGGL(classify_f64_bands_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, sxx, hits, T, fs, U, rule, band_rows(fs), mids, n_mids, labels, trace);
     return hipGetLastError();
 }
 

@@ -152,14 +152,25 @@ struct SpecTablesD {
 };
 void build_spec_tables_f64(int fs, SpecTablesD &t);
 // compute_spectrogram (classifier.c:448-592) of a batch for the classifier: one wavefront per frame, 256-point real transform as a
-// 128-point complex Stockham FFT through LDS; maps FRAME-major, sxx[c][t][129] (launch_spectrogram_f64 is the [129][T] direct DFT
-// behind dsp_compute_spectrogram_f64 and the yardstick of this one in the tests).  y rows must be 16-byte aligned (stride even).
-hipError_t launch_spectrogram_f64_fft(const double *y, long n_clips, int n, long stride, const SpecTablesD *tables, double *sxx, hipStream_t stream);
-// sxx_bp / sxx_mp: float64 PSD maps of the 3000-7500 Hz / 1000-3000 Hz filtered clips, [c][129][T] (launch_spectrogram_f64) or,
-// frame_major, [c][T][129] (launch_spectrogram_f64_fft);
-// labels[c] = the rule's verdict (classifier.c:184), trace (optional): midpoints and band sums per clip
+// 128-point complex Stockham FFT through LDS (launch_spectrogram_f64 is the [129][T] direct DFT behind dsp_compute_spectrogram_f64
+// and the yardstick of this one in the tests).  y rows must be 16-byte aligned (stride even).
+//   _flags   every frame of every clip; loud[c][t] = a cell of the frame is above midpoint_db (find_midpoints :679-745); no map
+//   _listed  the clips on the work list hits (hits[0] entries, then clip numbers): sxx[entry][t][129] = U * PSD (SpecTablesD::U)
+hipError_t launch_spectrogram_f64_flags(const double *y, long n_clips, int n, long stride, const SpecTablesD *tables, double midpoint_db,
+                                        int *loud, hipStream_t stream);
+hipError_t launch_spectrogram_f64_listed(const double *y, long n_clips, int n, long stride, const SpecTablesD *tables, const int *hits,
+                                         double *sxx, hipStream_t stream);
+// find_midpoints' clusters (:747-800) from loud[c][t]: mids[c][kMaxMidpoints], n_mids[c]; clips with midpoints on the work list
+// hits[1 + n_clips] (reset here), label 0 for the others; trace (optional): midpoints, sums zeroed
+hipError_t launch_classify_f64_midpoints(const int *loud, long n_clips, int n, int fs, double *mids, int *n_mids, int *hits, int *labels,
+                                         ClassifyTraceD *trace, hipStream_t stream);
+// band sums and rule (:105-190) of the listed clips over their frame-major U * PSD maps: labels[c], trace sums
+hipError_t launch_classify_f64_bands(const double *sxx, const int *hits, long n_clips, int n, int fs, double U, const ClassifyRuleD &rule, const double *mids,
+                                     const int *n_mids, int *labels, ClassifyTraceD *trace, hipStream_t stream);
+// the whole tail in one kernel per clip over [c][129][T] float64 PSD maps of the 3000-7500 Hz / 1000-3000 Hz filtered clips
+// (launch_spectrogram_f64): labels[c] = the rule's verdict (classifier.c:184), trace (optional): midpoints and band sums per clip
 hipError_t launch_classify_f64_tail(const double *sxx_bp, const double *sxx_mp, long n_clips, int n, int fs, const ClassifyRuleD &rule,
-                                    int *labels, ClassifyTraceD *trace, hipStream_t stream, bool frame_major = false);
+                                    int *labels, ClassifyTraceD *trace, hipStream_t stream);
 
 void build_spec_tables(int fs, SpecTables &t);
 
