@@ -38,16 +38,18 @@ constexpr int IIR_LD = IIR_TS + 1;   // +1 word: lane l reads column i of row l 
 template <typename T>
 struct IirState { T d[8]; };
 
-template <typename T, typename C>
+template <typename T, typename C, bool EVEN_B = false>
 __device__ __forceinline__ T iir_step(IirState<T> &s, const C &c, T x)
 {
     // classifier.cpp:199-216: v = x - sum_{j=1..8} a[j] d[j-1] (left to right), y = b0 v + sum b[j] d[j-1]
+    // EVEN_B: the odd numerator taps are exactly 0 and are skipped (see iir2_ckpt_kernel: at most the sign of an exact zero changes)
     T v = x;
 #pragma unroll
     for (int j = 1; j <= 8; ++j) v = v - c.a[j] * s.d[j - 1];
     T y = c.b[0] * v;
 #pragma unroll
-    for (int j = 1; j <= 8; ++j) y = y + c.b[j] * s.d[j - 1];
+    for (int j = 1; j <= 8; ++j)
+        if (!EVEN_B || j % 2 == 0) y = y + c.b[j] * s.d[j - 1];
 #pragma unroll
     for (int j = 7; j > 0; --j) s.d[j] = s.d[j - 1];
     s.d[0] = v;
@@ -59,7 +61,7 @@ __device__ __forceinline__ T iir_step(IirState<T> &s, const C &c, T x)
 // TWO: two filters over the same input, one wavefront each (128-thread block, shared input tile): the serial
 // recurrences of the two filters run side by side instead of back to back in one lane.
 // MEANS (float): also emit the spectrogram's segment means of the outputs (see classify_kernels.hpp).
-template <typename T, typename C, bool TWO, typename TIO = T, bool MEANS = false>
+template <typename T, typename C, bool TWO, typename TIO = T, bool MEANS = false, bool EVEN_B = false>
 __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restrict__ x, long n_clips, int n, long stride, long ystride,
                                                              const C c1, TIO *__restrict__ y1, const C c2, TIO *__restrict__ y2,
                                                              float *__restrict__ means1 = nullptr, float *__restrict__ means2 = nullptr)
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restri
         // one sample of this lane's recurrence (+ the segment sums when MEANS)
         // (the segment bookkeeping is derived from the wave-uniform sample index s, so it stays in scalar registers)
         auto sample = [&](T xv, int s) -> TIO {
-            const TIO o = (TIO)iir_step<T, C>(st, c, xv);
+            const TIO o = (TIO)iir_step<T, C, EVEN_B>(st, c, xv);
             if (MEANS) {
                 // sample s = 224 k + pos belongs to segment k and, for pos < 32, still to segment k - 1
                 const int k = s / kSpecHop, pos = s - k * kSpecHop;
@@ -1422,7 +1424,11 @@ hipError_t launch_iir2_f64(const double *x, long n_clips, int n, long stride, lo
 {
     if (n_clips <= 0 || n <= 0) return hipSuccess;
     const int blocks = (int)((n_clips + 63) / 64);
-    hipLaunchKernelGGL((iir_kernel<double, IirCoefD, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, ystride, c1, y1, c2, y2, nullptr, nullptr);
+    auto even = [](const IirCoefD &c) { return c.b[1] == 0.0 && c.b[3] == 0.0 && c.b[5] == 0.0 && c.b[7] == 0.0; };
+    if (even(c1) && even(c2))                 // a Butterworth band-pass numerator is (1 - z^-2)^4 scaled: the designs of dsp_butter_bandpass have exact zeros there
+        hipLaunchKernelGGL((iir_kernel<double, IirCoefD, true, double, false, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, ystride, c1, y1, c2, y2, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((iir_kernel<double, IirCoefD, true>), dim3(blocks), dim3(128), 0, stream, x, n_clips, n, stride, ystride, c1, y1, c2, y2, nullptr, nullptr);
     return hipGetLastError();
 }
 

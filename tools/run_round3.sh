@@ -13,7 +13,7 @@ if [ "$PART" == "a" ]; then
     cp gpurun_out/gate_report.json $OUT/gate_report.json 2>/dev/null
     python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; cut -c1-200 $OUT/bench.json
     python bench.py --no-cpu-baseline > $OUT/bench_200.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_200.json
-    for w in clips config3 config5 config5_2048 classify pcm16 stop; do
+    for w in clips config3 config5 config5_2048 classify classify_f64 pcm16 stop; do
         python bench.py --workload $w --no-cpu-baseline --steps 50 >> $OUT/side_workloads.jsonl 2>> $OUT/side.err
     done
     python - <<PY
@@ -24,12 +24,12 @@ for l in open("$OUT/side_workloads.jsonl"):
 PY
 elif [ "$PART" == "b" ]; then
     ( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_frames -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/trace_frames.json 2> $OUT/trace_frames.err )
-    for w in config3 classify stop config5_2048 config5 clips; do
+    for w in config3 classify classify_f64 stop config5_2048 config5 clips; do
         ( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python3 $R/bench.py --workload $w --no-cpu-baseline --steps 20 > $OUT/trace_$w.json 2> $OUT/trace_$w.err )
     done
     find $OUT -name "*kernel_stats.csv" | while read f; do echo "== $f"; head -4 "$f" | cut -c1-160; done
 else
-    for w in frames config3 stop config5_2048 classify clips config5 pcm16; do
+    for w in frames config3 stop config5_2048 classify classify_f64 clips config5 pcm16; do
         python tools/traffic.py $TAG $w 2>&1 | tail -1
     done
 fi
