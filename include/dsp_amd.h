@@ -232,8 +232,10 @@ int dsp_classify_batch_device_cfg(const dsp_classify_config *cfg, const float *d
  * find_midpoints :655-830): both Butterworth filters, both spectrograms, dB maps, 45 dB midpoints, normalisation, keep band,
  * band sums and rule in double on the GPU.  Thresholds are doubles as in the file; cfg NULL = its own
  * (0.70 / 0.85 :141-142, 45 dB :660, middle < 75 && above > 300 && below > 100 :184).  fs is 16000 (the rate butter_bandpass has
- * coefficients for).  The reference transforms with FFTW (unvendored): the spectrogram is a float64 DFT, so parity is by
- * tolerance (labels and midpoints equal, band sums to ~1e-9 relative); correctness first, this path is not tuned.
+ * coefficients for).  The reference transforms with FFTW (unvendored): the spectrogram is a float64 transform of its own (a
+ * 128-point complex FFT per wavefront; DSP_AMD_F64_DFT=1: the direct DFT of dsp_compute_spectrogram_f64), so parity is by
+ * tolerance (labels and midpoints equal, band sums to ~1e-9 relative).  The library keeps a grow-only workspace (330 KB per
+ * one-second clip of the largest pass, passes of at most 65 536 clips; DSP_AMD_F64_SUB_BATCH lowers that).
  * _host: host pointers; _device: HBM pointers (d_trace may be NULL), synchronised before returning.                        */
 typedef struct dsp_classify_config_f64 {
     double keep_lo, keep_hi, midpoint_db, middle_max, above_min, below_min;
