@@ -136,3 +136,40 @@ def test_fft_spectrogram_path_against_the_direct_dft_path(dsp):
         assert np.array_equal(a[0], b[0])
         for (m, s), (md, sd) in zip(a[1], b[1]):
             assert np.array_equal(m, md) and np.allclose(s, sd, rtol=1e-10, atol=1e-10)
+
+
+def test_long_clips_many_midpoints_and_run_to_run_identity(dsp):
+    """Clips of several seconds (T = 272 and 714 columns): three calls in one clip (the rule fires at the first midpoint or later),
+    33 bursts (33 midpoints, the rule never fires: every band window of every midpoint is summed).  The work list of clips with
+    midpoints is filled with atomics -- its order varies from run to run, a clip's results must not: three runs, identical bits."""
+    import torch
+    from oracle import oracle as O
+    x = S.classify_cases()["scrub_a"].astype(np.float64)
+    rng = np.random.default_rng(3)
+    three = np.concatenate([x, rng.uniform(-1, 1, 8000) * 0.001, x[::-1] * 0.7, x, rng.uniform(-1, 1, 5000) * 0.001])
+    labels, trace = dsp.classify_batch_f64(three[None, :], with_trace=True)
+    assert _check(labels[0], trace[0], three, what="three calls") == (1, 3)
+    quiet_first = np.concatenate([x[::-1] * 0.7, rng.uniform(-1, 1, 8000) * 0.001, x])       # the first midpoint misses the rule
+    labels, trace = dsp.classify_batch_f64(quiet_first[None, :], with_trace=True)
+    _check(labels[0], trace[0], quiet_first, what="reversed call first")
+    n = 160000
+    bursts = rng.uniform(-1, 1, n) * 0.0005
+    for k in range(0, n - 4000, 4800):
+        bursts[k:k + 3200] += rng.uniform(-1, 1, 3200) * 0.3
+    labels, trace = dsp.classify_batch_f64(bursts[None, :], with_trace=True)
+    assert _check(labels[0], trace[0], bursts, what="bursts") == (0, 33)
+    # a batch of the long clip among quiet ones, three times
+    batch = rng.uniform(-1, 1, (96, n)) * 0.0005
+    batch[::3] = bursts
+    batch[1::6, :len(three)] += three
+    d = torch.from_numpy(batch).cuda()
+    runs = []
+    for _ in range(3):
+        lab = torch.empty(96, dtype=torch.int32, device="cuda")
+        runs.append((dsp.classify_device_f64(d, lab).cpu().numpy().copy(), dsp.classify_batch_f64(batch, with_trace=True)))
+    for lab, (hl, tr) in runs:
+        assert np.array_equal(lab, runs[0][0]) and np.array_equal(hl, runs[0][0])
+        for (m, s), (m0, s0) in zip(tr, runs[0][1][1]):
+            assert np.array_equal(m, m0) and np.array_equal(s, s0)
+    assert runs[0][0][::3].sum() == 0 and runs[0][0][1::6].sum() >= 12 and [len(m) for m, _ in runs[0][1][1][:3]] == [33, 3, 0]
+    assert runs[0][0][1::6].tolist() == [O.classify_f64(c)[0] for c in batch[1::6]]        # (a noise floor can make the call miss the rule)
