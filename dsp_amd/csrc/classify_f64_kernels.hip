@@ -1,7 +1,7 @@
 // classify_f64_kernels.hip -- the float64 scrub-jay classifier of donut-classifier/classifier.c (main's per-file body :83-192,
 // sum_intense :594-653, find_midpoints :655-830) after its two band-pass filters (iir_kernel<double>, classify_kernels.hip).
 // A batch runs as
-//   spectrogram_f64_fft_kernel<flags>   1000-3000 Hz output: a wavefront per frame (128-point complex Stockham FFT through LDS); only
+//   spectrogram_f64_fft_kernel<flags>   1000-3000 Hz output: two frames per wavefront (128-point complex Stockham FFT through LDS); only
 //                                       "a cell of this time bin is above the midpoint threshold" leaves the kernel (:679-745)
 //   classify_f64_midpoints_kernel       a thread per clip clusters the flagged bins and averages them in the reference's order
 //                                       (:747-800); clips with midpoints go on a work list, the others are label 0
@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "classify_kernels.hpp"
 
@@ -61,108 +62,198 @@ __device__ __forceinline__ cd cmul(cd a, double wr, double wi) { return {a.re * 
 
 }  // namespace
 
-// compute_spectrogram (classifier.c:448-592) for the batch path.  Wave w transforms frames w, w + n_waves, ...: lane l loads samples
-// 2 l, 2 l + 1 and 128 + 2 l, 129 + 2 l (two 16-byte loads, the next frame's in flight during this one's transform), the mean comes
-// from a wave reduction, the detrended windowed samples are packed as z[n] = x[2 n] + i x[2 n + 1] and go through a radix-2 Stockham
-// FFT of 128 points (seven stages, two points per lane, ping-pong through 4 KB of LDS per wave, the window and the per-stage twiddles
-// in registers), then the real spectrum X[k] = E[k] + W256^k O[k] is taken from Z[k] and conj(Z[128 - k]), and
-// |X|^2 / U (doubled for 0 < k < 128) is the PSD cell of bin k (:574-592).
+// compute_spectrogram (classifier.c:448-592) for the batch path: a 256-point real transform per frame as a 128-point complex
+// Stockham FFT through LDS, TWO frames per wavefront.  32 lanes own a frame; lane i loads samples 2 i + 64 r, 2 i + 64 r + 1, r < 4
+// (four 16-byte loads per lane, 512 contiguous bytes per load and frame, the next turn's loads in flight during this one's
+// transform), the mean is a reduction over the 32 lanes, the detrended windowed samples (window in registers, host-built in the
+// reference's expressions) are packed as z[n] = x[2 n] + i x[2 n + 1], so that lane i holds z[i + 32 r].  128 = 4 x 4 x 4 x 2: three
+// radix-4 stages (p = 1, 4, 16) and one radix-2 stage (p = 64), ping-pong through 4 KB of LDS per frame, twiddles from a
+// block-shared LDS table of W256^m (in registers they cost 48 VGPRs and a wave per SIMD).  A stage of radix R with p = the product
+// of the radices before it, thread i of N / R: k = i mod p, inputs x[i + r N / R] times exp(-2 pi i r k / (p R)), an R-point DFT,
+// outputs y[(i - k) R + k + r p].  The real spectrum X[k] = E[k] + W256^k O[k] is taken from Z[k] and conj(Z[128 - k]), lane i
+// takes bins i, i + 32, i + 64, i + 96, and |X|^2 / U (doubled for 0 < k < 128) is the PSD cell of bin k (:574-592).
+// (First form of this round: one frame per wave, radix 2, seven stages of two points per lane -- 60 % of a CU's LDS bandwidth and
+// every frame a chain of seven dependent LDS round trips: 2.6 ms per 3.5 M frames against 2.0 ms.)
 //   MAPS = false  every frame of every clip: loud[frame] = one of its 129 cells is above the midpoint threshold (no map leaves the kernel)
 //   MAPS = true   the frames of the clips on the work list hits (hits[0] entries, clip numbers from hits[1]): sxx[entry][t][k] = U * PSD
 template <bool MAPS>
 __global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *__restrict__ y, long n_clips, int T, long stride,
-                                                                  const SpecTablesD *__restrict__ tab, const int *__restrict__ hits,
-                                                                  double *__restrict__ sxx, int *__restrict__ loud, double mid_power, double midpoint_db)
+                                                                   const SpecTablesD *__restrict__ tab, const int *__restrict__ hits,
+                                                                   double *__restrict__ sxx, int *__restrict__ loud, double mid_power, double midpoint_db, double guard)
 {
     const long total = (MAPS ? (long)hits[0] : n_clips) * T;
-    __shared__ __attribute__((aligned(16))) cd buf[4][2][kSpecSeg / 2];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    cd *cur = buf[wib][0], *nxt = buf[wib][1];
-    const double w0 = tab->win[2 * lane], w1 = tab->win[2 * lane + 1], w2 = tab->win[128 + 2 * lane], w3 = tab->win[129 + 2 * lane];
-    double tr[7], ti[7];
-    int jout[7];
-#pragma unroll
-    for (int s = 1; s < 7; ++s) {
-        const int p = 1 << s, k = lane & (p - 1);
-        tr[s] = tab->w_re[k << (7 - s)];
-        ti[s] = tab->w_im[k << (7 - s)];
-        jout[s] = ((lane - k) << 1) + k;
+    // [wave][half][ping-pong][128 + 32]: the image stage p = 1 writes is padded by one element in four (P1 below)
+    __shared__ __attribute__((aligned(16))) cd buf[4][2][2][kSpecSeg / 2 + 32];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, half = lane >> 5, i = lane & 31;
+    cd *b0 = buf[wib][half][0], *b1 = buf[wib][half][1];
+    // Twiddles: block-shared LDS tables laid out so that the lanes of a read are contiguous (a lane keeping its twelve twiddles in
+    // registers cost 48 VGPRs; one table of W256^m indexed by m put the 16 lanes of a read on one or two banks):
+    //   w16[r - 1][k] = W64^(k r), k < 16 (stage p = 16)   w128[b] = W128^b, b < 64 (radix-2 stage)   w256[k] = W256^k, k < 128 (bins)
+    // Stage p = 4 needs W16^(k r), k = i & 3: six doubles, in registers.
+    __shared__ __attribute__((aligned(16))) cd w16[3][16], w128[64], w256[kSpecSeg / 2];
+    auto tw = [&](int m) {                                               // W256^m from the half-circle table
+        m &= 255;
+        const double sg = (m & 128) ? -1.0 : 1.0;
+        return cd{sg * tab->w_re[m & 127], sg * tab->w_im[m & 127]};
+    };
+    {
+        const int n = threadIdx.x;
+        if (n < 48) w16[n >> 4][n & 15] = tw(4 * (n & 15) * ((n >> 4) + 1));
+        if (n < 64) w128[n] = tw(2 * n);
+        if (n < 128) w256[n] = tw(n);
     }
-    const double pr0 = tab->w_re[lane], pi0 = tab->w_im[lane], pr1 = tab->w_re[lane + 64], pi1 = tab->w_im[lane + 64];
+    __syncthreads();
+    cd t4[3];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) t4[r - 1] = tw(16 * (i & 3) * r);
+    double win[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { win[2 * r] = tab->win[2 * i + 64 * r]; win[2 * r + 1] = tab->win[2 * i + 64 * r + 1]; }
+    const int j4 = ((i - (i & 3)) << 2) + (i & 3), j16 = ((i - (i & 15)) << 2) + (i & 15);
     const double U = tab->U, mid_power_u = mid_power * U;
     (void)mid_power_u;
     const long wave = (long)blockIdx.x * 4 + wib, n_waves = (long)gridDim.x * 4;
     typedef double d2 __attribute__((ext_vector_type(2)));
-    auto src_of = [&](long f) {
-        const long e = f / T;
-        const long clip = MAPS ? (long)hits[1 + e] : e;
-        return y + clip * stride + (f - e * T) * (long)kSpecHop + 2 * lane;
+    // this half's frame f = 2 wave + half, then + 2 n_waves per turn; (entry, column) kept incrementally: one division per kernel
+    long f = 2 * wave + half;
+    long e = f / T;
+    int t = (int)(f - e * T);
+    const long step = 2 * n_waves, step_e = step / T;
+    const int step_t = (int)(step - step_e * T);
+    auto src_of = [&](long ee, int tt) {
+        const long clip = MAPS ? (long)hits[1 + ee] : ee;
+        return y + clip * stride + (long)tt * kSpecHop + 2 * i;
     };
-    d2 na = {0, 0}, nb = {0, 0};
-    if (wave < total) {
-        const double *src = src_of(wave);
-        na = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src));
-        nb = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 128));
+    // two turns of look-ahead: a wave has 8 KB of loads in flight (with one turn the kernel read at 3.2 TB/s whatever its LDS and
+    // VALU work -- twelve waves per CU x 4 KB do not cover the memory latency)
+    d2 nx[4], nx2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { nx[r] = d2{0.0, 0.0}; nx2[r] = d2{0.0, 0.0}; }
+    auto advance = [&](long &ee, int &tt) {
+        ee += step_e; tt += step_t;
+        if (tt >= T) { tt -= T; ++ee; }
+    };
+    long e1 = e, e2;
+    int t1 = t, t2;
+    advance(e1, t1);                                                     // (entry, column) of frame f + step
+    e2 = e1; t2 = t1;
+    advance(e2, t2);                                                     // ... of frame f + 2 step
+    if (f < total) {
+        const double *src = src_of(e, t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nx[r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
     }
-    for (long f = wave; f < total; f += n_waves) {
-        const d2 a = na, b = nb;
-        if (f + n_waves < total) {
-            const double *src = src_of(f + n_waves);
-            na = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src));
-            nb = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 128));
-        }
-        double sum = (a.x + a.y) + (b.x + b.y);
+    if (f + step < total) {
+        const double *src = src_of(e1, t1);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        for (int r = 0; r < 4; ++r) nx2[r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
+    }
+    auto fft4 = [](cd &u0, cd &u1, cd &u2, cd &u3) {
+        const cd v0 = u0 + u2, v1 = u0 - u2, v2 = u1 + u3, d = u1 - u3;
+        const cd v3 = {d.im, -d.re};                                     // (u1 - u3) (-i)
+        u0 = v0 + v2; u1 = v1 + v3; u2 = v0 - v2; u3 = v1 - v3;
+    };
+    for (long f0 = 2 * wave; f0 < total; f0 += step) {                    // wave-uniform: the wave runs while its first frame exists
+        const bool live = f < total;
+        d2 x[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { x[r] = nx[r]; nx[r] = nx2[r]; }
+        if (f + 2 * step < total) {
+            const double *src = src_of(e2, t2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nx2[r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
+        }
+        double sum = ((x[0].x + x[0].y) + (x[1].x + x[1].y)) + ((x[2].x + x[2].y) + (x[3].x + x[3].y));
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);      // within the half
         const double mean = sum / (double)kSpecSeg;                      // classifier.c:551-561 detrend
-        const cd z0 = {(a.x - mean) * w0, (a.y - mean) * w1}, z1 = {(b.x - mean) * w2, (b.y - mean) * w3};
-        // stage 0 (p = 1, twiddle 1)
-        cur[2 * lane] = z0 + z1;
-        cur[2 * lane + 1] = z0 - z1;
-        wave_sync_lds();
+        cd u[4];
 #pragma unroll
-        for (int s = 1; s < 7; ++s) {
-            const cd u0 = cur[lane], u1 = cmul(cur[lane + 64], tr[s], ti[s]);
-            nxt[jout[s]] = u0 + u1;
-            nxt[jout[s] + (1 << s)] = u0 - u1;
-            wave_sync_lds();
-            cd *t = cur; cur = nxt; nxt = t;
+        for (int r = 0; r < 4; ++r) u[r] = {(x[r].x - mean) * win[2 * r], (x[r].y - mean) * win[2 * r + 1]};
+        // stage p = 1
+        fft4(u[0], u[1], u[2], u[3]);
+        // (written at P1(n) = n + (n >> 2): lane i's four outputs start 80 bytes after lane i - 1's, so that the eight lanes a
+        // ds_write_b128 serves together fall on all 32 banks -- at 64 bytes they shared them four ways: 32 LDS cycles per store
+        // instead of 13, and the stores of this stage and the next were half of the kernel's LDS time)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b0[5 * i + r] = u[r];
+        wave_sync_lds();
+        // stage p = 4
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = b0[i + (i >> 2) + 40 * r];     // P1(i + 32 r)
+#pragma unroll
+        for (int r = 1; r < 4; ++r) u[r] = cmul(u[r], t4[r - 1].re, t4[r - 1].im);
+        fft4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b1[j4 + 4 * r] = u[r];
+        wave_sync_lds();
+        // stage p = 16
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = b1[i + 32 * r];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) { const cd w = w16[r - 1][i & 15]; u[r] = cmul(u[r], w.re, w.im); }
+        fft4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b0[j16 + 16 * r] = u[r];
+        wave_sync_lds();
+        // stage p = 64, radix 2: butterflies b = i and i + 32 on (x[b], x[b + 64])
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = b0[i + 32 * r];
+        {
+            const cd w0 = w128[i], w1 = w128[i + 32];
+            const cd a0 = cmul(u[2], w0.re, w0.im), a1 = cmul(u[3], w1.re, w1.im);
+            b1[i] = u[0] + a0; b1[i + 64] = u[0] - a0;
+            b1[i + 32] = u[1] + a1; b1[i + 96] = u[1] - a1;
         }
-        // Z in natural order in cur.  X[k] = (A + B) / 2 + W256^k (A - B) / (2 i), A = Z[k], B = conj(Z[128 - k])
-        // |X[k]|^2, doubled for the one-sided spectrum (:574-592): the cell is this over U.  The division is left to whoever needs
-        // the cell's value: x / U is monotonic in x and commutes with the doubling, so the map kernel stores U * PSD and the band
-        // kernel divides the cells it uses, and the flags compare against U * threshold unless the cell is within 2e-9 of it
-        auto bin = [&](int k, double wr, double wi) {
-            const cd A = cur[k & 127], Zb = cur[(128 - k) & 127];
+        wave_sync_lds();
+        // Z in natural order in b1.  X[k] = (A + B) / 2 + W256^k (A - B) / (2 i), A = Z[k], B = conj(Z[128 - k]); the cell is
+        // |X[k]|^2 (doubled for 0 < k < 128) over U.  The division is left to whoever needs the cell's value: x / U is monotonic in x
+        // and commutes with the doubling, so the map kernel stores U * PSD and the band kernel divides the cells it uses, and the
+        // flags compare against U * threshold unless the cell is within `guard` of it
+        double m[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = i + 32 * r;
+            const cd A = b1[k], Zb = b1[(128 - k) & 127];
             const cd e2 = {A.re + Zb.re, A.im - Zb.im}, d = {A.re - Zb.re, A.im + Zb.im};
             const cd o2 = {d.im, -d.re};
-            const cd x2 = e2 + cmul(o2, wr, wi);
+            const cd w = w256[k];
+            const cd x2 = e2 + cmul(o2, w.re, w.im);
             const double re = 0.5 * x2.re, im = 0.5 * x2.im;
-            return re * re + im * im;
-        };
-        double m0 = bin(lane, pr0, pi0);
-        const double m1 = bin(lane + 64, pr1, pi1) * 2.0;
-        if (lane > 0) m0 *= 2.0;
-        const cd Z0 = cur[0];
+            m[r] = (re * re + im * im) * ((r == 0 && i == 0) ? 1.0 : 2.0);
+        }
+        const cd Z0 = b1[0];
         const double r128 = Z0.re - Z0.im;                               // X[128] = E[0] - O[0]
         const double m128 = r128 * r128;
         if (MAPS) {
-            double *out = sxx + f * (long)kSpecBins;
-            out[lane] = m0;
-            out[lane + 64] = m1;
-            if (lane == 0) out[128] = m128;
+            if (live) {
+                double *out = sxx + f * (long)kSpecBins;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[i + 32 * r] = m[r];
+                if (i == 0) out[128] = m128;
+            }
         } else {
-            auto loud_cell = [&](double m) {
-                if (m > mid_power_u * (1.0 + 2e-9)) return true;
-                if (m < mid_power_u * (1.0 - 2e-9)) return false;
-                return is_loud(m / U, mid_power, midpoint_db);
-            };
-            bool any = loud_cell(m0) || loud_cell(m1);
-            if (lane == 0) any = any || loud_cell(m128);
-            const bool hit = __ballot(any) != 0;
-            if (lane == 0) loud[f] = hit;
+            // above / below the band around U x threshold: decided; inside it (rare): the reference's expression, evaluated in
+            // ONE rolled loop (inlined per cell, the float64 log10 cost the kernel 40 VGPRs)
+            const double thr_hi = mid_power_u * (1.0 + guard), thr_lo = mid_power_u * (1.0 - guard);
+            const double c4 = i == 0 ? m128 : 0.0;
+            bool any = m[0] > thr_hi || m[1] > thr_hi || m[2] > thr_hi || m[3] > thr_hi || c4 > thr_hi;
+            const bool near = (m[0] >= thr_lo && m[0] <= thr_hi) || (m[1] >= thr_lo && m[1] <= thr_hi) || (m[2] >= thr_lo && m[2] <= thr_hi) ||
+                              (m[3] >= thr_lo && m[3] <= thr_hi) || (c4 >= thr_lo && c4 <= thr_hi);
+            if (__ballot(near) != 0) {
+#pragma unroll 1
+                for (int c = 0; c < 5; ++c) {
+                    const double v = c == 0 ? m[0] : c == 1 ? m[1] : c == 2 ? m[2] : c == 3 ? m[3] : c4;
+                    if (v >= thr_lo && v <= thr_hi && is_loud(v / U, mid_power, midpoint_db)) any = true;
+                }
+            }
+            const unsigned long long bal = __ballot(any);
+            const bool hit = ((half ? (bal >> 32) : bal) & 0xffffffffull) != 0;
+            if (i == 0 && live) loud[f] = hit;
         }
-        wave_sync_lds();                                                 // the next frame's stage 0 overwrites what bin() read (six swaps: cur is buf[wib][0] again)
+        wave_sync_lds();                                                 // the next turn's stages overwrite b0 / b1
+        f += step;
+        advance(e2, t2);
     }
 }
 
@@ -215,10 +306,14 @@ hipError_t launch_spectrogram_f64_flags(const double *y, long n_clips, int n, lo
     const int T = columns_of(n);
     if (n_clips <= 0 || T <= 0) return hipSuccess;
     if (stride % 2 != 0 || reinterpret_cast<uintptr_t>(y) % 16 != 0) return hipErrorInvalidValue;
-    const long blocks = std::min<long>((n_clips * T + 3) / 4, fft_resident_blocks<false>());
+    const long blocks = std::min<long>((n_clips * T + 7) / 8, fft_resident_blocks<false>());
     const double mid_power = 1e-12 * std::pow(10.0, midpoint_db / 10.0);
+    // DSP_AMD_F64_GUARD: the half-width of the band around the threshold inside which the reference's expression decides (default
+    // 2e-9; the tests widen it to push every cell through that path)
+    const char *ge = std::getenv("DSP_AMD_F64_GUARD");
+    const double guard = ge && std::atof(ge) >= 2e-9 && std::atof(ge) < 1.0 ? std::atof(ge) : 2e-9;
     hipLaunchKernelGGL(spectrogram_f64_fft_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, y, n_clips, T, stride, tables,
-                       (const int *)nullptr, (double *)nullptr, loud, mid_power, midpoint_db);
+                       (const int *)nullptr, (double *)nullptr, loud, mid_power, midpoint_db, guard);
     return hipGetLastError();
 }
 
@@ -228,9 +323,9 @@ hipError_t launch_spectrogram_f64_listed(const double *y, long n_clips, int n, l
     const int T = columns_of(n);
     if (n_clips <= 0 || T <= 0) return hipSuccess;
     if (stride % 2 != 0 || reinterpret_cast<uintptr_t>(y) % 16 != 0) return hipErrorInvalidValue;
-    const long blocks = std::min<long>((n_clips * T + 3) / 4, fft_resident_blocks<true>());      // the bound: the list's count is read on the device
+    const long blocks = std::min<long>((n_clips * T + 7) / 8, fft_resident_blocks<true>());      // the bound: the list's count is read on the device
     hipLaunchKernelGGL(spectrogram_f64_fft_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, y, n_clips, T, stride, tables, hits, sxx,
-                       (int *)nullptr, 0.0, 0.0);
+                       (int *)nullptr, 0.0, 0.0, 0.0);
     return hipGetLastError();
 }
 

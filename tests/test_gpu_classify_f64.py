@@ -173,3 +173,24 @@ def test_long_clips_many_midpoints_and_run_to_run_identity(dsp):
             assert np.array_equal(m, m0) and np.array_equal(s, s0)
     assert runs[0][0][::3].sum() == 0 and runs[0][0][1::6].sum() >= 12 and [len(m) for m, _ in runs[0][1][1][:3]] == [33, 3, 0]
     assert runs[0][0][1::6].tolist() == [O.classify_f64(c)[0] for c in batch[1::6]]        # (a noise floor can make the call miss the rule)
+
+
+def test_threshold_guard_band_path_decides_like_the_comparison(dsp):
+    """A cell's "above the midpoint threshold" is a comparison with U x the threshold's power unless the cell lies within a guard band
+    of it (2e-9), where the reference's 10 log10(s / 1e-12) > midpoint_db is evaluated.  DSP_AMD_F64_GUARD (read per call) widens the
+    band to +-90 %, so that most cells of these clips go through the exact path: same labels, midpoints, sums, bit for bit."""
+    cases = S.classify_cases()
+    rng = np.random.default_rng(17)
+    clips = np.concatenate([np.stack([c.astype(np.float64) for c in cases.values()]),
+                            rng.uniform(-1, 1, (24, 16000)) * np.logspace(-3.5, -1, 24)[:, None]])     # floors around the 45 dB threshold
+    labels, trace = dsp.classify_batch_f64(clips, with_trace=True)
+    os.environ["DSP_AMD_F64_GUARD"] = "0.9"
+    try:
+        labels_g, trace_g = dsp.classify_batch_f64(clips, with_trace=True)
+    finally:
+        del os.environ["DSP_AMD_F64_GUARD"]
+    assert np.array_equal(labels, labels_g)
+    counts = [len(m) for m, _ in trace]
+    assert 0 in counts and max(counts) >= 1 and len(set(counts[len(cases):])) >= 2      # floors below and above the threshold
+    for (m, s), (mg, sg) in zip(trace, trace_g):
+        assert np.array_equal(m, mg) and np.array_equal(s, sg)
