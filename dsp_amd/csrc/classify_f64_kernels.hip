@@ -36,6 +36,10 @@ namespace {
 
 constexpr int kMaxColsF64 = 960;            // >= capi.cpp's kMaxSpecColumns (957): a flag per spectrogram column
 constexpr int kWinCells = 48 * 32;          // band window staged in LDS: the widest band has 41 rows (2500-5000 Hz) x 27 columns (0.36 s at 14 ms per column)
+#ifndef DSP_F64_FFT_AHEAD
+#define DSP_F64_FFT_AHEAD 2
+#endif
+constexpr int kFftAhead = DSP_F64_FFT_AHEAD;  // turns (two frames each) of loads a transform wave keeps in flight
 constexpr int kTailLoads = 8;               // map cells a thread has in flight while it scans a map (one at a time left the scan bound by the load latency)
 
 __device__ __forceinline__ double to_db64(double s) { return 10 * log10(s / 1e-12); }      // classifier.c:113, :688
@@ -65,7 +69,7 @@ __device__ __forceinline__ cd cmul(cd a, double wr, double wi) { return {a.re * 
 // compute_spectrogram (classifier.c:448-592) for the batch path: a 256-point real transform per frame as a 128-point complex
 // Stockham FFT through LDS, TWO frames per wavefront.  32 lanes own a frame; lane i loads samples 2 i + 64 r, 2 i + 64 r + 1, r < 4
 // (four 16-byte loads per lane, 512 contiguous bytes per load and frame, the next turn's loads in flight during this one's
-// transform), the mean is a reduction over the 32 lanes, the detrended windowed samples (window in registers, host-built in the
+// transform; kFftAhead turns ahead), the mean is a reduction over the 32 lanes, the detrended windowed samples (window in registers, host-built in the
 // reference's expressions) are packed as z[n] = x[2 n] + i x[2 n + 1], so that lane i holds z[i + 32 r].  128 = 4 x 4 x 4 x 2: three
 // radix-4 stages (p = 1, 4, 16) and one radix-2 stage (p = 64), ping-pong through 4 KB of LDS per frame, twiddles from a
 // block-shared LDS table of W256^m (in registers they cost 48 VGPRs and a wave per SIMD).  A stage of radix R with p = the product
@@ -124,29 +128,24 @@ __global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *
         const long clip = MAPS ? (long)hits[1 + ee] : ee;
         return y + clip * stride + (long)tt * kSpecHop + 2 * i;
     };
-    // two turns of look-ahead: a wave has 8 KB of loads in flight (with one turn the kernel read at 3.2 TB/s whatever its LDS and
-    // VALU work -- twelve waves per CU x 4 KB do not cover the memory latency)
-    d2 nx[4], nx2[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { nx[r] = d2{0.0, 0.0}; nx2[r] = d2{0.0, 0.0}; }
+    // kFftAhead turns of look-ahead (1, 2 and 3 measure the same within 1 %: profiles/r03_classify_f64_session2.txt)
+    d2 q[kFftAhead][4];
     auto advance = [&](long &ee, int &tt) {
         ee += step_e; tt += step_t;
         if (tt >= T) { tt -= T; ++ee; }
     };
-    long e1 = e, e2;
-    int t1 = t, t2;
-    advance(e1, t1);                                                     // (entry, column) of frame f + step
-    e2 = e1; t2 = t1;
-    advance(e2, t2);                                                     // ... of frame f + 2 step
-    if (f < total) {
-        const double *src = src_of(e, t);
+    long ea = e;                                                         // (entry, column) of the next frame to request
+    int ta = t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nx[r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
-    }
-    if (f + step < total) {
-        const double *src = src_of(e1, t1);
+    for (int j = 0; j < kFftAhead; ++j) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nx2[r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
+        for (int r = 0; r < 4; ++r) q[j][r] = d2{0.0, 0.0};
+        if (f + j * step < total) {
+            const double *src = src_of(ea, ta);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[j][r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
+        }
+        advance(ea, ta);
     }
     auto fft4 = [](cd &u0, cd &u1, cd &u2, cd &u3) {
         const cd v0 = u0 + u2, v1 = u0 - u2, v2 = u1 + u3, d = u1 - u3;
@@ -157,11 +156,15 @@ __global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *
         const bool live = f < total;
         d2 x[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { x[r] = nx[r]; nx[r] = nx2[r]; }
-        if (f + 2 * step < total) {
-            const double *src = src_of(e2, t2);
+        for (int r = 0; r < 4; ++r) x[r] = q[0][r];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) nx2[r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
+        for (int j = 0; j + 1 < kFftAhead; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[j][r] = q[j + 1][r];
+        if (f + kFftAhead * step < total) {
+            const double *src = src_of(ea, ta);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q[kFftAhead - 1][r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
         }
         double sum = ((x[0].x + x[0].y) + (x[1].x + x[1].y)) + ((x[2].x + x[2].y) + (x[3].x + x[3].y));
 #pragma unroll
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *
         }
         wave_sync_lds();                                                 // the next turn's stages overwrite b0 / b1
         f += step;
-        advance(e2, t2);
+        advance(ea, ta);
     }
 }
 
