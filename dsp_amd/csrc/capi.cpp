@@ -649,7 +649,8 @@ struct ClassifyCtx {
     float *d_ck_bp = nullptr, *d_ck_mp = nullptr;          // [clip][T][kCkPerSegBp / Mp][8]: delay line of each filter at every segment start (3000-7500 Hz: and middle)
     float *d_mean_mp = nullptr;                            // [clip][T]: segment means of the 1000-3000 Hz output
     int *d_labels = nullptr, *d_hits = nullptr;            // d_hits: work list of clips with midpoints
-    int *d_loud = nullptr;                                 // [clip][T]: time bins of the 1000-3000 Hz map above 70 dB
+    int *d_loud = nullptr;                                 // [clip][T]: time bins of the 1000-3000 Hz map above 70 dB; after the midpoints kernel: rows of the 3000-7500 Hz map the band sums read
+    unsigned *d_minmax = nullptr;                          // [clip][2]: float bits of the smallest / largest positive cell of the 3000-7500 Hz map
     int *d_simd = nullptr;                                 // iir2_ckpt_kernel's per-CU SIMD load table (launch_iir2_ckpt)
     int *d_gate = nullptr;                                 // work list of the segments whose energy does not rule a loud cell out (IIR kernel)
     dsp::ClassifyTrace *d_trace = nullptr;
@@ -727,10 +728,10 @@ long cls_row(int n) { return ((long)n + 3) & ~3L; }      // workspace row: n flo
 void cls_free_workspace()
 {
     for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_sbp, (void *)g_cls.d_ck_bp, (void *)g_cls.d_ck_mp, (void *)g_cls.d_loud, (void *)g_cls.d_gate, (void *)g_cls.d_simd,
-                    (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_hits, (void *)g_cls.d_trace})
+                    (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_hits, (void *)g_cls.d_trace, (void *)g_cls.d_minmax})
         if (p) hipFree(p);
     g_cls.d_x = g_cls.d_sbp = g_cls.d_ck_bp = g_cls.d_ck_mp = g_cls.d_mean_mp = nullptr;
-    g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = g_cls.d_gate = g_cls.d_simd = nullptr; g_cls.d_trace = nullptr;
+    g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = g_cls.d_gate = g_cls.d_simd = nullptr; g_cls.d_trace = nullptr; g_cls.d_minmax = nullptr;
     g_cls.cap_clips = 0; g_cls.cap_n = 0; g_cls.cap_x = false;
 }
 
@@ -754,6 +755,7 @@ int cls_reserve(long clips, int n, bool need_x)
     DSP_HIP(hipMalloc(&g_cls.d_ck_bp, (size_t)clips * T * dsp::kCkPerSegBp * 8 * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_ck_mp, (size_t)clips * T * dsp::kCkPerSegMp * 8 * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_loud, (size_t)clips * T * sizeof(int)));
+    DSP_HIP(hipMalloc(&g_cls.d_minmax, (size_t)clips * 2 * sizeof(unsigned)));
     DSP_HIP(hipMalloc(&g_cls.d_simd, sizeof(int) * dsp::kSimdLoadCus * dsp::kSimdLoadStride));
     DSP_HIP(hipMalloc(&g_cls.d_gate, ((size_t)clips * T + 1) * sizeof(int)));      // work list of gated-in frames: count + frame numbers
     DSP_HIP(hipMalloc(&g_cls.d_mean_mp, (size_t)clips * T * sizeof(float)));
@@ -790,9 +792,13 @@ int cls_run(const dsp_classify_config &cfg, const float *d_x, long clips, int n,
     // clips that have midpoints
     DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, mp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, nullptr, g_cls.d_tab,
                                        reinterpret_cast<float *>(g_cls.d_loud), true, st));
-    DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_loud, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, want_trace));
-    DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, bp, g_cls.d_ck_bp, nullptr, nullptr, g_cls.d_hits, g_cls.d_tab, g_cls.d_sbp, false, st));
-    DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, rule));
+    // DSP_AMD_CLASSIFY_FULL_MAPS=1: every row of the listed clips' maps is stored and read (the form before the need / minmax hand-over)
+    static const bool full_maps = [] { const char *e = std::getenv("DSP_AMD_CLASSIFY_FULL_MAPS"); return e && std::atoi(e) != 0; }();
+    unsigned *mm = full_maps ? nullptr : g_cls.d_minmax;
+    const int *need = full_maps ? nullptr : g_cls.d_loud;
+    DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_loud, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, want_trace, mm));
+    DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, bp, g_cls.d_ck_bp, nullptr, nullptr, g_cls.d_hits, g_cls.d_tab, g_cls.d_sbp, false, st, need, mm));
+    DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, rule, need, mm));
     return DSP_OK;
 }
 

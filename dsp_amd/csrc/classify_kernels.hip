@@ -1146,6 +1146,18 @@ hipError_t read_rc_stamps(unsigned long long *host, int count)
 #define BD_STAMP(k) do { } while (0)
 #endif
 
+// (wave-wide minimum / maximum of a float, every lane gets it)
+__device__ __forceinline__ float wave_min(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_maxf(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
 // Round 3: the block is PERSISTENT (grid = the blocks the chip holds; a block walks groups g, g + gridDim.x, ... of 60 frame slots) and
 // software-pipelined over its groups: while group g runs R .. F, the 60 KB of x rows of group g + 1, their restart states and (flags)
 // their segment means are already in flight into registers (8 float4 per thread), and the (clip, time bin) description of group g + 2
@@ -1156,8 +1168,13 @@ template <int OUT, bool EVEN_B>
 __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void spec_from_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride, const IirCoef c,
                                                              const float *__restrict__ ck, const float *__restrict__ means,
                                                              const int *__restrict__ wantlist, const int *__restrict__ hits,
-                                                             const SpecTables *__restrict__ tab, float *__restrict__ out, int T, int vec_ok)
+                                                             const SpecTables *__restrict__ tab, float *__restrict__ out, int T, int vec_ok,
+                                                             const int *__restrict__ need, unsigned *__restrict__ minmax)
 {
+    // SPEC_FRAME_MAJOR with need / minmax (classify): a row is stored only when need[clip][t] says a band window of one of the clip's
+    // midpoints covers time bin t (classify_midpoints_kernel), and the smallest / largest positive cell of every transformed frame
+    // goes into minmax[clip][2] (float bits, atomicMin / atomicMax; reset by classify_midpoints_kernel) -- what the band kernel's dB
+    // normalisation needs of the rows it no longer reads.
     static_assert(OUT == SPEC_FLAGS || OUT == SPEC_FRAME_MAJOR, "flags or [time][bin]");
     constexpr int kCkPerSeg = OUT == SPEC_FLAGS ? kCkPerSegMp : kCkPerSegBp;      // restart states per segment in `ck`
     __shared__ float rows[RC_FRAMES * RC_ROW];
@@ -1197,6 +1214,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     float4 v4[NL];
     float4 ckv[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     float mean_pre = 0.0f;
+    int need_pre = 1;
     // role: this wave's part of the serial phases (0 .. kCkPerSeg - 1: that part of R; 0 also M).  (Rotating the parts over the
     // waves from group to group, so that both resident blocks of a CU do not keep R on the same SIMDs, was measured: no change.)
     const int role = wib;
@@ -1215,6 +1233,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
             ckv[0] = src[0]; ckv[1] = src[1];
         }
         if (means && role == 0 && iclip >= 0) mean_pre = means[(long)iclip * T + it];
+        if (OUT == SPEC_FRAME_MAJOR && need && iclip >= 0) need_pre = need[(long)iclip * T + it];
     };
 
     int clip1, t1, clip2, t2;                       // descriptions of the next group and the one after it
@@ -1243,6 +1262,8 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         float d[8] = {ckv[0].x, ckv[0].y, ckv[0].z, ckv[0].w, ckv[1].x, ckv[1].y, ckv[1].z, ckv[1].w};
         const float mean_ck = mean_pre;
         (void)mean_ck;
+        const unsigned long long store_mask = __ballot(want && need_pre != 0);      // frames whose rows the band sums will read
+        (void)store_mask;
         if (wib == 0) sflag[lane] = 0;
         __syncthreads();
         // the next group's loads go out now and land while this group computes; the description after that is requested too
@@ -1345,6 +1366,22 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         RC_STAMP(4);
 
         // ---- F: one frame at a time per wave
+        // (minmax: a lane keeps the running minimum / maximum of the positive cells it has seen of the current clip; a wave reduction
+        // and two atomics when the clip changes or the group ends)
+        unsigned run_mn = 0xFFFFFFFFu;                      // (bits of the smallest positive cell) - 1
+        float run_mx = 0.0f;
+        int run_clip = -1;
+        auto flush_minmax = [&] {
+            if (run_clip < 0) return;
+            unsigned a = run_mn;
+            for (int o = 32; o > 0; o >>= 1) a = min(a, (unsigned)__shfl_xor((int)a, o));
+            const float b = wave_maxf(run_mx);
+            if (lane == 0) {
+                if (a != 0xFFFFFFFFu) atomicMin(minmax + 2 * (long)run_clip, a + 1u);
+                atomicMax(minmax + 2 * (long)run_clip + 1, __float_as_uint(b));
+            }
+        };
+        (void)run_mn; (void)run_mx; (void)run_clip; (void)flush_minmax;
 #pragma unroll 1
         for (int f = wib; f < RC_FRAMES; f += RC_WAVES) {
             if (!((todo >> f) & 1)) continue;
@@ -1360,12 +1397,22 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
             } else {
                 const long fclip = (long)__builtin_amdgcn_readlane(clip, f);
                 const int ft = __builtin_amdgcn_readlane(t, f);
-                float *o = out + (fclip * T + ft) * (long)kSpecBins;
-                o[lane] = p0;
-                o[lane + 64] = p1;
-                if (lane == 0) o[128] = p2;
+                if (minmax) {
+                    if ((int)fclip != run_clip) { flush_minmax(); run_clip = (int)fclip; run_mn = 0xFFFFFFFFu; run_mx = 0.0f; }
+                    // cells are >= 0: as unsigned words minus one, the positive ones keep their order and a zero becomes the largest
+                    const float q2 = lane == 0 ? p2 : p0;          // bin 128 exists on lane 0 only
+                    run_mn = min(run_mn, min(min(__float_as_uint(p0) - 1u, __float_as_uint(p1) - 1u), __float_as_uint(q2) - 1u));
+                    run_mx = fmaxf(run_mx, fmaxf(fmaxf(p0, p1), q2));
+                }
+                if ((store_mask >> f) & 1) {
+                    float *o = out + (fclip * T + ft) * (long)kSpecBins;
+                    o[lane] = p0;
+                    o[lane + 64] = p1;
+                    if (lane == 0) o[128] = p2;
+                }
             }
         }
+        if (OUT == SPEC_FRAME_MAJOR && minmax) { flush_minmax(); run_clip = -1; }
 #ifdef DSP_RC_STAMPS
         __syncthreads();
         RC_STAMP(5);
@@ -1395,7 +1442,8 @@ static int rc_resident_blocks()
 }
 
 hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
-                                 const int *wantlist, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream)
+                                 const int *wantlist, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream,
+                                 const int *need, unsigned *minmax)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0 || T <= 0) return hipSuccess;
@@ -1405,7 +1453,7 @@ hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long strid
     const long groups = (total + RC_FRAMES - 1) / RC_FRAMES;
     auto launch = [&](auto kernel, int resident, const int *wl, const int *hl) {
         const dim3 grid((unsigned)std::min<long>(groups, resident));
-        hipLaunchKernelGGL(kernel, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wl, hl, tables, out, T, vec_ok);
+        hipLaunchKernelGGL(kernel, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wl, hl, tables, out, T, vec_ok, need, minmax);
     };
     if (flags) {
         hipError_t e = hipMemsetAsync(out, 0, (size_t)total * sizeof(int), stream);      // frames not on the list are not loud
@@ -1530,17 +1578,6 @@ __device__ __forceinline__ float to_db(float s)
     return (float)(10 * log10((double)s / 1e-12));
 }
 
-__device__ __forceinline__ float wave_min(float v)
-{
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_maxf(float v)
-{
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
 // sum_intense for a whole wavefront: the cells are fetched 64 at a time in the reference's (row, column) order, then
 // added ONE BY ONE in that order (v_readlane + add: the float sum's order is part of the result).  NaN cells add 0.0f,
 // which leaves a float sum unchanged bit for bit, exactly like the reference's skip.  Returns the same value in every lane.
@@ -1570,22 +1607,30 @@ __device__ __forceinline__ int wave_last_false(int count, Pred pred)
     return -1;
 }
 
+// sum_intense's time-bin search (classifier.cpp:395-413) for a whole wavefront: the columns [t0, t1] of the window midpoint +-
+// half_range.  Used by the band sums AND by the midpoints kernel, which marks the columns whose rows have to be stored at all.
+__device__ __forceinline__ void intense_time_window(float half_range, int fs, int T, float midpoint, int &t0, int &t1)
+{
+    auto time = [&](int t) { return ((float)(t * kSpecHop + kSpecSeg / 2)) / (float)fs; };
+    const float t_lo = midpoint - half_range, t_hi = midpoint + half_range;
+    t0 = wave_first_false(T, [&](int t) { return time(t) < t_lo; });
+    t1 = wave_last_false(T, [&](int t) { return time(t) > t_hi; });
+    if (t0 >= T) t0 = T - 1;
+    if (t1 < 0) t1 = 0;
+    if (t0 > t1) { int x = t0; t0 = t1; t1 = x; }
+}
+
 __device__ float sum_intense_wave(float lower, float upper, float half_range, int fs, int T, const float *db, float midpoint,
                                   float *scratch /* LDS, 128 floats of this wavefront */)
 {
     auto freq = [&](int k) { return (float)k * (float)fs / (float)kSpecSeg; };
-    auto time = [&](int t) { return ((float)(t * kSpecHop + kSpecSeg / 2)) / (float)fs; };
-    const float t_lo = midpoint - half_range, t_hi = midpoint + half_range;
     int f0 = wave_first_false(kSpecBins, [&](int k) { return freq(k) < lower; });
     int f1 = wave_last_false(kSpecBins, [&](int k) { return freq(k) > upper; });
     if (f0 >= kSpecBins) f0 = kSpecBins - 1;
     if (f1 < 0) f1 = 0;
     if (f0 > f1) { int x = f0; f0 = f1; f1 = x; }
-    int t0 = wave_first_false(T, [&](int t) { return time(t) < t_lo; });
-    int t1 = wave_last_false(T, [&](int t) { return time(t) > t_hi; });
-    if (t0 >= T) t0 = T - 1;
-    if (t1 < 0) t1 = 0;
-    if (t0 > t1) { int x = t0; t0 = t1; t1 = x; }
+    int t0, t1;
+    intense_time_window(half_range, fs, T, midpoint, t0, t1);
     const int lane = threadIdx.x & 63;
     const int W = t1 - t0 + 1, N = (f1 - f0 + 1) * W;
     float total = 0.0f;
@@ -1674,10 +1719,15 @@ hipError_t launch_spec_threshold(SpecTables *tables, float threshold_db, hipStre
 //   classify_bands_kernel      (band-pass spectrogram, clips with midpoints only)  dB map, normalisation, the three
 //                              band sums per midpoint in the reference's order, the rule
 constexpr int kMidClipsPerWave = 4;       // clips one wavefront walks: one atomic on the work-list counter per 16 clips, not per clip
-__global__ __launch_bounds__(256) void classify_midpoints_kernel(const int *__restrict__ loud, long n_clips, int T, int fs,
+__global__ __launch_bounds__(256) void classify_midpoints_kernel(int *loud, long n_clips, int T, int fs,
                                                                  int *__restrict__ labels, ClassifyTrace *__restrict__ trace,
-                                                                 int *__restrict__ hits, int full_records)
+                                                                 int *__restrict__ hits, int full_records, unsigned *__restrict__ minmax)
 {
+    // minmax != nullptr (classify): once a clip's flags are read, its row of loud[] is rewritten as need[t] = "time bin t lies in a
+    // band window (+- 0.18 s or +- 0.05 s, sum_intense's own search) of one of the clip's midpoints" -- the rows the band sums will
+    // read and the only ones spec_from_ckpt_kernel<[time][bin]> stores -- and minmax[clip] is reset for that kernel's atomics.
+    __shared__ float mids_lds[4][kMaxMidpoints];
+    __shared__ int win_lo[4][2 * kMaxMidpoints], win_hi[4][2 * kMaxMidpoints];
     // a wavefront per clip, kMidClipsPerWave clips in turn; loud[clip][T] are the time bins with a cell above the threshold
     // (spec_from_ckpt_kernel<SPEC_FLAGS>).  Clips with midpoints go on the band kernels' work list: collected per block and
     // appended with ONE atomic (12 288 single-word atomics from as many wavefronts took 0.14 ms: the word saturates at
@@ -1718,7 +1768,7 @@ __global__ __launch_bounds__(256) void classify_midpoints_kernel(const int *__re
                 if (dur >= min_dur) {
                     float sm = 0.0f;
                     for (int k = i0; k <= i1; ++k) sm = sm + blob[k];
-                    if (count < kMaxMidpoints) trace[clip].midpoints[count] = sm / (float)(i1 - i0 + 1);
+                    if (count < kMaxMidpoints) { trace[clip].midpoints[count] = sm / (float)(i1 - i0 + 1); mids_lds[wib][count] = sm / (float)(i1 - i0 + 1); }
                     ++count;
                 }
                 i0 = i1 + 1;
@@ -1730,6 +1780,28 @@ __global__ __launch_bounds__(256) void classify_midpoints_kernel(const int *__re
         }
         count = __builtin_amdgcn_readfirstlane(count);
         n_hits += count > 0 ? 1 : 0;
+        if (minmax && count > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // mids_lds written by lane 0
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int k = 0; k < count; ++k) {
+                const float mid = mids_lds[wib][k];
+                int a0, a1, b0, b1;
+                intense_time_window(0.18f, fs, T, mid, a0, a1);        // the 5000-7000 Hz and 500-2500 Hz bands
+                intense_time_window(0.05f, fs, T, mid, b0, b1);        // the 2500-5000 Hz band
+                if (lane == 0) { win_lo[wib][2 * k] = a0; win_hi[wib][2 * k] = a1; win_lo[wib][2 * k + 1] = b0; win_hi[wib][2 * k + 1] = b1; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int j0 = 0; j0 < T; j0 += 64) {
+                const int j = j0 + lane;
+                int nd = 0;
+                for (int w = 0; w < 2 * count; ++w) nd |= (j >= win_lo[wib][w] && j <= win_hi[wib][w]) ? 1 : 0;
+                if (j < T) loud[clip * T + j] = nd;
+            }
+            if (lane == 0) { minmax[2 * clip] = 0x7F800000u; minmax[2 * clip + 1] = 0u; }      // + inf, 0: nothing seen yet
+        }
         if (full_records) {
             // a whole record per clip: unused midpoints and the band sums the rule never reaches (no midpoints, or after the
             // first hit) read as 0.  midpoints[64] and sums[64][3] are 256 consecutive floats.
@@ -1758,12 +1830,25 @@ __global__ __launch_bounds__(256) void classify_midpoints_kernel(const int *__re
 // registers (kTailPerThread per thread) and the map is written to LDS; otherwise the map is rebuilt in place in HBM.
 constexpr int kTailPerThread = (kTailLdsCells + 255) / 256;
 
+// need / minmax (both or neither): only the rows with need[clip][t] != 0 exist in sxx_bp (the others were never stored and are never
+// read: no band window covers them), and the smallest / largest positive cell of the WHOLE map comes from minmax[clip] (float bits).
 template <bool USE_LDS>
 __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, long clip, int T, int fs, int *__restrict__ labels,
-                                                    ClassifyTrace *__restrict__ trace, float *map_lds, const ClassifyRule &rule)
+                                                    ClassifyTrace *__restrict__ trace, float *map_lds, const ClassifyRule &rule,
+                                                    bool partial, const int (&need_regs)[USE_LDS ? 1 : 4], const unsigned (&minmax_regs)[2])
 {
+    // partial: need_regs = this thread's words of need[clip][] (time bins tid + 256 k) and minmax_regs = minmax[clip][], fetched by
+    // the caller while the previous clip was being worked on (read here they cost each clip two exposed round trips to memory)
     __shared__ float red_mn[4], red_mx[4];
     __shared__ float mids[kMaxMidpoints];
+    __shared__ unsigned char need_lds[1024];
+    if (partial) {
+#pragma unroll
+        for (int k = 0; k < (USE_LDS ? 1 : 4); ++k)          // USE_LDS: 129 T <= kTailLdsCells, T < 256
+            if (threadIdx.x + 256 * k < T) need_lds[threadIdx.x + 256 * k] = need_regs[k] != 0;
+        __syncthreads();
+    }
+    auto row_exists = [&](int idx) { return !partial || need_lds[idx / kSpecBins] != 0; };
     const int n_mids = trace[clip].n_midpoints;
     const int tid = threadIdx.x;
     const int cells = kSpecBins * T;
@@ -1777,7 +1862,36 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
     // widened by a safety margin can survive the reference's test: those get the exact dB value and the reference's
     // own float comparison, all others are NaN in the reference as well.
     float smn = INFINITY, smx = -INFINITY;
-    if (USE_LDS) {
+    if (USE_LDS && partial) {
+        // only the rows a band window covers exist: a wave takes rows wave, wave + 4, ... (whether a row exists is wave-uniform: a
+        // scalar branch, no per-cell predicate), eight rows' loads in flight; rows that do not exist read as 0 = "no candidate"
+        const int wv = tid >> 6, ln = tid & 63;
+        constexpr int RB = 8;
+        for (int r0 = wv; r0 < T; r0 += 4 * RB) {
+            float c0[RB], c1[RB], c2[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int r = r0 + 4 * u;
+                const bool ex = r < T && need_lds[r < T ? r : 0] != 0;
+                c0[u] = c1[u] = c2[u] = 0.0f;
+                if (ex) {
+                    const float *row = bp_g + (long)r * kSpecBins;
+                    c0[u] = row[ln]; c1[u] = row[64 + ln];
+                    if (ln == 0) c2[u] = row[128];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int r = r0 + 4 * u;
+                if (r < T) {
+                    float *row = map_lds + r * kSpecBins;
+                    row[ln] = c0[u]; row[64 + ln] = c1[u];
+                    if (ln == 0) row[128] = c2[u];
+                }
+            }
+        }
+        // (smn / smx come from minmax below)
+    } else if (USE_LDS) {
         // all loads of the thread in flight together, then the raw PSD values wait in the LDS map for their second pass
         float cell[kTailPerThread];
 #pragma unroll
@@ -1789,7 +1903,7 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
         }
     } else {
         for (int i = tid; i < cells; i += 256) {
-            const float sv = bp_g[i];
+            const float sv = row_exists(i) ? bp_g[i] : 0.0f;
             if (sv > 0) { smn = fminf(smn, sv); smx = fmaxf(smx, sv); }
         }
     }
@@ -1800,6 +1914,11 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
     BD_STAMP(1);
     smn = fminf(fminf(red_mn[0], red_mn[1]), fminf(red_mn[2], red_mn[3]));      // min / max are order-independent
     smx = fmaxf(fmaxf(red_mx[0], red_mx[1]), fmaxf(red_mx[2], red_mx[3]));
+    if (partial) {                                                              // of the whole map, rows that were not stored included
+        smn = __uint_as_float(minmax_regs[0]);
+        const float whole_mx = __uint_as_float(minmax_regs[1]);
+        smx = whole_mx > 0 ? whole_mx : -INFINITY;
+    }
     // the reference starts its running min / max from +-DBL_MAX stored in floats = +-inf
     const float mn = smn <= smx ? to_db(smn) : INFINITY, mx = smn <= smx ? to_db(smx) : -INFINITY;
     const float lo_thr = rule.keep_lo, hi_thr = rule.keep_hi;
@@ -1849,7 +1968,8 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
         }
         drain(pend);
     } else {
-        for (int i = tid; i < cells; i += 256) bp_g[i] = keep(bp_g[i]);
+        for (int i = tid; i < cells; i += 256)
+            if (row_exists(i)) bp_g[i] = keep(bp_g[i]);
     }
     const float *bp = USE_LDS ? map_lds : bp_g;
     __syncthreads();
@@ -1879,43 +1999,63 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
 // blocks of a fixed grid walk it, so the load is even over the XCDs whatever the positions of those clips in the batch
 // (workgroups go round-robin to the XCDs by block number: "one block per clip" left 6 of 8 XCDs idle for a batch with
 // every fourth clip positive).
+// (four waves per SIMD = four blocks per CU beside the 36 KB map: hipcc found 127 VGPRs by itself until the kernel grew, then 182 -- two
+// blocks per CU and 625 us instead of 396)
 template <bool USE_LDS>
-__global__ __launch_bounds__(256) void classify_bands_kernel(float *__restrict__ sxx_bp, int T, int fs, int *__restrict__ labels,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void classify_bands_kernel(float *__restrict__ sxx_bp, int T, int fs, int *__restrict__ labels,
                                                              ClassifyTrace *__restrict__ trace, const int *__restrict__ hits,
-                                                             const ClassifyRule rule)
+                                                             const ClassifyRule rule, const int *__restrict__ need, const unsigned *__restrict__ minmax)
 {
     extern __shared__ float map_lds[];
     const int count = hits[0];
+    const bool partial = need != nullptr;
+    constexpr int NK = USE_LDS ? 1 : 4;                      // words of need[clip][] per thread (T <= 1024; USE_LDS: T < 256)
+    int nd[NK], nd_next[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { nd[k] = 1; nd_next[k] = 1; }
+    unsigned mm2[2] = {0u, 0u}, mm2_next[2] = {0u, 0u};
+    auto fetch = [&](int it, int (&n4)[NK], unsigned (&m2)[2]) {
+        if (!partial || it >= count) return;
+        const long c = hits[1 + it];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) n4[k] = (int)threadIdx.x + 256 * k < T ? need[c * T + threadIdx.x + 256 * k] : 0;
+        m2[0] = minmax[2 * c]; m2[1] = minmax[2 * c + 1];
+    };
+    fetch(blockIdx.x, nd_next, mm2_next);
     for (int it = blockIdx.x; it < count; it += gridDim.x) {
-        classify_bands_clip<USE_LDS>(sxx_bp, hits[1 + it], T, fs, labels, trace, map_lds, rule);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) nd[k] = nd_next[k];
+        mm2[0] = mm2_next[0]; mm2[1] = mm2_next[1];
+        fetch(it + gridDim.x, nd_next, mm2_next);            // the next clip's, in flight during this one
+        classify_bands_clip<USE_LDS>(sxx_bp, hits[1 + it], T, fs, labels, trace, map_lds, rule, partial, nd, mm2);
         __syncthreads();                                     // the block's LDS is reused by the next clip
     }
 }
 
-hipError_t launch_classify_midpoints(const int *loud, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, int *hits,
-                                     hipStream_t stream, bool full_records)
+hipError_t launch_classify_midpoints(int *loud, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, int *hits,
+                                     hipStream_t stream, bool full_records, unsigned *minmax)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0) return hipSuccess;
     if (T <= 0 || T > 1024 || !trace || !hits) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(hits, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(classify_midpoints_kernel, dim3((unsigned)((n_clips + 4 * kMidClipsPerWave - 1) / (4 * kMidClipsPerWave))), dim3(256), 0, stream, loud, n_clips, T, fs, labels, trace, hits, full_records ? 1 : 0);
+    hipLaunchKernelGGL(classify_midpoints_kernel, dim3((unsigned)((n_clips + 4 * kMidClipsPerWave - 1) / (4 * kMidClipsPerWave))), dim3(256), 0, stream, loud, n_clips, T, fs, labels, trace, hits, full_records ? 1 : 0, minmax);
     return hipGetLastError();
 }
 
 hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, const int *hits,
-                                 hipStream_t stream, const ClassifyRule &rule)
+                                 hipStream_t stream, const ClassifyRule &rule, const int *need, const unsigned *minmax)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0) return hipSuccess;
-    if (T <= 0 || T > 1024 || !trace || !hits) return hipErrorInvalidValue;
+    if (T <= 0 || T > 1024 || !trace || !hits || (need == nullptr) != (minmax == nullptr)) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)(n_clips < 2048 ? n_clips : 2048);      // 256 CUs x 4 resident blocks x 2
     if (kSpecBins * T <= kTailLdsCells)
         hipLaunchKernelGGL(classify_bands_kernel<true>, dim3(blocks), dim3(256), (size_t)kSpecBins * T * sizeof(float), stream, sxx_bp, T, fs,
-                           labels, trace, hits, rule);
+                           labels, trace, hits, rule, need, minmax);
     else
-        hipLaunchKernelGGL(classify_bands_kernel<false>, dim3(blocks), dim3(256), 0, stream, sxx_bp, T, fs, labels, trace, hits, rule);
+        hipLaunchKernelGGL(classify_bands_kernel<false>, dim3(blocks), dim3(256), 0, stream, sxx_bp, T, fs, labels, trace, hits, rule, need, minmax);
     return hipGetLastError();
 }
 

@@ -84,9 +84,12 @@ hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, co
 // Spectrogram of segments recomputed from those checkpoints (filter c, checkpoints ck: ck_mp's layout for flags = true, ck_bp's
 // otherwise).  flags = true: out = int loud[c][T]
 // (1 = some cell >= mp_keep_min; 0 for every segment not on `wantlist`), means = means_mp; flags = false: out = PSD
-// [c][T][129] of every segment of the clips on the work list `hits` (means computed here).
+// [c][T][129] of every segment of the clips on the work list `hits` (means computed here) -- with need / minmax (optional, flags =
+// false): only the rows with need[c][t] != 0 are stored, and minmax[c][2] receives the float bits of the smallest / largest positive
+// cell over ALL transformed rows of clip c (atomicMin / atomicMax: the caller resets them to +inf / 0; launch_classify_midpoints does).
 hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
-                                 const int *wantlist, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream);
+                                 const int *wantlist, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream,
+                                 const int *need = nullptr, unsigned *minmax = nullptr);
 
 // sxx[c][129][T] (T = (n-256)/224+1) of clip rows y[c][0..n)
 struct ClassifyTrace {           // per clip, for parity tests
@@ -118,13 +121,16 @@ hipError_t launch_spectrogram_flags(const float *y, long n_clips, int n, long st
 // midpoints); `hits` (1 + n_clips ints) is the work list between the two: hits[0] = clips with midpoints, then their numbers.
 // full_records = false: only what the band kernel reads (count + midpoints) is written, not the zero-filled remainder of the
 // 1 KB record (callers that return labels only).
-hipError_t launch_classify_midpoints(const int *loud, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, int *hits,
-                                     hipStream_t stream, bool full_records = true);
+// minmax (optional, 2 x n_clips words): the rows of loud[] of the clips with midpoints are REWRITTEN as need[c][t] = "a band window of
+// one of the clip's midpoints covers time bin t", and minmax[c] is reset (+inf, 0) for launch_spec_from_ckpt's atomics; pass both to
+// launch_spec_from_ckpt and launch_classify_bands: only the needed rows of the map are then stored and read.
+hipError_t launch_classify_midpoints(int *loud, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, int *hits,
+                                     hipStream_t stream, bool full_records = true, unsigned *minmax = nullptr);
 // the thresholds of classify() the reference's variants differ in (dsp_classify_config): keep band of the normalised dB
 // map (classifier.cpp:67-68) and the rule middle < . && above > . && below > . (classifier.cpp:109)
 struct ClassifyRule { float keep_lo, keep_hi, middle_max, above_min, below_min; };
 hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, const int *hits,
-                                 hipStream_t stream, const ClassifyRule &rule);
+                                 hipStream_t stream, const ClassifyRule &rule, const int *need = nullptr, const unsigned *minmax = nullptr);
 // Counts, into *mismatches (device, zeroed by the caller), the floats p in [kDivFastLo, kDivFastHi] for which the three-instruction
 // form of p / tables->U (see SpecTables::rU) differs from the division: every bit pattern in the range is tried.
 hipError_t launch_spec_div_verify(const SpecTables *tables, unsigned long long *mismatches, hipStream_t stream);
