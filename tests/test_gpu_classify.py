@@ -315,20 +315,13 @@ def test_donut_classifier_recordings(dsp, golden):
             assert labels[0] == olab and np.array_equal(trace[0][0], omids) and np.array_equal(trace[0][1], osums), (n, cname)
 
 
-def test_simd_aware_parts_of_the_checkpoint_kernel_change_nothing(dsp, golden, tmp_path):
-    """iir2_ckpt_kernel gives the taps to whichever wave sits on its CU's most loaded SIMD (a table the launch fills itself;
-    launches of more than two blocks per CU only).  DSP_AMD_CKPT_SIMD_AWARE=2 forces the table for every launch: a child process
-    runs a shuffled batch that way, and labels, midpoints and band sums must equal this process's (fixed parts at this size)."""
+def _classify_in_a_child(clips, tmp_path, **env_vars):
+    """labels, midpoint counts, midpoints and band sums of classify_batch(clips) from a child process started with env_vars."""
     import os
     import subprocess
     import sys
-    g = golden("classifier_ref.npz")
-    base = np.stack([g[f"{n}__input"] for n in CASES])
-    order = np.random.default_rng(5).integers(0, len(CASES), 700)            # 11 blocks of 64 clips
-    clips = base[order]
-    labels, trace = dsp.classify_batch(clips, with_trace=True)
     src = tmp_path / "clips.npy"
-    out = tmp_path / "forced.npz"
+    out = tmp_path / "child.npz"
     np.save(src, clips)
     code = (
         "import sys, numpy as np\n"
@@ -340,15 +333,49 @@ def test_simd_aware_parts_of_the_checkpoint_kernel_change_nothing(dsp, golden, t
         "counts = np.array([len(m) for m, _ in trace])\n"
         f"np.savez({str(out)!r}, labels=labels, mids=mids, sums=sums, counts=counts)\n"
     )
-    env = dict(os.environ, DSP_AMD_CKPT_SIMD_AWARE="2")
+    env = dict(os.environ, **env_vars)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    f = np.load(out)
-    assert np.array_equal(f["labels"], labels) and set(labels) == {0, 1}
+    return np.load(out)
+
+
+def _same_as_child(f, labels, trace):
+    assert np.array_equal(f["labels"], labels)
     assert np.array_equal(f["counts"], np.array([len(m) for m, _ in trace]))
-    assert np.array_equal(f["mids"], np.concatenate([np.asarray(m, np.float32).ravel() for m, _ in trace]))
-    assert np.array_equal(f["sums"], np.concatenate([np.asarray(s, np.float32).ravel() for _, s in trace]))
+    assert np.array_equal(f["mids"], np.concatenate([np.asarray(m, np.float32).ravel() for m, _ in trace] + [np.zeros(0, np.float32)]))
+    assert np.array_equal(f["sums"], np.concatenate([np.asarray(s, np.float32).ravel() for _, s in trace] + [np.zeros(0, np.float32)]))
+
+
+def test_simd_aware_parts_of_the_checkpoint_kernel_change_nothing(dsp, golden, tmp_path):
+    """iir2_ckpt_kernel gives the taps to whichever wave sits on its CU's most loaded SIMD (a table the launch fills itself;
+    launches of more than two blocks per CU only).  DSP_AMD_CKPT_SIMD_AWARE=2 forces the table for every launch: a child process
+    runs a shuffled batch that way, and labels, midpoints and band sums must equal this process's (fixed parts at this size)."""
+    g = golden("classifier_ref.npz")
+    base = np.stack([g[f"{n}__input"] for n in CASES])
+    order = np.random.default_rng(5).integers(0, len(CASES), 700)            # 11 blocks of 64 clips
+    clips = base[order]
+    labels, trace = dsp.classify_batch(clips, with_trace=True)
+    assert set(labels) == {0, 1}
+    _same_as_child(_classify_in_a_child(clips, tmp_path, DSP_AMD_CKPT_SIMD_AWARE="2"), labels, trace)
+
+
+def test_storing_only_the_needed_map_rows_changes_nothing(dsp, golden, tmp_path):
+    """By default only the rows of the 3000-7500 Hz map that a band window of one of the clip's midpoints covers are stored and read,
+    and the map's minimum / maximum reach the band kernel through atomics; DSP_AMD_CLASSIFY_FULL_MAPS=1 (read once per process: a
+    child) stores and scans every row.  One-second clips (the map in LDS) and 5-second ones with several calls (the map in HBM):
+    labels, midpoints and band sums equal, bit for bit."""
+    g = golden("classifier_ref.npz")
+    base = np.stack([g[f"{n}__input"] for n in CASES])
+    rng = np.random.default_rng(9)
+    clips = base[rng.integers(0, len(CASES), 300)]
+    labels, trace = dsp.classify_batch(clips, with_trace=True)
+    assert set(labels) == {0, 1} and max(len(m) for m, _ in trace) >= 1
+    _same_as_child(_classify_in_a_child(clips, tmp_path, DSP_AMD_CLASSIFY_FULL_MAPS="1"), labels, trace)
+    long = np.concatenate([base[rng.integers(0, len(CASES), 40)] for _ in range(5)], axis=1)       # 40 clips of 5 s
+    labels, trace = dsp.classify_batch(long, with_trace=True)
+    assert max(len(m) for m, _ in trace) >= 2
+    _same_as_child(_classify_in_a_child(long, tmp_path, DSP_AMD_CLASSIFY_FULL_MAPS="1"), labels, trace)
 
 
 def test_fast_psd_division_is_the_division_on_every_float_of_its_range(dsp):
