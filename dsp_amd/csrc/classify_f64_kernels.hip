@@ -37,7 +37,7 @@ namespace {
 constexpr int kMaxColsF64 = 960;            // >= capi.cpp's kMaxSpecColumns (957): a flag per spectrogram column
 constexpr int kWinCells = 48 * 32;          // band window staged in LDS: the widest band has 41 rows (2500-5000 Hz) x 27 columns (0.36 s at 14 ms per column)
 #ifndef DSP_F64_FFT_AHEAD
-#define DSP_F64_FFT_AHEAD 2
+#define DSP_F64_FFT_AHEAD 1
 #endif
 constexpr int kFftAhead = DSP_F64_FFT_AHEAD;  // turns (two frames each) of loads a transform wave keeps in flight
 constexpr int kTailLoads = 8;               // map cells a thread has in flight while it scans a map (one at a time left the scan bound by the load latency)
@@ -76,25 +76,27 @@ __device__ __forceinline__ cd cmul(cd a, double wr, double wi) { return {a.re * 
 // of the radices before it, thread i of N / R: k = i mod p, inputs x[i + r N / R] times exp(-2 pi i r k / (p R)), an R-point DFT,
 // outputs y[(i - k) R + k + r p].  The real spectrum X[k] = E[k] + W256^k O[k] is taken from Z[k] and conj(Z[128 - k]), lane i
 // takes bins i, i + 32, i + 64, i + 96, and |X|^2 / U (doubled for 0 < k < 128) is the PSD cell of bin k (:574-592).
+// DSP_F64_FFT_DIAG = 1 / 2: timing-only builds (no loads / loads only) behind the record in profiles/r03_classify_f64_session2.txt.
 // (First form of this round: one frame per wave, radix 2, seven stages of two points per lane -- 60 % of a CU's LDS bandwidth and
 // every frame a chain of seven dependent LDS round trips: 2.6 ms per 3.5 M frames against 2.0 ms.)
 //   MAPS = false  every frame of every clip: loud[frame] = one of its 129 cells is above the midpoint threshold (no map leaves the kernel)
 //   MAPS = true   the frames of the clips on the work list hits (hits[0] entries, clip numbers from hits[1]): sxx[entry][t][k] = U * PSD
 template <bool MAPS>
-__global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *__restrict__ y, long n_clips, int T, long stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void spectrogram_f64_fft_kernel(const double *__restrict__ y, long n_clips, int T, long stride,
                                                                    const SpecTablesD *__restrict__ tab, const int *__restrict__ hits,
                                                                    double *__restrict__ sxx, int *__restrict__ loud, double mid_power, double midpoint_db, double guard)
 {
     const long total = (MAPS ? (long)hits[0] : n_clips) * T;
-    // [wave][half][ping-pong][128 + 32]: the image stage p = 1 writes is padded by one element in four (P1 below)
-    __shared__ __attribute__((aligned(16))) cd buf[4][2][2][kSpecSeg / 2 + 32];
+    // [wave][half]: ping (128 + 32: the image stage p = 1 writes is padded by one element in four, P1 below) and pong (128)
+    __shared__ __attribute__((aligned(16))) cd buf0[4][2][kSpecSeg / 2 + 32], buf1[4][2][kSpecSeg / 2];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, half = lane >> 5, i = lane & 31;
-    cd *b0 = buf[wib][half][0], *b1 = buf[wib][half][1];
+    cd *b0 = buf0[wib][half], *b1 = buf1[wib][half];
     // Twiddles: block-shared LDS tables laid out so that the lanes of a read are contiguous (a lane keeping its twelve twiddles in
     // registers cost 48 VGPRs; one table of W256^m indexed by m put the 16 lanes of a read on one or two banks):
-    //   w16[r - 1][k] = W64^(k r), k < 16 (stage p = 16)   w128[b] = W128^b, b < 64 (radix-2 stage)   w256[k] = W256^k, k < 128 (bins)
-    // Stage p = 4 needs W16^(k r), k = i & 3: six doubles, in registers.
-    __shared__ __attribute__((aligned(16))) cd w16[3][16], w128[64], w256[kSpecSeg / 2];
+    //   w16[r - 1][k] = W64^(k r), k < 16 (stage p = 16; stage p = 4 reads its W16^(k r) = W64^(4 k r) at [r - 1][4 k]: four addresses
+    //   on four different bank groups)          w256[k] = W256^k, k < 128 (bins; the radix-2 stage reads W128^b at [2 b])
+    // 39.8 KB of LDS per block and <= 128 VGPRs: four blocks per CU, four waves per SIMD.
+    __shared__ __attribute__((aligned(16))) cd w16[3][16], w256[kSpecSeg / 2];
     auto tw = [&](int m) {                                               // W256^m from the half-circle table
         m &= 255;
         const double sg = (m & 128) ? -1.0 : 1.0;
@@ -103,13 +105,9 @@ __global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *
     {
         const int n = threadIdx.x;
         if (n < 48) w16[n >> 4][n & 15] = tw(4 * (n & 15) * ((n >> 4) + 1));
-        if (n < 64) w128[n] = tw(2 * n);
         if (n < 128) w256[n] = tw(n);
     }
     __syncthreads();
-    cd t4[3];
-#pragma unroll
-    for (int r = 1; r < 4; ++r) t4[r - 1] = tw(16 * (i & 3) * r);
     double win[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { win[2 * r] = tab->win[2 * i + 64 * r]; win[2 * r + 1] = tab->win[2 * i + 64 * r + 1]; }
@@ -140,6 +138,9 @@ __global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *
     for (int j = 0; j < kFftAhead; ++j) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) q[j][r] = d2{0.0, 0.0};
+#if defined(DSP_F64_FFT_DIAG) && DSP_F64_FFT_DIAG == 1      // timing-only probe: no loads
+        if (MAPS)
+#endif
         if (f + j * step < total) {
             const double *src = src_of(ea, ta);
 #pragma unroll
@@ -161,11 +162,22 @@ __global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *
         for (int j = 0; j + 1 < kFftAhead; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) q[j][r] = q[j + 1][r];
+#if defined(DSP_F64_FFT_DIAG) && DSP_F64_FFT_DIAG == 1
+        if (MAPS)
+#endif
         if (f + kFftAhead * step < total) {
             const double *src = src_of(ea, ta);
 #pragma unroll
             for (int r = 0; r < 4; ++r) q[kFftAhead - 1][r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
         }
+#if defined(DSP_F64_FFT_DIAG) && DSP_F64_FFT_DIAG == 2      // timing-only probe: loads only, no transform
+        if (!MAPS) {
+            const double sx = x[0].x + x[1].x + x[2].x + x[3].x;
+            if (i == 0 && live) loud[f] = sx == 123.456;
+            f += step; advance(ea, ta);
+            continue;
+        }
+#endif
         double sum = ((x[0].x + x[0].y) + (x[1].x + x[1].y)) + ((x[2].x + x[2].y) + (x[3].x + x[3].y));
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);      // within the half
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *
 #pragma unroll
         for (int r = 0; r < 4; ++r) u[r] = b0[i + (i >> 2) + 40 * r];     // P1(i + 32 r)
 #pragma unroll
-        for (int r = 1; r < 4; ++r) u[r] = cmul(u[r], t4[r - 1].re, t4[r - 1].im);
+        for (int r = 1; r < 4; ++r) { const cd w = w16[r - 1][4 * (i & 3)]; u[r] = cmul(u[r], w.re, w.im); }
         fft4(u[0], u[1], u[2], u[3]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) b1[j4 + 4 * r] = u[r];
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256) void spectrogram_f64_fft_kernel(const double *
 #pragma unroll
         for (int r = 0; r < 4; ++r) u[r] = b0[i + 32 * r];
         {
-            const cd w0 = w128[i], w1 = w128[i + 32];
+            const cd w0 = w256[2 * i], w1 = w256[2 * i + 64];
             const cd a0 = cmul(u[2], w0.re, w0.im), a1 = cmul(u[3], w1.re, w1.im);
             b1[i] = u[0] + a0; b1[i + 64] = u[0] - a0;
             b1[i + 32] = u[1] + a1; b1[i + 96] = u[1] - a1;
