@@ -59,6 +59,29 @@ __device__ __forceinline__ bool is_loud(double s, double mid_power, double midpo
     return s > mid_power * (1.0 + 1e-9) || (s >= mid_power * (1.0 - 1e-9) && s > 0 && to_db64(s) > midpoint_db);
 }
 
+// a double from another lane by a DPP move of its two words (VALU, not the LDS crossbar a __shfl_xor takes)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// the sum of v over the 32 lanes of this lane's half-wave, in every lane: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+// (after each step the lanes of a group hold the group's sum, so the mirrored lane's value is the other group's), then the
+// neighbouring row through v_permlane16_swap
+__device__ __forceinline__ double half_wave_sum(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+}
+
 struct cd { double re, im; };
 __device__ __forceinline__ cd operator+(cd a, cd b) { return {a.re + b.re, a.im + b.im}; }
 __device__ __forceinline__ cd operator-(cd a, cd b) { return {a.re - b.re, a.im - b.im}; }
@@ -82,7 +105,7 @@ __device__ __forceinline__ cd cmul(cd a, double wr, double wi) { return {a.re * 
 //   MAPS = false  every frame of every clip: loud[frame] = one of its 129 cells is above the midpoint threshold (no map leaves the kernel)
 //   MAPS = true   the frames of the clips on the work list hits (hits[0] entries, clip numbers from hits[1]): sxx[entry][t][k] = U * PSD
 template <bool MAPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void spectrogram_f64_fft_kernel(const double *__restrict__ y, long n_clips, int T, long stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void spectrogram_f64_fft_kernel(const double *__restrict__ y, long n_clips, int T, long stride,
                                                                    const SpecTablesD *__restrict__ tab, const int *__restrict__ hits,
                                                                    double *__restrict__ sxx, int *__restrict__ loud, double mid_power, double midpoint_db, double guard)
 {
@@ -108,6 +131,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
         if (n < 128) w256[n] = tw(n);
     }
     __syncthreads();
+#ifndef DSP_F64_FFT_TW_REGS
+#define DSP_F64_FFT_TW_REGS 1
+#endif
+    // DSP_F64_FFT_TW_REGS = 1: the twiddles of the three butterfly stages in registers (32 VGPRs: three waves per SIMD instead of four,
+    // which measure the same) -- eight LDS reads per turn less in a kernel the LDS pipe bounds; the bins' W256^k stay in the table
+    cd t4[3], t16[3], t2[2];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) { t4[r - 1] = w16[r - 1][4 * (i & 3)]; t16[r - 1] = w16[r - 1][i & 15]; }
+    t2[0] = w256[2 * i]; t2[1] = w256[2 * i + 64];
+    (void)t4; (void)t16; (void)t2;
     double win[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { win[2 * r] = tab->win[2 * i + 64 * r]; win[2 * r + 1] = tab->win[2 * i + 64 * r + 1]; }
@@ -178,9 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
             continue;
         }
 #endif
-        double sum = ((x[0].x + x[0].y) + (x[1].x + x[1].y)) + ((x[2].x + x[2].y) + (x[3].x + x[3].y));
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);      // within the half
+        const double sum = half_wave_sum(((x[0].x + x[0].y) + (x[1].x + x[1].y)) + ((x[2].x + x[2].y) + (x[3].x + x[3].y)));
         const double mean = sum / (double)kSpecSeg;                      // classifier.c:551-561 detrend
         cd u[4];
 #pragma unroll
@@ -197,7 +228,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
 #pragma unroll
         for (int r = 0; r < 4; ++r) u[r] = b0[i + (i >> 2) + 40 * r];     // P1(i + 32 r)
 #pragma unroll
-        for (int r = 1; r < 4; ++r) { const cd w = w16[r - 1][4 * (i & 3)]; u[r] = cmul(u[r], w.re, w.im); }
+        for (int r = 1; r < 4; ++r) { const cd w = DSP_F64_FFT_TW_REGS ? t4[r - 1] : w16[r - 1][4 * (i & 3)]; u[r] = cmul(u[r], w.re, w.im); }
         fft4(u[0], u[1], u[2], u[3]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) b1[j4 + 4 * r] = u[r];
@@ -206,7 +237,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
 #pragma unroll
         for (int r = 0; r < 4; ++r) u[r] = b1[i + 32 * r];
 #pragma unroll
-        for (int r = 1; r < 4; ++r) { const cd w = w16[r - 1][i & 15]; u[r] = cmul(u[r], w.re, w.im); }
+        for (int r = 1; r < 4; ++r) { const cd w = DSP_F64_FFT_TW_REGS ? t16[r - 1] : w16[r - 1][i & 15]; u[r] = cmul(u[r], w.re, w.im); }
         fft4(u[0], u[1], u[2], u[3]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) b0[j16 + 16 * r] = u[r];
@@ -215,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
 #pragma unroll
         for (int r = 0; r < 4; ++r) u[r] = b0[i + 32 * r];
         {
-            const cd w0 = w256[2 * i], w1 = w256[2 * i + 64];
+            const cd w0 = DSP_F64_FFT_TW_REGS ? t2[0] : w256[2 * i], w1 = DSP_F64_FFT_TW_REGS ? t2[1] : w256[2 * i + 64];
             const cd a0 = cmul(u[2], w0.re, w0.im), a1 = cmul(u[3], w1.re, w1.im);
             b1[i] = u[0] + a0; b1[i + 64] = u[0] - a0;
             b1[i + 32] = u[1] + a1; b1[i + 96] = u[1] - a1;
