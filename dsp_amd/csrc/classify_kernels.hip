@@ -166,6 +166,9 @@ __global__ __launch_bounds__(TWO ? 128 : 64) void iir_kernel(const TIO *__restri
                     VIO q;
 #pragma unroll
                     for (int i = 0; i < PER; ++i) q[i] = to[r * IIR_LD + cc + i];
+#ifdef DSP_IIR_DIAG_NO_STORE        // timing-only probe: the tiles are computed and staged, not stored
+                    if (q[0] == (TIO)123.456)
+#endif
                     __builtin_nontemporal_store(q, reinterpret_cast<VIO *>(y + (clip0 + r) * ystride + t0 + cc));
                 }
             }
