@@ -105,14 +105,7 @@ def classify_batch_f64(clips: np.ndarray, with_trace: bool = False, config=None)
     cfg = None if config is None else _lib.ClassifyConfigF64(*[float(v) for v in config])
     _lib.check(_lib.load().dsp_classify_batch_host_f64(C.byref(cfg) if cfg is not None else None, clips.ctypes.data, n_clips, n, n,
                                                         labels.ctypes.data, C.byref(tr) if with_trace else None), "dsp_classify_batch_host_f64")
-    if not with_trace:
-        return labels
-    out = []
-    for t in tr:
-        k = t.n_midpoints
-        out.append((np.array(t.midpoints[:k], np.float64),
-                    np.array([[t.sums[i][j] for j in range(3)] for i in range(k)], np.float64).reshape(-1, 3)))
-    return labels, out
+    return (labels, _trace_f64(tr)) if with_trace else labels
 
 
 def classify_device_f64(clips, labels=None, config=None):
@@ -128,6 +121,69 @@ def classify_device_f64(clips, labels=None, config=None):
     _lib.check(_lib.load().dsp_classify_batch_device_f64(C.byref(cfg) if cfg is not None else None, clips.data_ptr(), n_clips, n,
                                                           clips.stride(0), labels.data_ptr(), None, st), "dsp_classify_batch_device_f64")
     return labels
+
+
+STEREO_CHANNEL0, STEREO_AVERAGE = 0, 1       # dsp_amd.h: how interleaved stereo PCM becomes mono
+
+
+def _trace_f64(tr):
+    out = []
+    for t in tr:
+        k = t.n_midpoints
+        out.append((np.array(t.midpoints[:k], np.float64),
+                    np.array([[t.sums[i][j] for j in range(3)] for i in range(k)], np.float64).reshape(-1, 3)))
+    return out
+
+
+def classify_batch_f64_pcm16(pcm: np.ndarray, stereo_mode: int = STEREO_CHANNEL0, with_trace: bool = False, config=None):
+    """dsp_classify_batch_pcm16_host_f64: pcm int16 [n_clips][n] (mono) or [n_clips][n][2] (interleaved stereo; channel 0 as
+    donut-classifier/classifier.c:286-297 or the channels' average) -> labels (+ midpoints / band sums), the samples converted in the
+    kernels' loads exactly like classifier.c:55-59 (s / 32768.0)."""
+    pcm = np.ascontiguousarray(pcm, np.int16)
+    if pcm.ndim == 1:
+        pcm = pcm[None, :]
+    channels = 2 if pcm.ndim == 3 else 1
+    if pcm.ndim not in (2, 3) or (pcm.ndim == 3 and pcm.shape[2] != 2):
+        raise ValueError("pcm must be int16 [n_clips][n] or [n_clips][n][2]")
+    n_clips, n = pcm.shape[:2]
+    labels = np.zeros(n_clips, np.int32)
+    tr = (_lib.ClassifyTraceF64 * n_clips)() if with_trace else None
+    cfg = None if config is None else _lib.ClassifyConfigF64(*[float(v) for v in config])
+    _lib.check(_lib.load().dsp_classify_batch_pcm16_host_f64(C.byref(cfg) if cfg is not None else None, pcm.ctypes.data, n_clips, n, n, channels,
+                                                              int(stereo_mode), labels.ctypes.data, C.byref(tr) if with_trace else None),
+               "dsp_classify_batch_pcm16_host_f64")
+    return (labels, _trace_f64(tr)) if with_trace else labels
+
+
+def classify_device_f64_pcm16(pcm, labels=None, stereo_mode: int = STEREO_CHANNEL0, config=None):
+    """pcm: cuda int16 [n_clips][n] or [n_clips][n][2] -> cuda int32 labels (dsp_classify_batch_pcm16_device_f64), stream-ordered on
+    torch's current stream."""
+    import torch
+    if not (pcm.is_cuda and pcm.dtype == torch.int16 and pcm.dim() in (2, 3) and pcm.stride(-1) == 1):
+        raise ValueError("pcm must be an int16 CUDA tensor [n_clips][n] or [n_clips][n][2] with unit inner stride")
+    channels = 2 if pcm.dim() == 3 else 1
+    if channels == 2 and (pcm.shape[2] != 2 or pcm.stride(1) != 2 or pcm.stride(0) % 2):
+        raise ValueError("stereo pcm must be interleaved [n_clips][n][2]")
+    n_clips, n = pcm.shape[:2]
+    if labels is None:
+        labels = torch.empty(n_clips, dtype=torch.int32, device=pcm.device)
+    st = C.c_void_p(torch.cuda.current_stream(pcm.device).cuda_stream)
+    cfg = None if config is None else _lib.ClassifyConfigF64(*[float(v) for v in config])
+    _lib.check(_lib.load().dsp_classify_batch_pcm16_device_f64(C.byref(cfg) if cfg is not None else None, pcm.data_ptr(), n_clips, n,
+                                                                pcm.stride(0) // channels, channels, int(stereo_mode), labels.data_ptr(), None, st),
+               "dsp_classify_batch_pcm16_device_f64")
+    return labels
+
+
+def classify_stats_f64(device: int = 0):
+    """-> (segments, undecided, listed_clips) of the last float64 classifier pass on `device` (dsp_classify_stats_f64)."""
+    a, b, c = C.c_long(), C.c_long(), C.c_long()
+    _lib.check(_lib.load().dsp_classify_stats_f64(int(device), C.byref(a), C.byref(b), C.byref(c)), "dsp_classify_stats_f64")
+    return a.value, b.value, c.value
+
+
+def classify_release_f64(device: int = -1) -> None:
+    _lib.check(_lib.load().dsp_classify_release_f64(int(device)), "dsp_classify_release_f64")
 
 
 def find_midpoints(data: np.ndarray, fs: int = 16000) -> np.ndarray:

@@ -1,0 +1,784 @@
+// classify_f64_ckpt_kernels.hip -- the float64 classifier of donut-classifier/classifier.c without materialised filter outputs.
+//
+// Round 3 wrote both filtered copies of every clip to HBM (2 x 128 KB per one-second clip beside 128 KB of input) and read them back
+// for the transforms: 4.65 x the algorithmic traffic.  Here ONE pass over the input
+//   iir2_screen_f64_kernel    runs both Butterworth recurrences (classifier.c:420-446, bit for bit: separate multiply and subtract in
+//                             the reference's order) and stores only their RESTART STATES -- the delay line v[n-1 .. n-8] at offsets
+//                             0, 64, 128, 192 of every spectrogram segment (64 B each; 18 KB per clip and filter instead of 128 KB) --
+//                             and decides, for every segment of the 1000-3000 Hz output, find_midpoints' question "is a cell of this
+//                             time bin above the threshold" (:679-745) WITHOUT a float64 transform: a screening DFT of the segment in
+//                             bf16 on the matrix pipe with a rigorous error bound.  Loud for sure / quiet for sure are final; the
+//                             segments in between (a cell within the bound of the threshold: ~0.06 dB for noise) go on a work list.
+//   spec_f64_from_ckpt_kernel recomputes exactly the listed segments from their restart states -- the same operations on the same
+//                             values in the same order as the whole-clip recurrence, so the same bits -- and transforms them in
+//                             float64 (fft_frame, classify_f64_device.hpp): <flags> the undecided segments of the screening,
+//                             <maps> every segment of the 3000-7500 Hz output of the clips that have midpoints.
+// Midpoints and band sums follow as before (classify_f64_kernels.hip).  Every decision the classifier makes is made on float64 values:
+// the screening only proves, segment by segment, what the float64 transform would have decided.
+//
+// The screening (why it is sound).  For a segment y[0..255] of the 1000-3000 Hz output, mean m, window w, the reference's cell of bin k
+// is c_k |X_k|^2 / U, X_k = sum_n w_n (y_n - m) e^(-2 pi i k n / 256), c_k = 2 (1 for k = 0, 128).  The pass computes
+//   D_k = sum_n (Whi + Wlo)_kn bf16(y_n),  W_kn = w_n e^(-2 pi i k n / 256) split into two bf16 tables (|Whi + Wlo - W| <= 2^-16 |W|)
+// for k = 0 .. 63 and k = 128 with v_mfma_f32_32x32x16_bf16 (products exact in float32, float32 accumulation), then X~_k = D_k - m What_k
+// (What = the window's own transform).  bf16(y) = y (1 + d), |d| <= 2^-8, so per component |X~_k - X_k| <= g := 1.03 * 2^-8 * sum_n |y_n|
+// (the 3 % cover the table's 2^-16, the accumulation's 256 * 2^-24 and the float32 mean term), sqrt(2) g for the complex value.
+//   a cell is loud for sure   when |X~_k| > T_k + sqrt2 g,  T_k = sqrt(U * threshold power / c_k)
+//   quiet for sure            when |X~_k| < T_k - sqrt2 g
+// and the bins 64 .. 127 that are not computed are bounded together by Parseval: sum_k c_k |X_k|^2 = 256 E, E = sum_n w_n^2 (y_n - m)^2,
+// so every one of their cells is at most 256 E - sum_{computed k} c_k |X_k|^2, the subtracted sum taken low by the 2-norm of the
+// rounding error (||e|| <= 1.1 * 16 * 2^-8 * sqrt(sum w_n^2 y_n^2): the transform of w * (bf16(y) - y) by Parseval again).  E, the sums
+// and m come from the taps wave in float32 beside the float64 filter.  A segment is "quiet" only when every computed cell is quiet for
+// sure AND that remainder is below the threshold; "loud" when one computed cell is loud for sure; otherwise it is listed.
+//
+// Block = 64 clips (lane = clip in the serial parts), five wavefronts:
+//   R_bp  recurrence 3000-7500 Hz: x tile -> delay line, restart states to HBM           R_mp  the same at 1000-3000 Hz, v tile -> LDS
+//   T     taps of the 1000-3000 Hz filter one tile behind (y = b0 v + sum b_j v[n-j]), float32 sums per segment, y as bf16 -> LDS
+//   X0 X1 two tiles behind: the MFMAs (64 table rows x 64 clips each), the verdict at every segment's end; they also load the x tiles
+// A tile = 16 samples = one MFMA k-step = one full 128-byte line of a float64 row.  One __syncthreads per tile.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "classify_f64_device.hpp"
+#include "classify_kernels.hpp"
+
+// classifier.c is compiled without contraction (plain gcc -O2 on x86-64): every product is rounded before it is added
+#pragma clang fp contract(off)
+
+namespace dsp {
+
+using namespace f64dev;
+
+namespace {
+
+constexpr int SC_TS = 16;                         // samples per tile
+constexpr int SC_XLD = 18;                        // doubles per LDS row of an x / v tile (144 B: 16-byte aligned rows, 36-dword stride)
+constexpr int SC_YROW = 48;                       // bytes per clip row of a bf16 y tile (32 + 16: conflict-free ds_read_b128 / ds_write_b128)
+constexpr int SC_RING = 4;                        // y tiles kept: the transform waves run two tiles behind and start a segment one tile late
+constexpr int SC_THREADS = 320;
+#ifndef SC_ROLES
+#define SC_ROLES 7        // diagnostic builds: which roles are compiled in (1 recurrences, 2 taps, 4 transform waves)
+#endif
+constexpr int kTilesPerHop = kSpecHop / SC_TS;    // 14
+constexpr int kTilesPerSeg = kSpecSeg / SC_TS;    // 16
+constexpr int kCkStep = kCkStrideF64 / SC_TS;     // a restart state every 4 tiles
+static_assert(kSpecHop % SC_TS == 0 && kSpecSeg % SC_TS == 0 && kCkStrideF64 % SC_TS == 0 && kSpecSeg == kCkPerSegF64 * kCkStrideF64, "tiles, segments and restart states line up");
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- input kinds: what one sample is in HBM (IN of the kernels) ----
+//   0 float64        1 int16 mono (s / 32768, classifier.c:55-59)       2 int16 interleaved stereo, channel 0 (:286-297)
+//   3 int16 interleaved stereo, (L + R) / 65536 = the average of the two channels' s / 32768 (main_test.c:205-217 in double: exact)
+template <int IN> struct In;
+template <> struct In<0> { static constexpr int kBytes = 8, kPerPiece = 2; };     // bytes per sample (all channels), samples per 16-byte piece
+template <> struct In<1> { static constexpr int kBytes = 2, kPerPiece = 8; };
+template <> struct In<2> { static constexpr int kBytes = 4, kPerPiece = 4; };
+template <> struct In<3> { static constexpr int kBytes = 4, kPerPiece = 4; };
+
+// the samples of one 16-byte piece as doubles
+template <int IN>
+__device__ __forceinline__ void piece_to_f64(const u32x4 &q, double (&o)[In<IN>::kPerPiece])
+{
+    if constexpr (IN == 0) {
+        o[0] = __hiloint2double((int)q[1], (int)q[0]);
+        o[1] = __hiloint2double((int)q[3], (int)q[2]);
+    } else if constexpr (IN == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[2 * k] = (double)(int)(short)(q[k] & 0xffffu) * (1.0 / 32768.0);
+            o[2 * k + 1] = (double)((int)q[k] >> 16) * (1.0 / 32768.0);
+        }
+    } else if constexpr (IN == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (double)(int)(short)(q[k] & 0xffffu) * (1.0 / 32768.0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (double)((int)(short)(q[k] & 0xffffu) + ((int)q[k] >> 16)) * (1.0 / 65536.0);
+    }
+}
+
+// one sample read element-wise (rows that are not 16-byte aligned, pieces that cross the end of a row)
+template <int IN>
+__device__ __forceinline__ double sample_at(const void *__restrict__ x, long idx)
+{
+    if constexpr (IN == 0) return reinterpret_cast<const double *>(x)[idx];
+    else if constexpr (IN == 1) return (double)reinterpret_cast<const short *>(x)[idx] * (1.0 / 32768.0);
+    else if constexpr (IN == 2) return (double)reinterpret_cast<const short *>(x)[2 * idx] * (1.0 / 32768.0);
+    else return (double)((int)reinterpret_cast<const short *>(x)[2 * idx] + (int)reinterpret_cast<const short *>(x)[2 * idx + 1]) * (1.0 / 65536.0);
+}
+
+}  // namespace
+
+// =====================================================================================================================================
+// pass 1: recurrences, restart states, screening
+// =====================================================================================================================================
+template <int IN, bool EVEN_B, bool VEC>
+__global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void iir2_screen_f64_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T, const IirCoefD c_bp,
+                                                                      const IirCoefD c_mp, double *__restrict__ ck_bp, double *__restrict__ ck_mp,
+                                                                      const ScreenTablesD *__restrict__ tab, int *__restrict__ loud, int *__restrict__ want,
+                                                                      float thr_u, float guard)
+{
+    __shared__ __attribute__((aligned(16))) double tin[2][64 * SC_XLD];                 // x tiles as doubles, [tile parity]
+    __shared__ __attribute__((aligned(16))) double vbuf[2][64 * SC_XLD];                // v tiles of the 1000-3000 Hz filter
+    __shared__ __attribute__((aligned(16))) unsigned char ybuf[SC_RING][64 * SC_YROW];  // its output as bf16, [tile mod 4][clip][16 samples]
+    __shared__ float f_mean[64], f_g[64], f_e[64], f_en[64], f_sum[64];                  // per clip, of the segment that has just ended
+    __shared__ unsigned f_state[64];
+    __shared__ float what[65][2];                                                       // the window's transform at bins 0 .. 63, [64] = bin 128
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // 0 R_bp, 1 R_mp, 2 T, 3 X0, 4 X1
+    const long clip0 = (long)blockIdx.x * 64;
+    const int rows = (int)((n_clips - clip0) < 64 ? (n_clips - clip0) : 64);
+    const int n_tiles = (T - 1) * kTilesPerHop + kTilesPerSeg;           // samples past the last whole segment reach no output
+    if (threadIdx.x < 64) {
+        f_state[threadIdx.x] = 0u; f_sum[threadIdx.x] = 0.0f;
+        what[threadIdx.x][0] = tab->what_re[threadIdx.x]; what[threadIdx.x][1] = tab->what_im[threadIdx.x];
+        if (threadIdx.x == 0) { what[64][0] = tab->what128; what[64][1] = 0.0f; }
+    }
+    // recurrence waves ahead of the others in their SIMD's arbiter: they are the block's critical path
+    if (wv < 2) __builtin_amdgcn_s_setprio(3);
+    else if (wv == 2) __builtin_amdgcn_s_setprio(1);
+
+    // ---- x tiles: the 128 threads of X0 / X1 fetch 128-byte row pieces one load tile ahead and commit one compute tile per step ----
+    constexpr int PP = In<IN>::kPerPiece;                 // samples per 16-byte piece
+    constexpr int LT = 8 * PP;                            // samples per 128-byte load tile
+    constexpr int KT = LT / SC_TS;                        // compute tiles per load tile (1, 4, 2)
+    const int n_ltiles = (n_tiles + KT - 1) / KT;
+    u32x4 raw[4];
+    // VEC: every row start is 16-byte aligned -- 16-byte pieces one load tile ahead in registers.  A piece past the end of a row (int16
+    // input, last load tile) belongs to a compute tile past the last segment and is never committed; it is not fetched either.
+    // !VEC (odd strides, unaligned bases): the commit reads its samples element by element, nothing is kept in flight.
+    auto fetch = [&](int L, int ltid) {                   // thread takes piece c = ltid & 7 of rows (ltid >> 3) + 16 k
+        if (!VEC) return;
+        const int c = ltid & 7;
+        const long s0 = (long)L * LT + (long)c * PP;      // first sample of the piece
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = (ltid >> 3) + 16 * k;
+            raw[k] = u32x4{0u, 0u, 0u, 0u};
+            if (r < rows && s0 + PP <= n)
+                raw[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(xin) + ((clip0 + r) * stride + s0) * In<IN>::kBytes));
+        }
+    };
+    auto commit = [&](int cs, int ltid) {                 // compute tile cs (of the load tile in raw[]) -> tin[cs & 1]
+        const int c = ltid & 7, sub = cs % KT;
+        constexpr int PIECES_PER_TILE = SC_TS / PP;       // 8, 2, 4
+        if (c / PIECES_PER_TILE != sub) return;
+        const int off = (c % PIECES_PER_TILE) * PP;       // sample offset of the piece inside the compute tile
+        double *dst = tin[cs & 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = (ltid >> 3) + 16 * k;
+            double o[PP];
+            if (VEC) piece_to_f64<IN>(raw[k], o);
+            else {
+                const long s0 = (long)(cs / KT) * LT + (long)c * PP;
+                const void *row = reinterpret_cast<const unsigned char *>(xin) + (clip0 + (r < rows ? r : 0)) * stride * In<IN>::kBytes;
+#pragma unroll
+                for (int j = 0; j < PP; ++j) o[j] = r < rows ? sample_at<IN>(row, s0 + j) : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < PP; ++j) dst[r * SC_XLD + off + j] = o[j];
+        }
+    };
+    if (wv >= 3) {
+        const int ltid = (wv - 3) * 64 + lane;            // loader thread number
+        fetch(0, ltid);
+        commit(0, ltid);
+        if (KT == 1 && n_ltiles > 1) fetch(1, ltid);
+    }
+    __syncthreads();
+
+    // Each role runs its own loop over the steps with ONE barrier per step (every wave of the block executes the same number of
+    // barriers; the branch is wave-uniform): the compiler then allocates registers for the largest role, not for the sum of their states.
+    const int n_steps = n_tiles + 3;
+    if ((SC_ROLES & 1) && wv < 2) {
+        // ================= recurrence waves: tile s at step s =================
+        const IirCoefD &c = wv == 0 ? c_bp : c_mp;
+        double *ck = wv == 0 ? ck_bp : ck_mp;
+        double d[8];                                      // v[n-1] .. v[n-8] of this lane's clip
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = 0.0;
+        for (int s = 0; s < n_steps; ++s) {
+            if (s < n_tiles) {
+                const int seg = s / kTilesPerHop, p = s - seg * kTilesPerHop;
+                // restart states: offsets 0, 64, 128, 192 of segment seg (tiles 14 seg + {0, 4, 8, 12}; the last two tiles of a
+                // segment are the first two of the next)
+                if (p % kCkStep == 0 && seg < T && lane < rows) {
+                    d2 *dst = reinterpret_cast<d2 *>(ck + (((long)seg * kCkPerSegF64 + p / kCkStep) * n_clips + clip0 + lane) * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(d2{d[2 * j], d[2 * j + 1]}, dst + j);
+                }
+                const double *xrow = tin[s & 1] + lane * SC_XLD;
+                double xr[SC_TS];
+#pragma unroll
+                for (int i = 0; i < SC_TS; i += 2) { const d2 v2 = *reinterpret_cast<const d2 *>(xrow + i); xr[i] = v2.x; xr[i + 1] = v2.y; }
+#pragma unroll
+                for (int i = 0; i < SC_TS; ++i) {                       // classifier.c:427-433
+                    double v = xr[i];
+#pragma unroll
+                    for (int j = 1; j <= 8; ++j) v = v - c.a[j] * d[j - 1];
+#pragma unroll
+                    for (int j = 7; j > 0; --j) d[j] = d[j - 1];
+                    d[0] = v;
+                    xr[i] = v;
+                }
+                if (wv == 1) {
+                    double *vrow = vbuf[s & 1] + lane * SC_XLD;
+#pragma unroll
+                    for (int i = 0; i < SC_TS; i += 2) *reinterpret_cast<d2 *>(vrow + i) = d2{xr[i], xr[i + 1]};
+                }
+            }
+            __syncthreads();
+        }
+    } else if ((SC_ROLES & 2) && wv == 2) {
+        // ================= taps wave: tile s - 1 at step s =================
+        const IirCoefD &c = c_mp;
+        double d[8];                                      // v[n-1] .. v[n-8]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = 0.0;
+        float s_cur = 0.f, a_cur = 0.f, q_cur = 0.f, s_prev = 0.f, a_prev = 0.f, q_prev = 0.f;       // sum y, sum |y|, sum w^2 y^2 of the open segments
+        for (int s = 0; s < n_steps; ++s) {
+            const int ts = s - 1;
+            if (ts >= 0 && ts < n_tiles) {
+                const int tc = ts / kTilesPerHop, p = ts - tc * kTilesPerHop;          // segment tc at tile p; for p < 2 also segment tc - 1 at tile 14 + p
+                if (p == 0) { s_prev = s_cur; a_prev = a_cur; q_prev = q_cur; s_cur = a_cur = q_cur = 0.f; }
+                const double *vrow = vbuf[ts & 1] + lane * SC_XLD;
+                double vr[SC_TS];
+#pragma unroll
+                for (int i = 0; i < SC_TS; i += 2) { const d2 v2 = *reinterpret_cast<const d2 *>(vrow + i); vr[i] = v2.x; vr[i + 1] = v2.y; }
+                float yf[SC_TS];
+#pragma unroll
+                for (int i = 0; i < SC_TS; ++i) {                       // classifier.c:435-441
+                    double o = c.b[0] * vr[i];
+#pragma unroll
+                    for (int j = 1; j <= 8; ++j)
+                        if (!EVEN_B || j % 2 == 0) o = o + c.b[j] * d[j - 1];
+#pragma unroll
+                    for (int j = 7; j > 0; --j) d[j] = d[j - 1];
+                    d[0] = vr[i];
+                    yf[i] = (float)o;
+                }
+                if (p >= 2) {                                           // the window is 1 here
+#pragma unroll
+                    for (int i = 0; i < SC_TS; ++i) { s_cur += yf[i]; a_cur += fabsf(yf[i]); q_cur = fmaf(yf[i], yf[i], q_cur); }
+                } else {                                                // tapered in for segment tc, out for segment tc - 1
+#pragma unroll
+                    for (int i = 0; i < SC_TS; ++i) {
+                        const float wi = tab->win2_in[SC_TS * p + i], wo = tab->win2_out[SC_TS * p + i];
+                        s_cur += yf[i]; a_cur += fabsf(yf[i]); q_cur = fmaf(wi * yf[i], yf[i], q_cur);
+                        s_prev += yf[i]; a_prev += fabsf(yf[i]); q_prev = fmaf(wo * yf[i], yf[i], q_prev);
+                    }
+                }
+                // y as bf16, [clip][16 samples]: what an MFMA B fragment of 32 clips x 16 samples reads 16 bytes at a time
+                u32x4 lo4, hi4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    lo4[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{yf[2 * k], yf[2 * k + 1]}, bf16x2));
+                    hi4[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{yf[8 + 2 * k], yf[9 + 2 * k]}, bf16x2));
+                }
+                u32x4 *yrow = reinterpret_cast<u32x4 *>(ybuf[ts & (SC_RING - 1)] + lane * SC_YROW);
+                yrow[0] = lo4; yrow[1] = hi4;
+                if (p == 1 && tc >= 1) {                                // segment tc - 1 is complete: what the transform waves need of it
+                    const float m = s_prev * (1.0f / kSpecSeg);
+                    const float e = q_prev + 2.0f * fabsf(m) * a_prev + m * m * tab->win2_sum;      // >= sum w^2 (y - m)^2
+                    f_mean[lane] = m;
+                    f_g[lane] = 1.4142136f * 1.03f * (1.0f / 256.0f) * a_prev;
+                    f_e[lane] = (float)kSpecSeg * e * 1.0001f;
+                    f_en[lane] = 1.1f * 16.0f * (1.0f / 256.0f) * sqrtf(q_prev);
+                }
+            }
+            __syncthreads();
+        }
+    } else if ((SC_ROLES & 4) && wv >= 3) {
+        // ================= transform waves: tile s - 2 at step s; loaders of the x tiles =================
+        const int xq = wv - 3;                            // table blocks 2 xq, 2 xq + 1 = bins 32 xq .. 32 xq + 31
+        f32x16 acc[2][2];                                 // [table block][clip half], rows = (bin, re / im) pairs
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+        int pending_seg = -1;                             // X0: the segment whose verdicts are waiting in f_state / f_sum
+        // (the lane number is made opaque once per step: everything derived from it -- LDS addresses of the verdict's table reads, row
+        // pointers of the loader -- is then recomputed where it is used instead of being kept in registers across the loop)
+        int lane_o = lane;
+        for (int s = 0; s < n_steps; ++s) {
+            asm volatile("" : "+v"(lane_o));
+            const int r = lane_o & 31, h = lane_o >> 5;
+            if (xq == 0 && pending_seg >= 0) {
+                // the verdicts of segment pending_seg: all four contributions (two lane halves x two waves) are in
+                unsigned st = f_state[lane_o];                          // 0 every computed cell quiet for sure, 1 undecided, 2 a cell loud for sure
+                if (st == 0u) {
+                    const float root = sqrtf(f_sum[lane_o]) - f_en[lane_o];
+                    const float low = root > 0.f ? root * root : 0.f;   // the computed bins hold at least this much of 256 E
+                    if (!(f_e[lane_o] - low < thr_u * (1.0f - guard) * 0.9999f)) st = 1u;      // a bin that was not computed could reach the threshold
+                }
+                if (lane_o < rows) {
+                    const long fr = (clip0 + lane_o) * T + pending_seg;
+                    loud[fr] = st == 2u ? 1 : (st == 1u ? 2 : 0);
+                    if (st == 1u) want[1 + atomicAdd(want, 1)] = (int)fr;
+                }
+                f_state[lane_o] = 0u; f_sum[lane_o] = 0.0f;
+            }
+            pending_seg = -1;
+            // loader duty: compute tile s + 1 into LDS, the next load tile into registers
+            if (s + 1 < n_tiles) {
+                const int ltid = xq * 64 + lane_o;
+                commit(s + 1, ltid);
+                if ((s + 1) % KT == KT - 1 && (s + 1) / KT + 1 < n_ltiles) fetch((s + 1) / KT + 1, ltid);
+            }
+            const int tx = s - 2;
+            if (tx >= 0 && tx < n_tiles) {
+                const int tc = tx / kTilesPerHop, p = tx - tc * kTilesPerHop;
+                // This tile's work as a short list of k-steps, ONE MFMA site and ONE verdict site in the code:
+                //   p = 0: k-step 14 of segment tc - 1 (segment tc's first k-step waits: the accumulators still belong to tc - 1)
+                //   p = 1: k-step 15 of segment tc - 1, its verdict, then k-steps 0 (the previous tile, still in the ring) and 1 of segment tc
+                //   p > 1: k-step p of segment tc
+                const bool prev = p < 2 && tc >= 1, cur = tc < T && p >= 1;
+                const int n_prev = prev ? 1 : 0, n_ops = n_prev + (cur ? (p == 1 ? 2 : 1) : 0);
+#pragma unroll 1
+                for (int o = 0; o < n_ops; ++o) {
+                    const bool is_prev = o < n_prev;
+                    const int ks = is_prev ? kTilesPerHop + p : (p == 1 ? o - n_prev : p);
+                    const int tile = (!is_prev && p == 1 && o == n_prev) ? tx - 1 : tx;
+                    const unsigned char *yb = ybuf[tile & (SC_RING - 1)] + r * SC_YROW + 16 * h;
+                    const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(yb), b1 = *reinterpret_cast<const bf16x8 *>(yb + 32 * SC_YROW);
+#pragma unroll
+                    for (int mbl = 0; mbl < 2; ++mbl) {
+                        const bf16x8 *a = reinterpret_cast<const bf16x8 *>(tab->a_tab) + (size_t)((ks * 4 + 2 * xq + mbl) * 2) * 64 + lane_o;
+                        const bf16x8 a_hi = a[0], a_lo = a[64];
+                        acc[mbl][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b0, acc[mbl][0], 0, 0, 0);
+                        acc[mbl][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b1, acc[mbl][1], 0, 0, 0);
+                        acc[mbl][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b0, acc[mbl][0], 0, 0, 0);
+                        acc[mbl][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b1, acc[mbl][1], 0, 0, 0);
+                    }
+                    if (is_prev && p == 1) {
+                        // ---- the verdict on segment tc - 1, per clip (column) ----
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const int col = 32 * nb + r;
+                            const float m = f_mean[col], g = f_g[col];
+                            auto bounds = [&](float t2, float &hi2, float &lo2) {
+                                const float t = sqrtf(t2), up = t + g, dn = t - g;
+                                hi2 = fmaxf(up * up, t2 * (1.0f + guard)) * 1.00001f;
+                                lo2 = dn > 0.f ? fminf(dn * dn, t2 * (1.0f - guard)) * 0.99999f : -1.0f;
+                            };
+                            float hi2, lo2;
+                            bounds(0.5f * thr_u, hi2, lo2);             // |X|^2 at the threshold, c_k = 2
+                            bool sure_loud = false, all_quiet = true;
+                            float sum = 0.f;
+#pragma unroll
+                            for (int mbl = 0; mbl < 2; ++mbl)
+#pragma unroll
+                                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                                    for (int e = 0; e < 2; ++e) {
+                                        const int bin = 16 * (2 * xq + mbl) + 4 * gq + 2 * h + e;
+                                        const f32x2 wh = *reinterpret_cast<const f32x2 *>(what[bin]);
+                                        const float re = acc[mbl][nb][4 * gq + 2 * e] - m * wh.x;
+                                        const float im = acc[mbl][nb][4 * gq + 2 * e + 1] - m * wh.y;
+                                        if (mbl == 0 && gq == 0 && e == 0 && bin == 0) {
+                                            // table row 1 holds bin 128 where bin 0 has its (zero) imaginary part: two real cells, c_k = 1
+                                            float hi1, lo1;
+                                            bounds(thr_u, hi1, lo1);
+                                            const float r128 = acc[mbl][nb][1] - m * what[64][0];
+                                            const float p0 = re * re, p128 = r128 * r128;
+                                            sure_loud = sure_loud || p0 > hi1 || p128 > hi1;
+                                            all_quiet = all_quiet && p0 < lo1 && p128 < lo1;
+                                            sum += p0 + p128;
+                                        } else {
+                                            const float pw = re * re + im * im;
+                                            sure_loud = sure_loud || pw > hi2;
+                                            all_quiet = all_quiet && pw < lo2;
+                                            sum = fmaf(2.0f, pw, sum);
+                                        }
+                                    }
+                            atomicMax(&f_state[col], sure_loud ? 2u : (all_quiet ? 0u : 1u));
+                            atomicAdd(&f_sum[col], sum);
+                        }
+                        pending_seg = tc - 1;
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// =====================================================================================================================================
+// recompute + float64 transform of listed segments
+// =====================================================================================================================================
+// A wavefront takes 16 work items (segments) at a time: lane (f, j) = (item, quarter) loads the restart state of its quarter, runs the
+// filter over its 64 samples -- the recurrence and the taps on each sample as classifier.c:427-441 writes them -- and leaves y in the
+// item's LDS row; then the wave transforms the 16 rows two at a time (fft_frame).  x reaches the rows through coalesced 16-byte loads
+// (a segment is 2 KB of contiguous float64) and is overwritten in place by y.
+//   MAPS = false  items = the frames on the work list want (want[0] entries, frame numbers clip * T + t): loud[frame] = 0 / 1
+//   MAPS = true   items = all T segments of the clips on the work list hits: sxx[entry][t][129] = U * PSD
+constexpr int RC_FRAMES = 16;                    // items per wave pass
+constexpr int RC_CHUNK_LD = kCkStrideF64 + 2;     // doubles per quarter in an LDS row (+2: the four lanes of an item start on different banks)
+constexpr int RC_ROW_LD = kCkPerSegF64 * RC_CHUNK_LD + 2;      // 266 doubles per row (16-byte aligned rows)
+template <bool MAPS, int IN, bool EVEN_B>
+__global__ __launch_bounds__(256) void spec_f64_from_ckpt_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T, const IirCoefD c,
+                                                                 const double *__restrict__ ck, const SpecTablesD *__restrict__ tab,
+                                                                 const int *__restrict__ worklist, double *__restrict__ sxx, int *__restrict__ loud,
+                                                                 double mid_power, double midpoint_db, double guard, int vec_ok)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [wave] rows[16][RC_ROW_LD] doubles, then [wave][half] ping (kPingCd cd), then the twiddles
+    double *rows_all = reinterpret_cast<double *>(smem);
+    cd *ping_all = reinterpret_cast<cd *>(smem + (size_t)4 * RC_FRAMES * RC_ROW_LD * sizeof(double));
+    FftTwiddles &tw = *reinterpret_cast<FftTwiddles *>(smem + (size_t)4 * RC_FRAMES * RC_ROW_LD * sizeof(double) + (size_t)8 * kPingCd * sizeof(cd));
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, half = lane >> 5, i = lane & 31;
+    double *rows = rows_all + (size_t)wib * RC_FRAMES * RC_ROW_LD;
+    cd *b0 = ping_all + (size_t)(wib * 2 + half) * kPingCd;
+    fill_twiddles(tw, tab, threadIdx.x);
+    __syncthreads();
+    FftLane L;
+    fft_lane_init(L, tw, tab, i);
+    const double U = tab->U;
+    const long total = MAPS ? (long)worklist[0] * T : (long)worklist[0];
+    const long wave = (long)blockIdx.x * 4 + wib, n_waves = (long)gridDim.x * 4;
+    const int f = lane >> 2, j = lane & 3;                              // recompute role: item f of the pass, quarter j
+    for (long item0 = wave * RC_FRAMES; item0 < total; item0 += n_waves * RC_FRAMES) {
+        // ---- the items of this pass: (clip, t) of item item0 + k, k < 16 (every lane computes the one it needs) ----
+        auto item_of = [&](long it, long &clip, int &t) {
+            if (MAPS) { const long e = it / T; t = (int)(it - e * T); clip = worklist[1 + e]; }
+            else { const long fr = worklist[1 + it]; clip = fr / T; t = (int)(fr - clip * T); }
+        };
+        // ---- x into the rows: item k's 256 samples, 2 x 16-byte pieces per lane and item for float64 ----
+        constexpr int PP = In<IN>::kPerPiece;
+        constexpr int PIECES = kSpecSeg / PP;                           // 16-byte pieces per segment: 128, 32, 64
+        for (int k0 = 0; k0 < RC_FRAMES; k0 += 4) {
+            // four items at a time keep at most 8 loads in flight per lane
+            constexpr int PER_LANE = (4 * PIECES + 63) / 64;            // pieces per lane for four items: 8, 2, 4
+            u32x4 q[PER_LANE];
+            bool fast[PER_LANE];
+#pragma unroll
+            for (int u = 0; u < PER_LANE; ++u) {
+                const int pc = lane + 64 * u, k = k0 + pc / PIECES, piece = pc % PIECES;
+                const long it = item0 + k;
+                q[u] = u32x4{0u, 0u, 0u, 0u};
+                fast[u] = false;
+                if (it < total) {
+                    long clip; int t;
+                    item_of(it, clip, t);
+                    const long s0 = (long)t * kSpecHop + (long)piece * PP;
+                    if (vec_ok) {
+                        fast[u] = true;
+                        q[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(xin) + (clip * stride + s0) * In<IN>::kBytes));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PER_LANE; ++u) {
+                const int pc = lane + 64 * u, k = k0 + pc / PIECES, piece = pc % PIECES;
+                const long it = item0 + k;
+                double o[PP];
+                if (it < total && !fast[u]) {
+                    long clip; int t;
+                    item_of(it, clip, t);
+                    const void *row = reinterpret_cast<const unsigned char *>(xin) + clip * stride * In<IN>::kBytes;
+                    const long s0 = (long)t * kSpecHop + (long)piece * PP;
+#pragma unroll
+                    for (int jj = 0; jj < PP; ++jj) o[jj] = sample_at<IN>(row, s0 + jj);
+                } else piece_to_f64<IN>(q[u], o);
+                const int n0 = piece * PP;                               // first sample of the piece inside the segment
+                double *dst = rows + k * RC_ROW_LD + (n0 / kCkStrideF64) * RC_CHUNK_LD + n0 % kCkStrideF64;
+#pragma unroll
+                for (int jj = 0; jj < PP; ++jj) dst[jj] = o[jj];
+            }
+        }
+        // ---- restart state of (item f, quarter j) ----
+        double d[8];
+        {
+            const long it = item0 + f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = 0.0;
+            if (it < total) {
+                long clip; int t;
+                item_of(it, clip, t);
+                const d2 *src = reinterpret_cast<const d2 *>(ck + (((long)t * kCkPerSegF64 + j) * n_clips + clip) * 8);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const d2 v2 = src[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
+            }
+        }
+        wave_sync_lds();
+        // ---- the filter over the quarter: classifier.c:427-441 per sample, y over x in place ----
+        {
+            double *row = rows + f * RC_ROW_LD + j * RC_CHUNK_LD;
+#pragma unroll 1
+            for (int h0 = 0; h0 < kCkStrideF64; h0 += 16) {
+                double xr[16];
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) { const d2 v2 = *reinterpret_cast<const d2 *>(row + h0 + u); xr[u] = v2.x; xr[u + 1] = v2.y; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    double v = xr[u];
+#pragma unroll
+                    for (int a = 1; a <= 8; ++a) v = v - c.a[a] * d[a - 1];
+                    double o = c.b[0] * v;
+#pragma unroll
+                    for (int a = 1; a <= 8; ++a)
+                        if (!EVEN_B || a % 2 == 0) o = o + c.b[a] * d[a - 1];
+#pragma unroll
+                    for (int a = 7; a > 0; --a) d[a] = d[a - 1];
+                    d[0] = v;
+                    xr[u] = o;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) *reinterpret_cast<d2 *>(row + h0 + u) = d2{xr[u], xr[u + 1]};
+            }
+        }
+        wave_sync_lds();
+        // ---- transforms: rows 2 turn + half ----
+        for (int turn = 0; turn < RC_FRAMES / 2; ++turn) {
+            const int k = 2 * turn + half;
+            const long it = item0 + k;
+            if (item0 + 2 * turn >= total) break;                        // wave-uniform: neither half has a segment
+            double *row = rows + k * RC_ROW_LD;
+            d2 x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = *reinterpret_cast<const d2 *>(row + r * RC_CHUNK_LD + 2 * i);
+            wave_sync_lds();                                             // the row becomes the transform's second buffer
+            double m[4], m128;
+            fft_frame(x, L, tw, b0, reinterpret_cast<cd *>(row), i, m, m128);
+            if (MAPS) {
+                if (it < total) {
+                    double *out = sxx + it * (long)kSpecBins;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) out[i + 32 * r] = m[r];
+                    if (i == 0) out[128] = m128;
+                }
+            } else {
+                const bool hit = frame_is_loud(m, m128, i, half, U, mid_power, midpoint_db, guard);
+                if (i == 0 && it < total) loud[worklist[1 + it]] = hit;
+            }
+            wave_sync_lds();
+        }
+    }
+}
+
+// =====================================================================================================================================
+// host side
+// =====================================================================================================================================
+namespace {
+
+unsigned short bf16_rne(float v)
+{
+    unsigned u;
+    std::memcpy(&u, &v, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+float bf16_to_float(unsigned short b)
+{
+    const unsigned u = (unsigned)b << 16;
+    float v;
+    std::memcpy(&v, &u, 4);
+    return v;
+}
+
+bool even_taps_only(const IirCoefD &c) { return c.b[1] == 0.0 && c.b[3] == 0.0 && c.b[5] == 0.0 && c.b[7] == 0.0; }
+
+int columns_of(int n) { return n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1; }
+
+template <typename K>
+int resident_blocks(K kernel, int threads, size_t smem)      // per device: the persistent grids walk their work from there
+{
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, threads, smem) != hipSuccess || cus <= 0 || per <= 0) {
+        (void)hipGetLastError();
+        cus = 256; per = 1;
+    }
+    return cus * per;
+}
+
+// alignment the 16-byte loads need: every row start and every piece on 16 bytes
+template <int IN>
+bool rows_vec_ok(const void *x, long stride)
+{
+    return reinterpret_cast<uintptr_t>(x) % 16 == 0 && (stride * In<IN>::kBytes) % 16 == 0;
+}
+
+}  // namespace
+
+bool build_screen_tables_f64(const SpecTablesD &spec, int fs, ScreenTablesD &t)
+{
+    // the taper is 32 samples at either end (classifier.c:504-521 with alpha 0.25: n <= 32 and n >= 224) and the window is exactly 1 in
+    // between: the taps wave takes the squares of the first / last two tiles from the table and 1 elsewhere
+    for (int n = kSpecSeg - kSpecHop; n < kSpecHop; ++n)
+        if (spec.win[n] != 1.0) return false;
+    double w2 = 0.0;
+    for (int n = 0; n < kSpecSeg; ++n) w2 += spec.win[n] * spec.win[n];
+    if (std::fabs(w2 * fs - spec.U) > 1e-9 * spec.U) return false;
+    t.win2_sum = (float)(w2 * (1.0 + 1e-6));
+    for (int n = 0; n < kSpecSeg - kSpecHop; ++n) {
+        t.win2_in[n] = (float)(spec.win[n] * spec.win[n] * (1.0 + 1e-6));                 // (rounded up: they enter upper bounds only)
+        t.win2_out[n] = (float)(spec.win[kSpecHop + n] * spec.win[kSpecHop + n] * (1.0 + 1e-6));
+    }
+    const long double PI2 = 6.283185307179586476925286766559005768L;
+    auto row_value = [&](int row, int n) -> double {                     // table row -> (bin, part): rows 2 q, 2 q + 1 = re, im of bin q; row 1 = bin 128
+        const int bin = row == 1 ? 128 : row >> 1;
+        const long double a = PI2 * (long double)((bin * n) & 255) / 256.0L;
+        return spec.win[n] * (double)((row & 1) && row != 1 ? -sinl(a) : cosl(a));
+    };
+    for (int ks = 0; ks < 16; ++ks)
+        for (int mb = 0; mb < 4; ++mb)
+            for (int l = 0; l < 64; ++l)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const double v = row_value(32 * mb + (l & 31), 16 * ks + 8 * (l >> 5) + jj);
+                    const unsigned short hi = bf16_rne((float)v);
+                    const unsigned short lo = bf16_rne((float)(v - (double)bf16_to_float(hi)));
+                    t.a_tab[ks][mb][0][l][jj] = hi;
+                    t.a_tab[ks][mb][1][l][jj] = lo;
+                }
+    for (int bin = 0; bin < 64; ++bin) {
+        long double re = 0, im = 0;
+        for (int n = 0; n < kSpecSeg; ++n) {
+            const long double a = PI2 * (long double)((bin * n) & 255) / 256.0L;
+            re += spec.win[n] * cosl(a);
+            im -= spec.win[n] * sinl(a);
+        }
+        t.what_re[bin] = (float)re;
+        t.what_im[bin] = (float)im;
+    }
+    long double s128 = 0;
+    for (int n = 0; n < kSpecSeg; ++n) s128 += (n & 1) ? -spec.win[n] : spec.win[n];
+    t.what128 = (float)s128;
+    return true;
+}
+
+int f64_screen_blocks_per_pass()
+{
+    // the blocks of a pass must all be resident (every block runs the whole clip length); 64 clips per block
+    static int per_device[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+    if (per_device[dev] == 0) per_device[dev] = resident_blocks(iir2_screen_f64_kernel<0, true, true>, SC_THREADS, 0);
+    return per_device[dev];
+}
+
+template <int IN>
+static hipError_t launch_screen_in(const void *x, long n_clips, int n, long stride, const IirCoefD &c_bp, const IirCoefD &c_mp, double *ck_bp,
+                                   double *ck_mp, const ScreenTablesD *tables, double U, double midpoint_db, double guard, int *loud, int *want,
+                                   hipStream_t stream)
+{
+    const int T = columns_of(n);
+    const int blocks = (int)((n_clips + 63) / 64);
+    const double mid_power = 1e-12 * std::pow(10.0, midpoint_db / 10.0);
+    const float thr_u = (float)(mid_power * U);
+    const float g = (float)std::min(std::max(guard, 0.0), 0.999);
+    const bool vec = rows_vec_ok<IN>(x, stride), even = even_taps_only(c_mp);
+#define DSP_SC_LAUNCH(E, V)                                                                                                                      \
+    hipLaunchKernelGGL((iir2_screen_f64_kernel<IN, E, V>), dim3(blocks), dim3(SC_THREADS), 0, stream, x, n_clips, n, stride, T, c_bp, c_mp, ck_bp, \
+                       ck_mp, tables, loud, want, thr_u, g)
+    if (even && vec) DSP_SC_LAUNCH(true, true);
+    else if (even) DSP_SC_LAUNCH(true, false);
+    else if (vec) DSP_SC_LAUNCH(false, true);
+    else DSP_SC_LAUNCH(false, false);
+#undef DSP_SC_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_iir2_screen_f64(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const IirCoefD &c_mp,
+                                  double *ck_bp, double *ck_mp, const ScreenTablesD *tables, double U, double midpoint_db, double guard,
+                                  int *loud, int *want, hipStream_t stream)
+{
+    const int T = columns_of(n);
+    if (n_clips <= 0 || T <= 0) return hipSuccess;
+    if (n_clips * (long)T >= (1L << 31)) return hipErrorInvalidValue;                 // frame numbers are ints
+    if ((n_clips + 63) / 64 > f64_screen_blocks_per_pass()) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(want, 0, sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    switch (in_kind) {
+    case 0: return launch_screen_in<0>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, stream);
+    case 1: return launch_screen_in<1>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, stream);
+    case 2: return launch_screen_in<2>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, stream);
+    case 3: return launch_screen_in<3>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+namespace {
+
+constexpr size_t kRcSmem = (size_t)4 * RC_FRAMES * RC_ROW_LD * sizeof(double) + (size_t)8 * kPingCd * sizeof(cd) + sizeof(FftTwiddles);
+
+template <bool MAPS, int IN, bool EVEN_B>
+hipError_t launch_rc(const void *x, long n_clips, int n, long stride, const IirCoefD &c, const double *ck, const SpecTablesD *tab, const int *worklist,
+                     double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream)
+{
+    auto kernel = spec_f64_from_ckpt_kernel<MAPS, IN, EVEN_B>;
+    static bool attr_set[64] = {false};
+    static int resident[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRcSmem);
+        if (e != hipSuccess) return e;
+        resident[dev] = resident_blocks(kernel, 256, kRcSmem);
+        attr_set[dev] = true;
+    }
+    const int T = columns_of(n);
+    const long max_items = n_clips * (long)T;                            // the bound: the list's count is read on the device
+    const long blocks = std::min<long>((max_items + 4 * RC_FRAMES - 1) / (4 * RC_FRAMES), resident[dev]);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), kRcSmem, stream, x, n_clips, n, stride, T, c, ck, tab, worklist, sxx, loud, mid_power,
+                       midpoint_db, guard, (int)rows_vec_ok<IN>(x, stride));
+    return hipGetLastError();
+}
+
+template <bool MAPS, int IN>
+hipError_t launch_rc_b(const void *x, long n_clips, int n, long stride, const IirCoefD &c, const double *ck, const SpecTablesD *tab, const int *worklist,
+                       double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream)
+{
+    return even_taps_only(c) ? launch_rc<MAPS, IN, true>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream)
+                             : launch_rc<MAPS, IN, false>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream);
+}
+
+template <bool MAPS>
+hipError_t launch_rc_k(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c, const double *ck, const SpecTablesD *tab,
+                       const int *worklist, double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream)
+{
+    switch (in_kind) {
+    case 0: return launch_rc_b<MAPS, 0>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream);
+    case 1: return launch_rc_b<MAPS, 1>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream);
+    case 2: return launch_rc_b<MAPS, 2>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream);
+    case 3: return launch_rc_b<MAPS, 3>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_spec_f64_recheck(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_mp, const double *ck_mp,
+                                   const SpecTablesD *tables, const int *want, double midpoint_db, double guard, int *loud, hipStream_t stream)
+{
+    if (n_clips <= 0 || columns_of(n) <= 0) return hipSuccess;
+    const double mid_power = 1e-12 * std::pow(10.0, midpoint_db / 10.0);
+    return launch_rc_k<false>(x, in_kind, n_clips, n, stride, c_mp, ck_mp, tables, want, nullptr, loud, mid_power, midpoint_db, guard, stream);
+}
+
+hipError_t launch_spec_f64_listed_from_ckpt(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const double *ck_bp,
+                                            const SpecTablesD *tables, const int *hits, double *sxx, hipStream_t stream)
+{
+    if (n_clips <= 0 || columns_of(n) <= 0) return hipSuccess;
+    return launch_rc_k<true>(x, in_kind, n_clips, n, stride, c_bp, ck_bp, tables, hits, sxx, nullptr, 0.0, 0.0, 0.0, stream);
+}
+
+}  // namespace dsp

@@ -28,80 +28,26 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include "classify_f64_device.hpp"
 #include "classify_kernels.hpp"
 
 namespace dsp {
+
+using namespace f64dev;
 
 namespace {
 
 constexpr int kMaxColsF64 = 960;            // >= capi.cpp's kMaxSpecColumns (957): a flag per spectrogram column
 constexpr int kWinCells = 48 * 32;          // band window staged in LDS: the widest band has 41 rows (2500-5000 Hz) x 27 columns (0.36 s at 14 ms per column)
-#ifndef DSP_F64_FFT_AHEAD
-#define DSP_F64_FFT_AHEAD 1
-#endif
-constexpr int kFftAhead = DSP_F64_FFT_AHEAD;  // turns (two frames each) of loads a transform wave keeps in flight
 constexpr int kTailLoads = 8;               // map cells a thread has in flight while it scans a map (one at a time left the scan bound by the load latency)
-
-__device__ __forceinline__ double to_db64(double s) { return 10 * log10(s / 1e-12); }      // classifier.c:113, :688
-
-__device__ __forceinline__ void wave_sync_lds()
-{   // a wave's DS instructions complete in order: ordering the compiler is all a write -> read of another lane's data needs
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// find_midpoints' "10 log10(s / 1e-12) > midpoint_db" (:688-745).  A cell well above / below the threshold's power mid_power =
-// 1e-12 * 10^(midpoint_db / 10) is decided by a comparison; within 1e-9 relative of it (4e-9 dB, against the ~1e-14 dB the
-// expression's roundings can move) the reference's expression decides
-__device__ __forceinline__ bool is_loud(double s, double mid_power, double midpoint_db)
-{
-    return s > mid_power * (1.0 + 1e-9) || (s >= mid_power * (1.0 - 1e-9) && s > 0 && to_db64(s) > midpoint_db);
-}
-
-// a double from another lane by a DPP move of its two words (VALU, not the LDS crossbar a __shfl_xor takes)
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-// the sum of v over the 32 lanes of this lane's half-wave, in every lane: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
-// (after each step the lanes of a group hold the group's sum, so the mirrored lane's value is the other group's), then the
-// neighbouring row through v_permlane16_swap
-__device__ __forceinline__ double half_wave_sum(double v)
-{
-    v += dpp_f64<0xB1>(v);
-    v += dpp_f64<0x4E>(v);
-    v += dpp_f64<0x141>(v);
-    v += dpp_f64<0x140>(v);
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
-}
-
-struct cd { double re, im; };
-__device__ __forceinline__ cd operator+(cd a, cd b) { return {a.re + b.re, a.im + b.im}; }
-__device__ __forceinline__ cd operator-(cd a, cd b) { return {a.re - b.re, a.im - b.im}; }
-__device__ __forceinline__ cd cmul(cd a, double wr, double wi) { return {a.re * wr - a.im * wi, a.re * wi + a.im * wr}; }
 
 }  // namespace
 
-// compute_spectrogram (classifier.c:448-592) for the batch path: a 256-point real transform per frame as a 128-point complex
-// Stockham FFT through LDS, TWO frames per wavefront.  32 lanes own a frame; lane i loads samples 2 i + 64 r, 2 i + 64 r + 1, r < 4
-// (four 16-byte loads per lane, 512 contiguous bytes per load and frame, the next turn's loads in flight during this one's
-// transform; kFftAhead turns ahead), the mean is a reduction over the 32 lanes, the detrended windowed samples (window in registers, host-built in the
-// reference's expressions) are packed as z[n] = x[2 n] + i x[2 n + 1], so that lane i holds z[i + 32 r].  128 = 4 x 4 x 4 x 2: three
-// radix-4 stages (p = 1, 4, 16) and one radix-2 stage (p = 64), ping-pong through 4 KB of LDS per frame, twiddles from a
-// block-shared LDS table of W256^m (in registers they cost 48 VGPRs and a wave per SIMD).  A stage of radix R with p = the product
-// of the radices before it, thread i of N / R: k = i mod p, inputs x[i + r N / R] times exp(-2 pi i r k / (p R)), an R-point DFT,
-// outputs y[(i - k) R + k + r p].  The real spectrum X[k] = E[k] + W256^k O[k] is taken from Z[k] and conj(Z[128 - k]), lane i
-// takes bins i, i + 32, i + 64, i + 96, and |X|^2 / U (doubled for 0 < k < 128) is the PSD cell of bin k (:574-592).
-// DSP_F64_FFT_DIAG = 1 / 2: timing-only builds (no loads / loads only) behind the record in profiles/r03_classify_f64_session2.txt.
-// (First form of this round: one frame per wave, radix 2, seven stages of two points per lane -- 60 % of a CU's LDS bandwidth and
-// every frame a chain of seven dependent LDS round trips: 2.6 ms per 3.5 M frames against 2.0 ms.)
+// compute_spectrogram (classifier.c:448-592) of MATERIALISED filter outputs (the yardstick pipeline, DSP_AMD_F64_PIPELINE=materialize;
+// the default pipeline transforms segments recomputed from checkpoints, classify_f64_ckpt_kernels.hip, with the same fft_frame):
+// TWO frames per wavefront, 32 lanes own a frame; lane i loads samples 2 i + 64 r, 2 i + 64 r + 1, r < 4 (four 16-byte loads per
+// lane, 512 contiguous bytes per load and frame, the next turn's loads in flight during this one's transform).  Measured history of
+// this kernel (radix 2 -> radix 4, twiddle placement, padded stage image, DPP mean): profiles/r03_classify_f64_session2.txt.
 //   MAPS = false  every frame of every clip: loud[frame] = one of its 129 cells is above the midpoint threshold (no map leaves the kernel)
 //   MAPS = true   the frames of the clips on the work list hits (hits[0] entries, clip numbers from hits[1]): sxx[entry][t][k] = U * PSD
 template <bool MAPS>
@@ -110,45 +56,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                                                                    double *__restrict__ sxx, int *__restrict__ loud, double mid_power, double midpoint_db, double guard)
 {
     const long total = (MAPS ? (long)hits[0] : n_clips) * T;
-    // [wave][half]: ping (128 + 32: the image stage p = 1 writes is padded by one element in four, P1 below) and pong (128)
-    __shared__ __attribute__((aligned(16))) cd buf0[4][2][kSpecSeg / 2 + 32], buf1[4][2][kSpecSeg / 2];
+    __shared__ __attribute__((aligned(16))) cd buf0[4][2][kPingCd], buf1[4][2][kPongCd];       // [wave][half]
+    __shared__ __attribute__((aligned(16))) FftTwiddles tw;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, half = lane >> 5, i = lane & 31;
     cd *b0 = buf0[wib][half], *b1 = buf1[wib][half];
-    // Twiddles: block-shared LDS tables laid out so that the lanes of a read are contiguous (a lane keeping its twelve twiddles in
-    // registers cost 48 VGPRs; one table of W256^m indexed by m put the 16 lanes of a read on one or two banks):
-    //   w16[r - 1][k] = W64^(k r), k < 16 (stage p = 16; stage p = 4 reads its W16^(k r) = W64^(4 k r) at [r - 1][4 k]: four addresses
-    //   on four different bank groups)          w256[k] = W256^k, k < 128 (bins; the radix-2 stage reads W128^b at [2 b])
-    // 39.8 KB of LDS per block and <= 128 VGPRs: four blocks per CU, four waves per SIMD.
-    __shared__ __attribute__((aligned(16))) cd w16[3][16], w256[kSpecSeg / 2];
-    auto tw = [&](int m) {                                               // W256^m from the half-circle table
-        m &= 255;
-        const double sg = (m & 128) ? -1.0 : 1.0;
-        return cd{sg * tab->w_re[m & 127], sg * tab->w_im[m & 127]};
-    };
-    {
-        const int n = threadIdx.x;
-        if (n < 48) w16[n >> 4][n & 15] = tw(4 * (n & 15) * ((n >> 4) + 1));
-        if (n < 128) w256[n] = tw(n);
-    }
+    fill_twiddles(tw, tab, threadIdx.x);
     __syncthreads();
-#ifndef DSP_F64_FFT_TW_REGS
-#define DSP_F64_FFT_TW_REGS 1
-#endif
-    // DSP_F64_FFT_TW_REGS = 1: the twiddles of the three butterfly stages in registers (32 VGPRs: three waves per SIMD instead of four,
-    // which measure the same) -- eight LDS reads per turn less in a kernel the LDS pipe bounds; the bins' W256^k stay in the table
-    cd t4[3], t16[3], t2[2];
-#pragma unroll
-    for (int r = 1; r < 4; ++r) { t4[r - 1] = w16[r - 1][4 * (i & 3)]; t16[r - 1] = w16[r - 1][i & 15]; }
-    t2[0] = w256[2 * i]; t2[1] = w256[2 * i + 64];
-    (void)t4; (void)t16; (void)t2;
-    double win[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { win[2 * r] = tab->win[2 * i + 64 * r]; win[2 * r + 1] = tab->win[2 * i + 64 * r + 1]; }
-    const int j4 = ((i - (i & 3)) << 2) + (i & 3), j16 = ((i - (i & 15)) << 2) + (i & 15);
-    const double U = tab->U, mid_power_u = mid_power * U;
-    (void)mid_power_u;
+    FftLane L;
+    fft_lane_init(L, tw, tab, i);
+    const double U = tab->U;
     const long wave = (long)blockIdx.x * 4 + wib, n_waves = (long)gridDim.x * 4;
-    typedef double d2 __attribute__((ext_vector_type(2)));
     // this half's frame f = 2 wave + half, then + 2 n_waves per turn; (entry, column) kept incrementally: one division per kernel
     long f = 2 * wave + half;
     long e = f / T;
@@ -159,8 +76,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
         const long clip = MAPS ? (long)hits[1 + ee] : ee;
         return y + clip * stride + (long)tt * kSpecHop + 2 * i;
     };
-    // kFftAhead turns of look-ahead (1, 2 and 3 measure the same within 1 %: profiles/r03_classify_f64_session2.txt)
-    d2 q[kFftAhead][4];
+    d2 q[4];
     auto advance = [&](long &ee, int &tt) {
         ee += step_e; tt += step_t;
         if (tt >= T) { tt -= T; ++ee; }
@@ -168,109 +84,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     long ea = e;                                                         // (entry, column) of the next frame to request
     int ta = t;
 #pragma unroll
-    for (int j = 0; j < kFftAhead; ++j) {
+    for (int r = 0; r < 4; ++r) q[r] = d2{0.0, 0.0};
+    if (f < total) {
+        const double *src = src_of(ea, ta);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) q[j][r] = d2{0.0, 0.0};
-#if defined(DSP_F64_FFT_DIAG) && DSP_F64_FFT_DIAG == 1      // timing-only probe: no loads
-        if (MAPS)
-#endif
-        if (f + j * step < total) {
-            const double *src = src_of(ea, ta);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) q[j][r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
-        }
-        advance(ea, ta);
+        for (int r = 0; r < 4; ++r) q[r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
     }
-    auto fft4 = [](cd &u0, cd &u1, cd &u2, cd &u3) {
-        const cd v0 = u0 + u2, v1 = u0 - u2, v2 = u1 + u3, d = u1 - u3;
-        const cd v3 = {d.im, -d.re};                                     // (u1 - u3) (-i)
-        u0 = v0 + v2; u1 = v1 + v3; u2 = v0 - v2; u3 = v1 - v3;
-    };
+    advance(ea, ta);
     for (long f0 = 2 * wave; f0 < total; f0 += step) {                    // wave-uniform: the wave runs while its first frame exists
         const bool live = f < total;
         d2 x[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = q[0][r];
-#pragma unroll
-        for (int j = 0; j + 1 < kFftAhead; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) q[j][r] = q[j + 1][r];
-#if defined(DSP_F64_FFT_DIAG) && DSP_F64_FFT_DIAG == 1
-        if (MAPS)
-#endif
-        if (f + kFftAhead * step < total) {
+        for (int r = 0; r < 4; ++r) x[r] = q[r];
+        if (f + step < total) {
             const double *src = src_of(ea, ta);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) q[kFftAhead - 1][r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
+            for (int r = 0; r < 4; ++r) q[r] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + 64 * r));
         }
-#if defined(DSP_F64_FFT_DIAG) && DSP_F64_FFT_DIAG == 2      // timing-only probe: loads only, no transform
-        if (!MAPS) {
-            const double sx = x[0].x + x[1].x + x[2].x + x[3].x;
-            if (i == 0 && live) loud[f] = sx == 123.456;
-            f += step; advance(ea, ta);
-            continue;
-        }
-#endif
-        const double sum = half_wave_sum(((x[0].x + x[0].y) + (x[1].x + x[1].y)) + ((x[2].x + x[2].y) + (x[3].x + x[3].y)));
-        const double mean = sum / (double)kSpecSeg;                      // classifier.c:551-561 detrend
-        cd u[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = {(x[r].x - mean) * win[2 * r], (x[r].y - mean) * win[2 * r + 1]};
-        // stage p = 1
-        fft4(u[0], u[1], u[2], u[3]);
-        // (written at P1(n) = n + (n >> 2): lane i's four outputs start 80 bytes after lane i - 1's, so that the eight lanes a
-        // ds_write_b128 serves together fall on all 32 banks -- at 64 bytes they shared them four ways: 32 LDS cycles per store
-        // instead of 13, and the stores of this stage and the next were half of the kernel's LDS time)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b0[5 * i + r] = u[r];
-        wave_sync_lds();
-        // stage p = 4
-#pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = b0[i + (i >> 2) + 40 * r];     // P1(i + 32 r)
-#pragma unroll
-        for (int r = 1; r < 4; ++r) { const cd w = DSP_F64_FFT_TW_REGS ? t4[r - 1] : w16[r - 1][4 * (i & 3)]; u[r] = cmul(u[r], w.re, w.im); }
-        fft4(u[0], u[1], u[2], u[3]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b1[j4 + 4 * r] = u[r];
-        wave_sync_lds();
-        // stage p = 16
-#pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = b1[i + 32 * r];
-#pragma unroll
-        for (int r = 1; r < 4; ++r) { const cd w = DSP_F64_FFT_TW_REGS ? t16[r - 1] : w16[r - 1][i & 15]; u[r] = cmul(u[r], w.re, w.im); }
-        fft4(u[0], u[1], u[2], u[3]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b0[j16 + 16 * r] = u[r];
-        wave_sync_lds();
-        // stage p = 64, radix 2: butterflies b = i and i + 32 on (x[b], x[b + 64])
-#pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = b0[i + 32 * r];
-        {
-            const cd w0 = DSP_F64_FFT_TW_REGS ? t2[0] : w256[2 * i], w1 = DSP_F64_FFT_TW_REGS ? t2[1] : w256[2 * i + 64];
-            const cd a0 = cmul(u[2], w0.re, w0.im), a1 = cmul(u[3], w1.re, w1.im);
-            b1[i] = u[0] + a0; b1[i + 64] = u[0] - a0;
-            b1[i + 32] = u[1] + a1; b1[i + 96] = u[1] - a1;
-        }
-        wave_sync_lds();
-        // Z in natural order in b1.  X[k] = (A + B) / 2 + W256^k (A - B) / (2 i), A = Z[k], B = conj(Z[128 - k]); the cell is
-        // |X[k]|^2 (doubled for 0 < k < 128) over U.  The division is left to whoever needs the cell's value: x / U is monotonic in x
-        // and commutes with the doubling, so the map kernel stores U * PSD and the band kernel divides the cells it uses, and the
-        // flags compare against U * threshold unless the cell is within `guard` of it
-        double m[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = i + 32 * r;
-            const cd A = b1[k], Zb = b1[(128 - k) & 127];
-            const cd e2 = {A.re + Zb.re, A.im - Zb.im}, d = {A.re - Zb.re, A.im + Zb.im};
-            const cd o2 = {d.im, -d.re};
-            const cd w = w256[k];
-            const cd x2 = e2 + cmul(o2, w.re, w.im);
-            const double re = 0.5 * x2.re, im = 0.5 * x2.im;
-            m[r] = (re * re + im * im) * ((r == 0 && i == 0) ? 1.0 : 2.0);
-        }
-        const cd Z0 = b1[0];
-        const double r128 = Z0.re - Z0.im;                               // X[128] = E[0] - O[0]
-        const double m128 = r128 * r128;
+        double m[4], m128;
+        fft_frame(x, L, tw, b0, b1, i, m, m128);
         if (MAPS) {
             if (live) {
                 double *out = sxx + f * (long)kSpecBins;
@@ -279,22 +111,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                 if (i == 0) out[128] = m128;
             }
         } else {
-            // above / below the band around U x threshold: decided; inside it (rare): the reference's expression, evaluated in
-            // ONE rolled loop (inlined per cell, the float64 log10 cost the kernel 40 VGPRs)
-            const double thr_hi = mid_power_u * (1.0 + guard), thr_lo = mid_power_u * (1.0 - guard);
-            const double c4 = i == 0 ? m128 : 0.0;
-            bool any = m[0] > thr_hi || m[1] > thr_hi || m[2] > thr_hi || m[3] > thr_hi || c4 > thr_hi;
-            const bool near = (m[0] >= thr_lo && m[0] <= thr_hi) || (m[1] >= thr_lo && m[1] <= thr_hi) || (m[2] >= thr_lo && m[2] <= thr_hi) ||
-                              (m[3] >= thr_lo && m[3] <= thr_hi) || (c4 >= thr_lo && c4 <= thr_hi);
-            if (__ballot(near) != 0) {
-#pragma unroll 1
-                for (int c = 0; c < 5; ++c) {
-                    const double v = c == 0 ? m[0] : c == 1 ? m[1] : c == 2 ? m[2] : c == 3 ? m[3] : c4;
-                    if (v >= thr_lo && v <= thr_hi && is_loud(v / U, mid_power, midpoint_db)) any = true;
-                }
-            }
-            const unsigned long long bal = __ballot(any);
-            const bool hit = ((half ? (bal >> 32) : bal) & 0xffffffffull) != 0;
+            const bool hit = frame_is_loud(m, m128, i, half, U, mid_power, midpoint_db, guard);
             if (i == 0 && live) loud[f] = hit;
         }
         wave_sync_lds();                                                 // the next turn's stages overwrite b0 / b1
@@ -324,22 +141,36 @@ void build_spec_tables_f64(int fs, SpecTablesD &t)
     }
 }
 
+double f64_threshold_guard()
+{
+    const char *ge = std::getenv("DSP_AMD_F64_GUARD");
+    return ge && std::atof(ge) >= 2e-9 && std::atof(ge) < 1.0 ? std::atof(ge) : 2e-9;
+}
+
 namespace {
 
-template <bool MAPS>
-int fft_resident_blocks()                     // blocks that fit the GPU at once: the waves walk the frames from there
+// blocks that fit the GPU at once (the waves walk the frames from there), per device: a process may drive several GPUs
+template <typename K>
+int resident_blocks_of(K kernel, int (&cache)[64])
 {
-    static int resident = 0;
-    if (resident == 0) {
-        int dev = 0, cus = 0, per = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, spectrogram_f64_fft_kernel<MAPS>, 256, 0) != hipSuccess || cus <= 0 || per <= 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 512; }
+    if (cache[dev] == 0) {
+        int cus = 0, per = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, 256, 0) != hipSuccess || cus <= 0 || per <= 0) {
             (void)hipGetLastError();
             cus = 256; per = 2;
         }
-        resident = cus * per;
+        cache[dev] = cus * per;
     }
-    return resident;
+    return cache[dev];
+}
+template <bool MAPS>
+int fft_resident_blocks()
+{
+    static int cache[64] = {0};
+    return resident_blocks_of(spectrogram_f64_fft_kernel<MAPS>, cache);
 }
 
 int columns_of(int n) { return n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1; }
@@ -354,10 +185,7 @@ hipError_t launch_spectrogram_f64_flags(const double *y, long n_clips, int n, lo
     if (stride % 2 != 0 || reinterpret_cast<uintptr_t>(y) % 16 != 0) return hipErrorInvalidValue;
     const long blocks = std::min<long>((n_clips * T + 7) / 8, fft_resident_blocks<false>());
     const double mid_power = 1e-12 * std::pow(10.0, midpoint_db / 10.0);
-    // DSP_AMD_F64_GUARD: the half-width of the band around the threshold inside which the reference's expression decides (default
-    // 2e-9; the tests widen it to push every cell through that path)
-    const char *ge = std::getenv("DSP_AMD_F64_GUARD");
-    const double guard = ge && std::atof(ge) >= 2e-9 && std::atof(ge) < 1.0 ? std::atof(ge) : 2e-9;
+    const double guard = f64_threshold_guard();
     hipLaunchKernelGGL(spectrogram_f64_fft_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, y, n_clips, T, stride, tables,
                        (const int *)nullptr, (double *)nullptr, loud, mid_power, midpoint_db, guard);
     return hipGetLastError();
@@ -679,16 +507,8 @@ hipError_t launch_classify_f64_bands(const double *sxx, const int *hits, long n_
     const int T = columns_of(n);
     if (n_clips <= 0) return hipSuccess;
     if (T <= 0 || T > kMaxColsF64) return hipErrorInvalidValue;
-    static int resident = 0;
-    if (resident == 0) {
-        int dev = 0, cus = 0, per = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, classify_f64_bands_kernel, 256, 0) != hipSuccess || cus <= 0 || per <= 0) {
-            (void)hipGetLastError();
-            cus = 256; per = 2;
-        }
-        resident = cus * per;
-    }
+    static int cache[64] = {0};
+    const int resident = resident_blocks_of(classify_f64_bands_kernel, cache);
     const long blocks = std::min<long>(n_clips, 4L * resident);              // the bound: the list's count is read on the device
     hipLaunchKernelGGL(classify_f64_bands_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, sxx, hits, T, fs, U, rule, band_rows(fs), mids, n_mids, labels, trace);
     return hipGetLastError();

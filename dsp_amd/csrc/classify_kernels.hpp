@@ -178,6 +178,39 @@ hipError_t launch_classify_f64_bands(const double *sxx, const int *hits, long n_
 hipError_t launch_classify_f64_tail(const double *sxx_bp, const double *sxx_mp, long n_clips, int n, int fs, const ClassifyRuleD &rule,
                                     int *labels, ClassifyTraceD *trace, hipStream_t stream);
 
+// ---- the same classifier without materialised filter outputs (classify_f64_ckpt_kernels.hip; the default pipeline) ----
+// Restart states of a Butterworth filter: its delay line v[n-1 .. n-8] at offsets 0, 64, 128, 192 of every spectrogram segment,
+// ck[t][quarter][clip][8] doubles (the clip index innermost among the rows: a wavefront of 64 clips stores 4 KB contiguous).
+constexpr int kCkStrideF64 = 64, kCkPerSegF64 = 4;
+// Device-resident constants of the screening pass: the windowed DFT matrix of bins 0 .. 63 and 128 as two bf16 tables in MFMA A-fragment
+// order [k-step][32-row block][hi / lo][lane][8] (rows 2 q, 2 q + 1 = real, imaginary part of bin q; row 1 = bin 128), the window's own
+// transform at those bins, the squared taper and sum w^2 (rounded up: they enter upper bounds).
+struct ScreenTablesD {
+    unsigned short a_tab[16][4][2][64][8];
+    float what_re[64], what_im[64], what128;
+    float win2_in[kSpecSeg - kSpecHop], win2_out[kSpecSeg - kSpecHop], win2_sum;
+};
+bool build_screen_tables_f64(const SpecTablesD &spec, int fs, ScreenTablesD &t);      // false: the window is not 1 between its tapers
+// Input kinds of the float64 classifier's kernels: 0 = float64 samples, 1 = int16 mono (s / 32768), 2 = interleaved int16 stereo, channel 0,
+// 3 = interleaved int16 stereo, (L + R) / 65536.  stride counts samples (per channel).
+// One pass over x: restart states of both filters (ck_bp, ck_mp: [T][4][n_clips][8]) and loud[c][t] = 0 quiet / 1 loud / 2 undecided for every
+// segment of the 1000-3000 Hz output; the undecided ones also on the work list want (want[0] = count, then frame numbers c * T + t;
+// 1 + n_clips * T ints).  guard: the relative half-width (in power) of the band around the threshold that is always left to the float64
+// transform (>= 2e-9).  At most f64_screen_blocks_per_pass() * 64 clips per launch (every block must be resident).
+int f64_screen_blocks_per_pass();
+hipError_t launch_iir2_screen_f64(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const IirCoefD &c_mp,
+                                  double *ck_bp, double *ck_mp, const ScreenTablesD *tables, double U, double midpoint_db, double guard,
+                                  int *loud, int *want, hipStream_t stream);
+// the float64 verdict on the listed (undecided) segments, recomputed from ck_mp: loud[frame] = 0 / 1
+hipError_t launch_spec_f64_recheck(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_mp, const double *ck_mp,
+                                   const SpecTablesD *tables, const int *want, double midpoint_db, double guard, int *loud, hipStream_t stream);
+// sxx[entry][t][129] = U * PSD of the 3000-7500 Hz output of the clips on the work list hits, recomputed from ck_bp
+hipError_t launch_spec_f64_listed_from_ckpt(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const double *ck_bp,
+                                            const SpecTablesD *tables, const int *hits, double *sxx, hipStream_t stream);
+// DSP_AMD_F64_GUARD (read per call; tests): the half-width of the band around the threshold inside which the reference's own expression
+// decides, default 2e-9
+double f64_threshold_guard();
+
 void build_spec_tables(int fs, SpecTables &t);
 
 }  // namespace dsp

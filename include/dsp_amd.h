@@ -233,10 +233,19 @@ int dsp_classify_batch_device_cfg(const dsp_classify_config *cfg, const float *d
  * band sums and rule in double on the GPU.  Thresholds are doubles as in the file; cfg NULL = its own
  * (0.70 / 0.85 :141-142, 45 dB :660, middle < 75 && above > 300 && below > 100 :184).  fs is 16000 (the rate butter_bandpass has
  * coefficients for).  The reference transforms with FFTW (unvendored): the spectrogram is a float64 transform of its own (a
- * 128-point complex FFT per wavefront; DSP_AMD_F64_DFT=1: the direct DFT of dsp_compute_spectrogram_f64), so parity is by
- * tolerance (labels and midpoints equal, band sums to ~1e-9 relative).  The library keeps a grow-only workspace (330 KB per
- * one-second clip of the largest pass, passes of at most 65 536 clips; DSP_AMD_F64_SUB_BATCH lowers that).
- * _host: host pointers; _device: HBM pointers (d_trace may be NULL), synchronised before returning.                        */
+ * 128-point complex FFT per half-wavefront; DSP_AMD_F64_DFT=1: the direct DFT of dsp_compute_spectrogram_f64), so parity is by
+ * tolerance (labels and midpoints equal, band sums to ~1e-9 relative).  Neither filtered signal is written to HBM: one pass keeps the
+ * filters' restart states (36 KB per one-second clip) and settles the loud time bins with a bounded screening transform; only
+ * undecided segments and the clips with midpoints are recomputed and transformed in float64.  The library keeps one grow-only workspace
+ * PER DEVICE (112 KB per one-second clip of the largest pass, passes of at most 49 152 clips on 256 CUs; DSP_AMD_F64_SUB_BATCH lowers
+ * that; dsp_classify_release_f64 frees it).
+ * _host: host pointers, blocking.  _device: HBM pointers (d_trace may be NULL), STREAM-ORDERED: the call returns once its work is
+ * enqueued on `stream`; results are valid when the stream reaches that point.  Calls on one device share its workspace and are
+ * ordered one behind the other (whatever their streams); calls on different devices share nothing.
+ * _pcm16_: int16 PCM, mono or interleaved stereo (channel 0, or the average of the two channels), converted in the kernels' loads
+ * exactly like the reference's readers: s / 32768.0 (classifier.c:55-59, channel 0 of a stereo file :286-297; sync/sync.cpp:237-242;
+ * the average as main_test.c:205-217) -- bit-identical to the float64 entry points on the same samples, at a quarter of the input bytes.
+ * n and stride count samples PER CHANNEL.                                                                                  */
 typedef struct dsp_classify_config_f64 {
     double keep_lo, keep_hi, midpoint_db, middle_max, above_min, below_min;
 } dsp_classify_config_f64;
@@ -250,6 +259,15 @@ int dsp_classify_batch_host_f64(const dsp_classify_config_f64 *cfg, const double
                                 int *labels, dsp_classify_trace_f64 *trace);
 int dsp_classify_batch_device_f64(const dsp_classify_config_f64 *cfg, const double *d_signal, long n_clips, int n, long stride,
                                   int *d_labels, dsp_classify_trace_f64 *d_trace, void *stream);
+int dsp_classify_batch_pcm16_host_f64(const dsp_classify_config_f64 *cfg, const int16_t *pcm, long n_clips, int n, long stride, int channels,
+                                      int stereo_mode, int *labels, dsp_classify_trace_f64 *trace);
+int dsp_classify_batch_pcm16_device_f64(const dsp_classify_config_f64 *cfg, const int16_t *d_pcm, long n_clips, int n, long stride, int channels,
+                                        int stereo_mode, int *d_labels, dsp_classify_trace_f64 *d_trace, void *stream);
+/* What the LAST pass of the float64 classifier on `device` did (blocks until it has finished): spectrogram segments of the
+ * 1000-3000 Hz output, how many of them the screening left to the float64 transform, clips that had midpoints.  Any pointer may be NULL. */
+int dsp_classify_stats_f64(int device, long *segments, long *undecided, long *listed_clips);
+/* frees the float64 classifier's workspace on `device` (-1: on every device) after its pending work has finished */
+int dsp_classify_release_f64(int device);
 
 /* sum_intense (sync/lib/classifier.h:17, classifier.cpp:370-431) on a flat matrix: db[freq_bins][time_bins] (NaN = dropped
  * cell), the reference's index searches and its (row, column) summation order.  Host pointers; *out receives the sum.   */
