@@ -49,6 +49,7 @@ struct Scratch {
     int device = -1;
     dsp::SpecTablesD *tab = nullptr;
     dsp::ScreenTablesD *scr = nullptr;
+    int *cu_table = nullptr;               // launch_iir2_screen_f64's per-CU arrival counters
     double U = 0.0;
     // per pass of `cap_clips` clips with `cap_T` columns
     double *ck_bp = nullptr, *ck_mp = nullptr, *s_bp = nullptr, *mids = nullptr;
@@ -93,7 +94,8 @@ struct Scratch {
         x = nullptr; cap_x = 0;
         if (tab) (void)hipFree(tab);
         if (scr) (void)hipFree(scr);
-        tab = nullptr; scr = nullptr;
+        if (cu_table) (void)hipFree(cu_table);
+        tab = nullptr; scr = nullptr; cu_table = nullptr;
         if (done) (void)hipEventDestroy(done);
         done = nullptr;
     }
@@ -135,7 +137,7 @@ int run(const dsp_classify_config_f64 &cfg, Scratch &w, Pipeline pl, const void 
     w.last_segments = cnt * (long)columns(n);
     if (pl == kCkpt) {
         const double guard = dsp::f64_threshold_guard();
-        DSP_CAPI_HIP(dsp::launch_iir2_screen_f64(d_x, in, cnt, n, stride, c_bp, c_mp, w.ck_bp, w.ck_mp, w.scr, w.U, cfg.midpoint_db, guard, w.loud, w.want, st));
+        DSP_CAPI_HIP(dsp::launch_iir2_screen_f64(d_x, in, cnt, n, stride, c_bp, c_mp, w.ck_bp, w.ck_mp, w.scr, w.U, cfg.midpoint_db, guard, w.loud, w.want, w.cu_table, st));
         DSP_CAPI_HIP(dsp::launch_spec_f64_recheck(d_x, in, cnt, n, stride, c_mp, w.ck_mp, w.tab, w.want, cfg.midpoint_db, guard, w.loud, st));
         DSP_CAPI_HIP(dsp::launch_classify_f64_midpoints(w.loud, cnt, n, 16000, w.mids, w.n_mids, w.hits, w.labels, tr, st));
         DSP_CAPI_HIP(dsp::launch_spec_f64_listed_from_ckpt(d_x, in, cnt, n, stride, c_bp, w.ck_bp, w.tab, w.hits, w.s_bp, st));
@@ -171,6 +173,7 @@ int reserve(Scratch &w, int device, Pipeline pl, long clips, int n, size_t x_byt
         if (!dsp::build_screen_tables_f64(*t, 16000, *s)) return dsp::capi_fail(DSP_EINVAL, "screening tables: the window is not flat between its tapers");
         DSP_CAPI_HIP(hipMalloc(&w.tab, sizeof(*t)));
         DSP_CAPI_HIP(hipMemcpy(w.tab, t.get(), sizeof(*t), hipMemcpyHostToDevice));
+        DSP_CAPI_HIP(hipMalloc(&w.cu_table, sizeof(int) * (dsp::kSimdLoadCus + 16 * 4096)));      // (+ the diagnostic build's per-block records)
         DSP_CAPI_HIP(hipMalloc(&w.scr, sizeof(*s)));
         DSP_CAPI_HIP(hipMemcpy(w.scr, s.get(), sizeof(*s), hipMemcpyHostToDevice));
         w.U = t->U;
@@ -374,6 +377,18 @@ int dsp_classify_stats_f64(int device, long *segments, long *undecided, long *li
     if (segments) *segments = w.last_segments;
     if (undecided) *undecided = nw;
     if (listed_clips) *listed_clips = nh;
+    return DSP_OK;
+}
+
+int dsp_classify_debug_f64(int device, int *out, int n_ints)      /* diagnostic builds: the screening kernel's per-block records */
+{
+    if (device < 0 || device >= kMaxDevices || !out || n_ints < 0 || n_ints > 16 * 4096) return dsp::capi_fail(DSP_EINVAL, "bad argument");
+    Scratch &w = g_w[device];
+    std::lock_guard<std::mutex> lock(w.mu);
+    if (!w.cu_table) return dsp::capi_fail(DSP_EINVAL, "no pass has run");
+    DSP_ON_DEVICE(device);
+    w.wait_idle();
+    DSP_CAPI_HIP(hipMemcpy(out, w.cu_table + dsp::kSimdLoadCus, sizeof(int) * (size_t)n_ints, hipMemcpyDeviceToHost));
     return DSP_OK;
 }
 

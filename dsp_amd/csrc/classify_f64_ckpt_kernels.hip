@@ -30,10 +30,13 @@
 // and m come from the taps wave in float32 beside the float64 filter.  A segment is "quiet" only when every computed cell is quiet for
 // sure AND that remainder is below the threshold; "loud" when one computed cell is loud for sure; otherwise it is listed.
 //
-// Block = 64 clips (lane = clip in the serial parts), five wavefronts:
+// Block = 64 clips (lane = clip in the serial parts), four wavefronts -- one per SIMD, so that three blocks share a CU with one wave of
+// each on every SIMD (five-wave blocks put two waves of a block on one SIMD and the third block of a CU did not fit beside the others):
 //   R_bp  recurrence 3000-7500 Hz: x tile -> delay line, restart states to HBM           R_mp  the same at 1000-3000 Hz, v tile -> LDS
-//   T     taps of the 1000-3000 Hz filter one tile behind (y = b0 v + sum b_j v[n-j]), float32 sums per segment, y as bf16 -> LDS
-//   X0 X1 two tiles behind: the MFMAs (64 table rows x 64 clips each), the verdict at every segment's end; they also load the x tiles
+//         (the two also fetch the x tiles, three tiles ahead in registers)
+//   T     taps of the 1000-3000 Hz filter one tile behind (y = b0 v + sum b_j v[n-j]), float32 sums per segment, y as bf16 -> LDS,
+//         and the MFMAs + verdicts of table rows 0 .. 63 (bins 0 .. 31, 128) on that tile
+//   X     two tiles behind: the MFMAs + verdicts of rows 64 .. 127 (bins 32 .. 63); writes the segments' flags
 // A tile = 16 samples = one MFMA k-step = one full 128-byte line of a float64 row.  One __syncthreads per tile.
 #include <hip/hip_runtime.h>
 
@@ -60,7 +63,7 @@ constexpr int SC_TS = 16;                         // samples per tile
 constexpr int SC_XLD = 18;                        // doubles per LDS row of an x / v tile (144 B: 16-byte aligned rows, 36-dword stride)
 constexpr int SC_YROW = 48;                       // bytes per clip row of a bf16 y tile (32 + 16: conflict-free ds_read_b128 / ds_write_b128)
 constexpr int SC_RING = 4;                        // y tiles kept: the transform waves run two tiles behind and start a segment one tile late
-constexpr int SC_THREADS = 320;
+constexpr int SC_THREADS = 256;
 #ifndef SC_ROLES
 #define SC_ROLES 7        // diagnostic builds: which roles are compiled in (1 recurrences, 2 taps, 4 transform waves)
 #endif
@@ -122,10 +125,10 @@ __device__ __forceinline__ double sample_at(const void *__restrict__ x, long idx
 // pass 1: recurrences, restart states, screening
 // =====================================================================================================================================
 template <int IN, bool EVEN_B, bool VEC>
-__global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void iir2_screen_f64_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T, const IirCoefD c_bp,
+__global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void iir2_screen_f64_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T, const IirCoefD c_bp,
                                                                       const IirCoefD c_mp, double *__restrict__ ck_bp, double *__restrict__ ck_mp,
                                                                       const ScreenTablesD *__restrict__ tab, int *__restrict__ loud, int *__restrict__ want,
-                                                                      float thr_u, float guard)
+                                                                      float thr_u, float guard, int *__restrict__ cu_table)
 {
     __shared__ __attribute__((aligned(16))) double tin[2][64 * SC_XLD];                 // x tiles as doubles, [tile parity]
     __shared__ __attribute__((aligned(16))) double vbuf[2][64 * SC_XLD];                // v tiles of the 1000-3000 Hz filter
@@ -134,7 +137,60 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     __shared__ unsigned f_state[64];
     __shared__ float what[65][2];                                                       // the window's transform at bins 0 .. 63, [64] = bin 128
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // 0 R_bp, 1 R_mp, 2 T, 3 X0, 4 X1
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Which wave runs which role (0 R_bp, 1 R_mp, 2 T, 3 X) follows the SIMD it landed on and the block's arrival number k on its CU.
+    // The dispatcher gives the waves of a block to the four SIMDs in a fixed order, so with wave number = role the three blocks of a CU
+    // stack their R_bp waves on one SIMD and their R_mp waves on another -- 768 float64 operations per step there, ~40 on the SIMD of
+    // the X waves: measured 2.30 ms for the recurrences alone.  The table spreads them: per SIMD {R, R, X}, {R, R, X}, {R, T, T},
+    // {R, T, X}.  Scheduling only: what a role computes does not depend on the wave that runs it; waves that share a SIMD (any other
+    // placement) simply take the roles that are left.
+    __shared__ int s_simd[4], s_role[4];
+    {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;     // HW_ID, XCC_ID
+        if (lane == 0) s_simd[wib] = (int)((hw >> 4) & 3u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int k = 0;
+            if (cu_table) k = atomicAdd(cu_table + (((xcc << 8) | ((hw >> 8) & 0xFFu)) & (kSimdLoadCus - 1)), 1);      // (XCC, SE, SH, CU)
+            constexpr int want_role[3][4] = {{0, 1, 2, 3}, {1, 3, 2, 0}, {3, 0, 1, 2}};      // [k mod 3][SIMD]
+            bool taken[4] = {false, false, false, false};
+            int role[4] = {-1, -1, -1, -1};
+            for (int w = 0; w < 4; ++w) {
+                const int r0 = want_role[k % 3][s_simd[w] & 3];
+                if (cu_table && !taken[r0]) { role[w] = r0; taken[r0] = true; }
+            }
+            for (int w = 0; w < 4; ++w)
+                if (role[w] < 0)
+                    for (int r0 = 0; r0 < 4; ++r0)
+                        if (!taken[r0]) { role[w] = r0; taken[r0] = true; break; }
+            for (int w = 0; w < 4; ++w) s_role[w] = role[w];
+#ifdef SC_DIAG
+            if (cu_table) {
+                cu_table[kSimdLoadCus + (long)blockIdx.x * 16] = (int)(((xcc << 8) | ((hw >> 8) & 0xFFu)) & (kSimdLoadCus - 1));
+                cu_table[kSimdLoadCus + (long)blockIdx.x * 16 + 1] = k;
+            }
+#endif
+        }
+        __syncthreads();
+    }
+    const int wv = __builtin_amdgcn_readfirstlane(s_role[wib]);
+#ifdef SC_DIAG      // diagnostic build: per block [16]: CU index, arrival number, the waves' SIMDs and roles, busy / total cycles per role
+    unsigned long long diag_busy = 0, diag_t0 = 0;
+    const unsigned long long diag_start = __builtin_amdgcn_s_memtime();
+#define SC_DIAG_BEGIN() diag_t0 = __builtin_amdgcn_s_memtime()
+#define SC_DIAG_END() diag_busy += __builtin_amdgcn_s_memtime() - diag_t0
+#define SC_DIAG_WRITE()                                                                                                            \
+    if (cu_table && lane == 0) {                                                                                                   \
+        int *dg = cu_table + kSimdLoadCus + (long)blockIdx.x * 16;                                                                 \
+        dg[4 + wv] = s_simd[wib];                                                                                                  \
+        dg[8 + wv] = (int)(diag_busy >> 4);                                                                                        \
+        dg[12 + wv] = (int)((__builtin_amdgcn_s_memtime() - diag_start) >> 4);                                                     \
+    }
+#else
+#define SC_DIAG_BEGIN()
+#define SC_DIAG_END()
+#define SC_DIAG_WRITE()
+#endif
     const long clip0 = (long)blockIdx.x * 64;
     const int rows = (int)((n_clips - clip0) < 64 ? (n_clips - clip0) : 64);
     const int n_tiles = (T - 1) * kTilesPerHop + kTilesPerSeg;           // samples past the last whole segment reach no output
@@ -143,63 +199,91 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         what[threadIdx.x][0] = tab->what_re[threadIdx.x]; what[threadIdx.x][1] = tab->what_im[threadIdx.x];
         if (threadIdx.x == 0) { what[64][0] = tab->what128; what[64][1] = 0.0f; }
     }
-    // recurrence waves ahead of the others in their SIMD's arbiter: they are the block's critical path
-    if (wv < 2) __builtin_amdgcn_s_setprio(3);
-    else if (wv == 2) __builtin_amdgcn_s_setprio(1);
+#ifndef SC_PRIO
+#define SC_PRIO 2
+#endif
+    if (SC_PRIO == 1) {            // recurrence waves first
+        if (wv < 2) __builtin_amdgcn_s_setprio(3);
+        else if (wv == 2) __builtin_amdgcn_s_setprio(1);
+    } else if (SC_PRIO == 2) {     // short jobs first
+        if (wv == 3) __builtin_amdgcn_s_setprio(3);
+        else if (wv == 2) __builtin_amdgcn_s_setprio(1);
+    }
 
-    // ---- x tiles: the 128 threads of X0 / X1 fetch 128-byte row pieces one load tile ahead and commit one compute tile per step ----
+    // ---- x tiles: the 128 threads of R_bp and R_mp fetch 128-byte row pieces and commit one compute tile per step ----
+    // A queue of LD_DEPTH load tiles rides in registers: with one tile in flight per block (24 KB per CU) the float64 input could not
+    // be streamed faster than ~3 TB/s at the loaded HBM latency, and the transform waves that used to load were the slowest of the block.
     constexpr int PP = In<IN>::kPerPiece;                 // samples per 16-byte piece
     constexpr int LT = 8 * PP;                            // samples per 128-byte load tile
     constexpr int KT = LT / SC_TS;                        // compute tiles per load tile (1, 4, 2)
+    constexpr int LD_PER = 4;                             // pieces per loader thread and load tile (512 pieces over 128 threads)
+    constexpr int LD_DEPTH = KT == 1 ? 3 : 2;             // load tiles in flight
     const int n_ltiles = (n_tiles + KT - 1) / KT;
-    u32x4 raw[4];
-    // VEC: every row start is 16-byte aligned -- 16-byte pieces one load tile ahead in registers.  A piece past the end of a row (int16
-    // input, last load tile) belongs to a compute tile past the last segment and is never committed; it is not fetched either.
+    typedef u32x4 RawQueue[LD_DEPTH][LD_PER];        // (declared inside each loading role: its registers are that role's only)
+    // VEC: every row start is 16-byte aligned -- 16-byte pieces.  Every load is UNCONDITIONAL on a clamped address (rows past the
+    // block's last clip repeat that clip, pieces past the end of a row -- int16 input, last load tile: compute tiles past the last
+    // segment, never committed -- read the row's last whole piece): a load under a condition lands in a temporary that is moved into the
+    // queue's registers, and that move waits for the load just issued (the first form of this kernel exposed the whole HBM latency in
+    // every step that way).  For the same reason the queue never rotates: slot = load tile mod LD_DEPTH, selected by a uniform switch.
     // !VEC (odd strides, unaligned bases): the commit reads its samples element by element, nothing is kept in flight.
-    auto fetch = [&](int L, int ltid) {                   // thread takes piece c = ltid & 7 of rows (ltid >> 3) + 16 k
+    const long last_piece = ((long)n - PP) / PP * PP;     // first sample of the last whole piece of a row
+    auto fetch = [&](u32x4 (&dst)[LD_PER], int L, int ltid) {          // thread takes piece c = ltid & 7 of rows (ltid >> 3) + 16 k
         if (!VEC) return;
         const int c = ltid & 7;
-        const long s0 = (long)L * LT + (long)c * PP;      // first sample of the piece
+        long s0 = (long)L * LT + (long)c * PP;            // first sample of the piece
+        s0 = s0 < last_piece ? s0 : last_piece;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = (ltid >> 3) + 16 * k;
-            raw[k] = u32x4{0u, 0u, 0u, 0u};
-            if (r < rows && s0 + PP <= n)
-                raw[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(xin) + ((clip0 + r) * stride + s0) * In<IN>::kBytes));
+        for (int k = 0; k < LD_PER; ++k) {
+            int r = (ltid >> 3) + 16 * k;
+            r = r < rows ? r : rows - 1;
+            dst[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(xin) + ((clip0 + r) * stride + s0) * In<IN>::kBytes));
         }
     };
-    auto commit = [&](int cs, int ltid) {                 // compute tile cs (of the load tile in raw[]) -> tin[cs & 1]
+    auto commit = [&](const u32x4 (&src)[LD_PER], int cs, int ltid) {  // compute tile cs (of the load tile in src) -> tin[cs & 1]
         const int c = ltid & 7, sub = cs % KT;
         constexpr int PIECES_PER_TILE = SC_TS / PP;       // 8, 2, 4
         if (c / PIECES_PER_TILE != sub) return;
         const int off = (c % PIECES_PER_TILE) * PP;       // sample offset of the piece inside the compute tile
         double *dst = tin[cs & 1];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < LD_PER; ++k) {
             const int r = (ltid >> 3) + 16 * k;
             double o[PP];
-            if (VEC) piece_to_f64<IN>(raw[k], o);
+            if (VEC) piece_to_f64<IN>(src[k], o);
             else {
                 const long s0 = (long)(cs / KT) * LT + (long)c * PP;
-                const void *row = reinterpret_cast<const unsigned char *>(xin) + (clip0 + (r < rows ? r : 0)) * stride * In<IN>::kBytes;
+                const void *row = reinterpret_cast<const unsigned char *>(xin) + (clip0 + (r < rows ? r : rows - 1)) * stride * In<IN>::kBytes;
 #pragma unroll
-                for (int j = 0; j < PP; ++j) o[j] = r < rows ? sample_at<IN>(row, s0 + j) : 0.0;
+                for (int j = 0; j < PP; ++j) o[j] = sample_at<IN>(row, s0 + j);
             }
 #pragma unroll
             for (int j = 0; j < PP; ++j) dst[r * SC_XLD + off + j] = o[j];
         }
     };
-    if (wv >= 3) {
-        const int ltid = (wv - 3) * 64 + lane;            // loader thread number
-        fetch(0, ltid);
-        commit(0, ltid);
-        if (KT == 1 && n_ltiles > 1) fetch(1, ltid);
-    }
-    __syncthreads();
+    // during step s: compute tile s + 1 into LDS; when that uses its load tile up, the tile LD_DEPTH further on is requested into its slot
+    // (slot_hint: the R / T loops are unrolled LD_DEPTH times, so that for float64 input -- one load tile per step -- the slot is a
+    // compile-time constant of each copy and the compiler's vmcnt waits count exactly the younger loads; behind a run-time switch it
+    // waits for every outstanding load.  int16 input changes slot every 4 / 2 steps and keeps the switch: a quarter of the bytes.)
+    auto loader_step = [&](RawQueue &raw, int s, int ltid, int slot_hint) {
+        const int cs = s + 1, L = cs / KT;
+        // (the fetch is issued whether or not its tile exists -- past the end it re-reads the rows' last pieces: a fetch under a run-time
+        // condition makes the number of younger loads unknown to the compiler, which then waits for all of them)
+        const bool live = cs < n_tiles, used_up = cs % KT == KT - 1;
+        switch (KT == 1 ? slot_hint : L % LD_DEPTH) {
+        case 0: if (live) commit(raw[0], cs, ltid); if (used_up) fetch(raw[0], L + LD_DEPTH, ltid); break;
+        case 1: if (live) commit(raw[1], cs, ltid); if (used_up) fetch(raw[1], L + LD_DEPTH, ltid); break;
+        default: if (live) commit(raw[LD_DEPTH - 1], cs, ltid); if (used_up) fetch(raw[LD_DEPTH - 1], L + LD_DEPTH, ltid); break;
+        }
+    };
+    auto loader_start = [&](RawQueue &raw, int ltid) {
+#pragma unroll
+        for (int dd = 0; dd < LD_DEPTH; ++dd) fetch(raw[dd], dd, ltid);
+        loader_step(raw, -1, ltid, 0);
+    };
 
     // Each role runs its own loop over the steps with ONE barrier per step (every wave of the block executes the same number of
     // barriers; the branch is wave-uniform): the compiler then allocates registers for the largest role, not for the sum of their states.
-    const int n_steps = n_tiles + 3;
+    const int n_steps = (n_tiles + 3 + LD_DEPTH - 1) / LD_DEPTH * LD_DEPTH;     // (padded: the last steps only meet at the barrier)
     if ((SC_ROLES & 1) && wv < 2) {
         // ================= recurrence waves: tile s at step s =================
         const IirCoefD &c = wv == 0 ? c_bp : c_mp;
@@ -207,7 +291,12 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
         double d[8];                                      // v[n-1] .. v[n-8] of this lane's clip
 #pragma unroll
         for (int j = 0; j < 8; ++j) d[j] = 0.0;
-        for (int s = 0; s < n_steps; ++s) {
+        RawQueue raw;
+        loader_start(raw, wv * 64 + lane);
+        __syncthreads();
+        auto step = [&](int s, int slot_hint) {
+            SC_DIAG_BEGIN();
+            loader_step(raw, s, wv * 64 + lane, slot_hint);
             if (s < n_tiles) {
                 const int seg = s / kTilesPerHop, p = s - seg * kTilesPerHop;
                 // restart states: offsets 0, 64, 128, 192 of segment seg (tiles 14 seg + {0, 4, 8, 12}; the last two tiles of a
@@ -237,21 +326,81 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                     for (int i = 0; i < SC_TS; i += 2) *reinterpret_cast<d2 *>(vrow + i) = d2{xr[i], xr[i + 1]};
                 }
             }
+            SC_DIAG_END();
             __syncthreads();
+        };
+        // whole groups of LD_DEPTH steps, no condition between the copies (a copy that may be skipped makes its fetch conditional again)
+        for (int s0 = 0; s0 < n_steps; s0 += LD_DEPTH) {
+#pragma unroll
+            for (int u = 0; u < LD_DEPTH; ++u) step(s0 + u, (u + 1) % LD_DEPTH);
         }
-    } else if ((SC_ROLES & 2) && wv == 2) {
-        // ================= taps wave: tile s - 1 at step s =================
+        SC_DIAG_WRITE();
+    } else if ((SC_ROLES & 6) && wv >= 2) {
+        // ================= taps wave (tile s - 1 at step s) and transform wave (tile s - 2) =================
+        const bool taps = wv == 2;
+        const int xq = wv - 2;                            // table blocks 2 xq, 2 xq + 1 = bins 32 xq .. 32 xq + 31 (and bin 128 with xq = 0)
         const IirCoefD &c = c_mp;
-        double d[8];                                      // v[n-1] .. v[n-8]
+        double d[8];                                      // T: v[n-1] .. v[n-8]
 #pragma unroll
         for (int j = 0; j < 8; ++j) d[j] = 0.0;
-        float s_cur = 0.f, a_cur = 0.f, q_cur = 0.f, s_prev = 0.f, a_prev = 0.f, q_prev = 0.f;       // sum y, sum |y|, sum w^2 y^2 of the open segments
+        float s_cur = 0.f, a_cur = 0.f, q_cur = 0.f, s_prev = 0.f, a_prev = 0.f, q_prev = 0.f;       // T: sum y, sum |y|, sum w^2 y^2 of the open segments
+        f32x16 acc[2][2];                                 // [table block][clip half], rows = (bin, re / im) pairs
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+        int pending_seg = -1;                             // X: the segment whose verdicts are waiting in f_state / f_sum
+        // (the lane number is made opaque once per step: everything derived from it -- LDS addresses of the verdict's table reads -- is
+        // then recomputed where it is used instead of being kept in registers across the loop)
+        int lane_o = lane;
+        __syncthreads();                                  // (the loaders' first tile)
         for (int s = 0; s < n_steps; ++s) {
-            const int ts = s - 1;
-            if (ts >= 0 && ts < n_tiles) {
-                const int tc = ts / kTilesPerHop, p = ts - tc * kTilesPerHop;          // segment tc at tile p; for p < 2 also segment tc - 1 at tile 14 + p
+            SC_DIAG_BEGIN();
+            asm volatile("" : "+v"(lane_o));
+            const int r = lane_o & 31, h = lane_o >> 5;
+            if (!taps && pending_seg >= 0) {
+                // the verdicts of segment pending_seg: all four contributions (two lane halves x two waves) are in
+                unsigned st = f_state[lane_o];                          // 0 every computed cell quiet for sure, 1 undecided, 2 a cell loud for sure
+                if (st == 0u) {
+                    const float root = sqrtf(f_sum[lane_o]) - f_en[lane_o];
+                    const float low = root > 0.f ? root * root : 0.f;   // the computed bins hold at least this much of 256 E
+                    if (!(f_e[lane_o] - low < thr_u * (1.0f - guard) * 0.9999f)) st = 1u;      // a bin that was not computed could reach the threshold
+                }
+                if (lane_o < rows) {
+                    const long fr = (clip0 + lane_o) * T + pending_seg;
+                    loud[fr] = st == 2u ? 1 : (st == 1u ? 2 : 0);
+                    if (st == 1u) want[1 + atomicAdd(want, 1)] = (int)fr;
+                }
+                f_state[lane_o] = 0u; f_sum[lane_o] = 0.0f;
+            }
+            pending_seg = -1;
+            const int tx = taps ? s - 1 : s - 2;
+            // This tile's transform work as a short list of k-steps, ONE MFMA site and ONE verdict site in the code:
+            //   p = 0: k-step 14 of segment tc - 1 (segment tc's first k-step waits: the accumulators still belong to tc - 1)
+            //   p = 1: k-step 15 of segment tc - 1, its verdict, then k-steps 0 (the previous tile, still in the ring) and 1 of segment tc
+            //   p > 1: k-step p of segment tc
+            const bool tile_live = tx >= 0 && tx < n_tiles;
+            const int tc = tile_live ? tx / kTilesPerHop : 0, p = tile_live ? tx - tc * kTilesPerHop : 0;
+            const bool prev = tile_live && p < 2 && tc >= 1, cur = tile_live && tc < T && p >= 1;
+            const int n_prev = prev ? 1 : 0, n_ops = (SC_ROLES & 4) ? n_prev + (cur ? (p == 1 ? 2 : 1) : 0) : 0;
+            auto ks_of = [&](int o) { return o < n_prev ? kTilesPerHop + p : (p == 1 ? o - n_prev : p); };
+            // the table fragments of the first k-step are requested HERE, before the taps: behind them their L2 latency (~2 000 cycles with
+            // every CU streaming) stood in series with the taps and made this wave the block's slowest (85 % busy, the recurrences 53 - 67 %)
+            bf16x8 a_pre[2][2];                           // [table block][hi / lo]
+            auto request = [&](int ks) {
+#pragma unroll
+                for (int mbl = 0; mbl < 2; ++mbl) {
+                    const bf16x8 *a = reinterpret_cast<const bf16x8 *>(tab->a_tab) + (size_t)((ks * 4 + 2 * xq + mbl) * 2) * 64 + lane_o;
+                    a_pre[mbl][0] = a[0]; a_pre[mbl][1] = a[64];
+                }
+            };
+            request(n_ops > 0 ? ks_of(0) : 0);
+            if ((SC_ROLES & 2) && taps && tile_live) {
+                const int ts = tx;                                      // segment tc at tile p; for p < 2 also segment tc - 1 at tile 14 + p
                 if (p == 0) { s_prev = s_cur; a_prev = a_cur; q_prev = q_cur; s_cur = a_cur = q_cur = 0.f; }
-                const double *vrow = vbuf[ts & 1] + lane * SC_XLD;
+                const double *vrow = vbuf[ts & 1] + lane_o * SC_XLD;
                 double vr[SC_TS];
 #pragma unroll
                 for (int i = 0; i < SC_TS; i += 2) { const d2 v2 = *reinterpret_cast<const d2 *>(vrow + i); vr[i] = v2.x; vr[i + 1] = v2.y; }
@@ -285,83 +434,33 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                     lo4[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{yf[2 * k], yf[2 * k + 1]}, bf16x2));
                     hi4[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{yf[8 + 2 * k], yf[9 + 2 * k]}, bf16x2));
                 }
-                u32x4 *yrow = reinterpret_cast<u32x4 *>(ybuf[ts & (SC_RING - 1)] + lane * SC_YROW);
+                u32x4 *yrow = reinterpret_cast<u32x4 *>(ybuf[ts & (SC_RING - 1)] + lane_o * SC_YROW);
                 yrow[0] = lo4; yrow[1] = hi4;
-                if (p == 1 && tc >= 1) {                                // segment tc - 1 is complete: what the transform waves need of it
+                if (p == 1 && tc >= 1) {                                // segment tc - 1 is complete: what the verdicts need of it
                     const float m = s_prev * (1.0f / kSpecSeg);
                     const float e = q_prev + 2.0f * fabsf(m) * a_prev + m * m * tab->win2_sum;      // >= sum w^2 (y - m)^2
-                    f_mean[lane] = m;
-                    f_g[lane] = 1.4142136f * 1.03f * (1.0f / 256.0f) * a_prev;
-                    f_e[lane] = (float)kSpecSeg * e * 1.0001f;
-                    f_en[lane] = 1.1f * 16.0f * (1.0f / 256.0f) * sqrtf(q_prev);
+                    f_mean[lane_o] = m;
+                    f_g[lane_o] = 1.4142136f * 1.03f * (1.0f / 256.0f) * a_prev;
+                    f_e[lane_o] = (float)kSpecSeg * e * 1.0001f;
+                    f_en[lane_o] = 1.1f * 16.0f * (1.0f / 256.0f) * sqrtf(q_prev);
                 }
+                wave_sync_lds();                                        // this wave reads the tile and the segment's figures back below
             }
-            __syncthreads();
-        }
-    } else if ((SC_ROLES & 4) && wv >= 3) {
-        // ================= transform waves: tile s - 2 at step s; loaders of the x tiles =================
-        const int xq = wv - 3;                            // table blocks 2 xq, 2 xq + 1 = bins 32 xq .. 32 xq + 31
-        f32x16 acc[2][2];                                 // [table block][clip half], rows = (bin, re / im) pairs
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
-        int pending_seg = -1;                             // X0: the segment whose verdicts are waiting in f_state / f_sum
-        // (the lane number is made opaque once per step: everything derived from it -- LDS addresses of the verdict's table reads, row
-        // pointers of the loader -- is then recomputed where it is used instead of being kept in registers across the loop)
-        int lane_o = lane;
-        for (int s = 0; s < n_steps; ++s) {
-            asm volatile("" : "+v"(lane_o));
-            const int r = lane_o & 31, h = lane_o >> 5;
-            if (xq == 0 && pending_seg >= 0) {
-                // the verdicts of segment pending_seg: all four contributions (two lane halves x two waves) are in
-                unsigned st = f_state[lane_o];                          // 0 every computed cell quiet for sure, 1 undecided, 2 a cell loud for sure
-                if (st == 0u) {
-                    const float root = sqrtf(f_sum[lane_o]) - f_en[lane_o];
-                    const float low = root > 0.f ? root * root : 0.f;   // the computed bins hold at least this much of 256 E
-                    if (!(f_e[lane_o] - low < thr_u * (1.0f - guard) * 0.9999f)) st = 1u;      // a bin that was not computed could reach the threshold
-                }
-                if (lane_o < rows) {
-                    const long fr = (clip0 + lane_o) * T + pending_seg;
-                    loud[fr] = st == 2u ? 1 : (st == 1u ? 2 : 0);
-                    if (st == 1u) want[1 + atomicAdd(want, 1)] = (int)fr;
-                }
-                f_state[lane_o] = 0u; f_sum[lane_o] = 0.0f;
-            }
-            pending_seg = -1;
-            // loader duty: compute tile s + 1 into LDS, the next load tile into registers
-            if (s + 1 < n_tiles) {
-                const int ltid = xq * 64 + lane_o;
-                commit(s + 1, ltid);
-                if ((s + 1) % KT == KT - 1 && (s + 1) / KT + 1 < n_ltiles) fetch((s + 1) / KT + 1, ltid);
-            }
-            const int tx = s - 2;
-            if (tx >= 0 && tx < n_tiles) {
-                const int tc = tx / kTilesPerHop, p = tx - tc * kTilesPerHop;
-                // This tile's work as a short list of k-steps, ONE MFMA site and ONE verdict site in the code:
-                //   p = 0: k-step 14 of segment tc - 1 (segment tc's first k-step waits: the accumulators still belong to tc - 1)
-                //   p = 1: k-step 15 of segment tc - 1, its verdict, then k-steps 0 (the previous tile, still in the ring) and 1 of segment tc
-                //   p > 1: k-step p of segment tc
-                const bool prev = p < 2 && tc >= 1, cur = tc < T && p >= 1;
-                const int n_prev = prev ? 1 : 0, n_ops = n_prev + (cur ? (p == 1 ? 2 : 1) : 0);
+            if (n_ops > 0) {
 #pragma unroll 1
                 for (int o = 0; o < n_ops; ++o) {
                     const bool is_prev = o < n_prev;
-                    const int ks = is_prev ? kTilesPerHop + p : (p == 1 ? o - n_prev : p);
                     const int tile = (!is_prev && p == 1 && o == n_prev) ? tx - 1 : tx;
                     const unsigned char *yb = ybuf[tile & (SC_RING - 1)] + r * SC_YROW + 16 * h;
                     const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(yb), b1 = *reinterpret_cast<const bf16x8 *>(yb + 32 * SC_YROW);
 #pragma unroll
                     for (int mbl = 0; mbl < 2; ++mbl) {
-                        const bf16x8 *a = reinterpret_cast<const bf16x8 *>(tab->a_tab) + (size_t)((ks * 4 + 2 * xq + mbl) * 2) * 64 + lane_o;
-                        const bf16x8 a_hi = a[0], a_lo = a[64];
-                        acc[mbl][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b0, acc[mbl][0], 0, 0, 0);
-                        acc[mbl][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b1, acc[mbl][1], 0, 0, 0);
-                        acc[mbl][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b0, acc[mbl][0], 0, 0, 0);
-                        acc[mbl][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, b1, acc[mbl][1], 0, 0, 0);
+                        acc[mbl][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_pre[mbl][0], b0, acc[mbl][0], 0, 0, 0);
+                        acc[mbl][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_pre[mbl][0], b1, acc[mbl][1], 0, 0, 0);
+                        acc[mbl][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_pre[mbl][1], b0, acc[mbl][0], 0, 0, 0);
+                        acc[mbl][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_pre[mbl][1], b1, acc[mbl][1], 0, 0, 0);
                     }
+                    if (o + 1 < n_ops) request(ks_of(o + 1));           // (ahead of the verdict below, which does not need them)
                     if (is_prev && p == 1) {
                         // ---- the verdict on segment tc - 1, per clip (column) ----
 #pragma unroll
@@ -416,8 +515,10 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                     }
                 }
             }
+            SC_DIAG_END();
             __syncthreads();
         }
+        SC_DIAG_WRITE();
     }
 }
 
@@ -434,7 +535,7 @@ constexpr int RC_FRAMES = 16;                    // items per wave pass
 constexpr int RC_CHUNK_LD = kCkStrideF64 + 2;     // doubles per quarter in an LDS row (+2: the four lanes of an item start on different banks)
 constexpr int RC_ROW_LD = kCkPerSegF64 * RC_CHUNK_LD + 2;      // 266 doubles per row (16-byte aligned rows)
 template <bool MAPS, int IN, bool EVEN_B>
-__global__ __launch_bounds__(256) void spec_f64_from_ckpt_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T, const IirCoefD c,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void spec_f64_from_ckpt_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T, const IirCoefD c,
                                                                  const double *__restrict__ ck, const SpecTablesD *__restrict__ tab,
                                                                  const int *__restrict__ worklist, double *__restrict__ sxx, int *__restrict__ loud,
                                                                  double mid_power, double midpoint_db, double guard, int vec_ok)
@@ -455,69 +556,71 @@ __global__ __launch_bounds__(256) void spec_f64_from_ckpt_kernel(const void *__r
     const long total = MAPS ? (long)worklist[0] * T : (long)worklist[0];
     const long wave = (long)blockIdx.x * 4 + wib, n_waves = (long)gridDim.x * 4;
     const int f = lane >> 2, j = lane & 3;                              // recompute role: item f of the pass, quarter j
+    if (wave * RC_FRAMES >= total) return;
+    // (clip, t) of work item `it`
+    auto item_of = [&](long it, long &clip, int &t) {
+        if (MAPS) { const long e = it / T; t = (int)(it - e * T); clip = worklist[1 + e]; }
+        else { const long fr = worklist[1 + it]; clip = fr / T; t = (int)(fr - clip * T); }
+    };
+    // A pass's input -- 16 segments of 256 samples as 16-byte pieces, coalesced (a segment is contiguous), and the restart state of
+    // (item f, quarter j) -- is requested one pass AHEAD into registers: with one wave per SIMD (the rows fill the LDS) nothing else
+    // hides the HBM latency, and four dependent load batches per pass were a quarter of this kernel's time.  Every load is
+    // unconditional on a clamped item (the last one stands in for the items past the end; their results are not stored).
+    constexpr int PP = In<IN>::kPerPiece;
+    constexpr int PIECES = kSpecSeg / PP;                               // 16-byte pieces per segment: 128, 32, 64
+    constexpr int PER_LANE = RC_FRAMES * PIECES / 64;                   // pieces per lane and pass: 32, 8, 16
+    u32x4 q[PER_LANE];
+    d2 ckq[4];
+    auto request = [&](long item0) {
+        if (vec_ok) {
+#pragma unroll
+            for (int u = 0; u < PER_LANE; ++u) {
+                const int pc = lane + 64 * u, k = pc / PIECES, piece = pc % PIECES;
+                long it = item0 + k;
+                it = it < total ? it : total - 1;
+                long clip; int t;
+                item_of(it, clip, t);
+                const long s0 = (long)t * kSpecHop + (long)piece * PP;
+                q[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(xin) + (clip * stride + s0) * In<IN>::kBytes));
+            }
+        }
+        long it = item0 + f;
+        it = it < total ? it : total - 1;
+        long clip; int t;
+        item_of(it, clip, t);
+        const d2 *src = reinterpret_cast<const d2 *>(ck + (((long)t * kCkPerSegF64 + j) * n_clips + clip) * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ckq[u] = src[u];
+    };
+    request(wave * RC_FRAMES);
     for (long item0 = wave * RC_FRAMES; item0 < total; item0 += n_waves * RC_FRAMES) {
-        // ---- the items of this pass: (clip, t) of item item0 + k, k < 16 (every lane computes the one it needs) ----
-        auto item_of = [&](long it, long &clip, int &t) {
-            if (MAPS) { const long e = it / T; t = (int)(it - e * T); clip = worklist[1 + e]; }
-            else { const long fr = worklist[1 + it]; clip = fr / T; t = (int)(fr - clip * T); }
-        };
-        // ---- x into the rows: item k's 256 samples, 2 x 16-byte pieces per lane and item for float64 ----
-        constexpr int PP = In<IN>::kPerPiece;
-        constexpr int PIECES = kSpecSeg / PP;                           // 16-byte pieces per segment: 128, 32, 64
-        for (int k0 = 0; k0 < RC_FRAMES; k0 += 4) {
-            // four items at a time keep at most 8 loads in flight per lane
-            constexpr int PER_LANE = (4 * PIECES + 63) / 64;            // pieces per lane for four items: 8, 2, 4
-            u32x4 q[PER_LANE];
-            bool fast[PER_LANE];
+        // ---- x into the rows ----
 #pragma unroll
-            for (int u = 0; u < PER_LANE; ++u) {
-                const int pc = lane + 64 * u, k = k0 + pc / PIECES, piece = pc % PIECES;
-                const long it = item0 + k;
-                q[u] = u32x4{0u, 0u, 0u, 0u};
-                fast[u] = false;
-                if (it < total) {
-                    long clip; int t;
-                    item_of(it, clip, t);
-                    const long s0 = (long)t * kSpecHop + (long)piece * PP;
-                    if (vec_ok) {
-                        fast[u] = true;
-                        q[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(xin) + (clip * stride + s0) * In<IN>::kBytes));
-                    }
-                }
+        for (int u = 0; u < PER_LANE; ++u) {
+            const int pc = lane + 64 * u, k = pc / PIECES, piece = pc % PIECES;
+            double o[PP];
+            if (vec_ok) piece_to_f64<IN>(q[u], o);
+            else {
+                long it = item0 + k;
+                it = it < total ? it : total - 1;
+                long clip; int t;
+                item_of(it, clip, t);
+                const void *row = reinterpret_cast<const unsigned char *>(xin) + clip * stride * In<IN>::kBytes;
+                const long s0 = (long)t * kSpecHop + (long)piece * PP;
+#pragma unroll
+                for (int jj = 0; jj < PP; ++jj) o[jj] = sample_at<IN>(row, s0 + jj);
             }
+            const int n0 = piece * PP;                                   // first sample of the piece inside the segment
+            double *dst = rows + k * RC_ROW_LD + (n0 / kCkStrideF64) * RC_CHUNK_LD + n0 % kCkStrideF64;
 #pragma unroll
-            for (int u = 0; u < PER_LANE; ++u) {
-                const int pc = lane + 64 * u, k = k0 + pc / PIECES, piece = pc % PIECES;
-                const long it = item0 + k;
-                double o[PP];
-                if (it < total && !fast[u]) {
-                    long clip; int t;
-                    item_of(it, clip, t);
-                    const void *row = reinterpret_cast<const unsigned char *>(xin) + clip * stride * In<IN>::kBytes;
-                    const long s0 = (long)t * kSpecHop + (long)piece * PP;
-#pragma unroll
-                    for (int jj = 0; jj < PP; ++jj) o[jj] = sample_at<IN>(row, s0 + jj);
-                } else piece_to_f64<IN>(q[u], o);
-                const int n0 = piece * PP;                               // first sample of the piece inside the segment
-                double *dst = rows + k * RC_ROW_LD + (n0 / kCkStrideF64) * RC_CHUNK_LD + n0 % kCkStrideF64;
-#pragma unroll
-                for (int jj = 0; jj < PP; ++jj) dst[jj] = o[jj];
-            }
+            for (int jj = 0; jj < PP; ++jj) dst[jj] = o[jj];
         }
         // ---- restart state of (item f, quarter j) ----
         double d[8];
-        {
-            const long it = item0 + f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) d[u] = 0.0;
-            if (it < total) {
-                long clip; int t;
-                item_of(it, clip, t);
-                const d2 *src = reinterpret_cast<const d2 *>(ck + (((long)t * kCkPerSegF64 + j) * n_clips + clip) * 8);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const d2 v2 = src[u]; d[2 * u] = v2.x; d[2 * u + 1] = v2.y; }
-            }
-        }
+        for (int u = 0; u < 4; ++u) { d[2 * u] = ckq[u].x; d[2 * u + 1] = ckq[u].y; }
+        // ---- the next pass's input on its way while this one is filtered and transformed ----
+        request(item0 + n_waves * RC_FRAMES);
         wave_sync_lds();
         // ---- the filter over the quarter: classifier.c:427-441 per sample, y over x in place ----
         {
@@ -678,7 +781,7 @@ int f64_screen_blocks_per_pass()
 template <int IN>
 static hipError_t launch_screen_in(const void *x, long n_clips, int n, long stride, const IirCoefD &c_bp, const IirCoefD &c_mp, double *ck_bp,
                                    double *ck_mp, const ScreenTablesD *tables, double U, double midpoint_db, double guard, int *loud, int *want,
-                                   hipStream_t stream)
+                                   int *cu_table, hipStream_t stream)
 {
     const int T = columns_of(n);
     const int blocks = (int)((n_clips + 63) / 64);
@@ -688,7 +791,7 @@ static hipError_t launch_screen_in(const void *x, long n_clips, int n, long stri
     const bool vec = rows_vec_ok<IN>(x, stride), even = even_taps_only(c_mp);
 #define DSP_SC_LAUNCH(E, V)                                                                                                                      \
     hipLaunchKernelGGL((iir2_screen_f64_kernel<IN, E, V>), dim3(blocks), dim3(SC_THREADS), 0, stream, x, n_clips, n, stride, T, c_bp, c_mp, ck_bp, \
-                       ck_mp, tables, loud, want, thr_u, g)
+                       ck_mp, tables, loud, want, thr_u, g, cu_table)
     if (even && vec) DSP_SC_LAUNCH(true, true);
     else if (even) DSP_SC_LAUNCH(true, false);
     else if (vec) DSP_SC_LAUNCH(false, true);
@@ -699,7 +802,7 @@ static hipError_t launch_screen_in(const void *x, long n_clips, int n, long stri
 
 hipError_t launch_iir2_screen_f64(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const IirCoefD &c_mp,
                                   double *ck_bp, double *ck_mp, const ScreenTablesD *tables, double U, double midpoint_db, double guard,
-                                  int *loud, int *want, hipStream_t stream)
+                                  int *loud, int *want, int *cu_table, hipStream_t stream)
 {
     const int T = columns_of(n);
     if (n_clips <= 0 || T <= 0) return hipSuccess;
@@ -707,11 +810,15 @@ hipError_t launch_iir2_screen_f64(const void *x, int in_kind, long n_clips, int 
     if ((n_clips + 63) / 64 > f64_screen_blocks_per_pass()) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(want, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
+    // DSP_AMD_F64_ROLES=0: wave number = role (A/B runs)
+    static const bool spread = [] { const char *v = std::getenv("DSP_AMD_F64_ROLES"); return !(v && std::atoi(v) == 0); }();
+    if (!spread) cu_table = nullptr;
+    if (cu_table && (e = hipMemsetAsync(cu_table, 0, sizeof(int) * kSimdLoadCus, stream)) != hipSuccess) return e;
     switch (in_kind) {
-    case 0: return launch_screen_in<0>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, stream);
-    case 1: return launch_screen_in<1>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, stream);
-    case 2: return launch_screen_in<2>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, stream);
-    case 3: return launch_screen_in<3>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, stream);
+    case 0: return launch_screen_in<0>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream);
+    case 1: return launch_screen_in<1>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream);
+    case 2: return launch_screen_in<2>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream);
+    case 3: return launch_screen_in<3>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream);
     default: return hipErrorInvalidValue;
     }
 }

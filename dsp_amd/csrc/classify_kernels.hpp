@@ -197,10 +197,11 @@ bool build_screen_tables_f64(const SpecTablesD &spec, int fs, ScreenTablesD &t);
 // segment of the 1000-3000 Hz output; the undecided ones also on the work list want (want[0] = count, then frame numbers c * T + t;
 // 1 + n_clips * T ints).  guard: the relative half-width (in power) of the band around the threshold that is always left to the float64
 // transform (>= 2e-9).  At most f64_screen_blocks_per_pass() * 64 clips per launch (every block must be resident).
+// cu_table (optional, kSimdLoadCus ints, zeroed by the launch): per CU the blocks that have arrived -- spreads the roles over the SIMDs.
 int f64_screen_blocks_per_pass();
 hipError_t launch_iir2_screen_f64(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const IirCoefD &c_mp,
                                   double *ck_bp, double *ck_mp, const ScreenTablesD *tables, double U, double midpoint_db, double guard,
-                                  int *loud, int *want, hipStream_t stream);
+                                  int *loud, int *want, int *cu_table, hipStream_t stream);
 // the float64 verdict on the listed (undecided) segments, recomputed from ck_mp: loud[frame] = 0 / 1
 hipError_t launch_spec_f64_recheck(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_mp, const double *ck_mp,
                                    const SpecTablesD *tables, const int *want, double midpoint_db, double guard, int *loud, hipStream_t stream);

@@ -88,7 +88,7 @@ PREFILTER_NONE, PREFILTER_BUTTER_1000_3000, PREFILTER_BUTTER_3000_7500 = 0, 1, 2
 SYMBOLS = [
     "compute_mfcc", "dsp_classify",
     "dsp_classify_default_config_f64", "dsp_classify_batch_host_f64", "dsp_classify_batch_device_f64",
-    "dsp_classify_batch_pcm16_host_f64", "dsp_classify_batch_pcm16_device_f64", "dsp_classify_release_f64", "dsp_classify_stats_f64",
+    "dsp_classify_batch_pcm16_host_f64", "dsp_classify_batch_pcm16_device_f64", "dsp_classify_release_f64", "dsp_classify_stats_f64", "dsp_classify_debug_f64",
     "dsp_classify_default_config", "dsp_classify_batch_host_cfg", "dsp_classify_batch_device_cfg", "dsp_sum_intense_f32",
     "dsp_butter_bandpass_filter_f32", "dsp_butter_bandpass_filter_f64", "dsp_compute_spectrogram_f32", "dsp_compute_spectrogram_f64",
     "dsp_classify_batch_host", "dsp_classify_batch_device", "dsp_find_midpoints", "dsp_classify_division_check",

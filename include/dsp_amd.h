@@ -266,6 +266,8 @@ int dsp_classify_batch_pcm16_device_f64(const dsp_classify_config_f64 *cfg, cons
 /* What the LAST pass of the float64 classifier on `device` did (blocks until it has finished): spectrogram segments of the
  * 1000-3000 Hz output, how many of them the screening left to the float64 transform, clips that had midpoints.  Any pointer may be NULL. */
 int dsp_classify_stats_f64(int device, long *segments, long *undecided, long *listed_clips);
+/* Diagnostic builds of the library only (-DSC_DIAG): the screening kernel's per-block records of the last pass (16 ints per block).  */
+int dsp_classify_debug_f64(int device, int *out, int n_ints);
 /* frees the float64 classifier's workspace on `device` (-1: on every device) after its pending work has finished */
 int dsp_classify_release_f64(int device);
 

@@ -86,7 +86,8 @@ def test_screening_never_contradicts_the_float64_transform(dsp):
     _same(got, ref)
     # the screening does its job: few segments undecided by default, most of them with the guard band at +-90 %
     assert undecided < 0.05 * seg, (undecided, seg)
-    assert undecided2 > 0.3 * seg2, (undecided2, seg2)
+    assert undecided2 > 0.15 * seg2 and undecided2 > 4 * undecided, (undecided, undecided2, seg2)
+    print(f"screening: {undecided} of {seg} segments undecided by default, {undecided2} with the guard at +-90 %")
     counts = [len(m) for m, _ in got[1]]
     assert 0 in counts and max(counts) >= 1
 
@@ -128,7 +129,7 @@ def test_int16_input_is_bit_identical_to_float64_input(dsp, golden):
     rng = np.random.default_rng(41)
     call = S.classify_cases()["scrub_a"].astype(np.float64)
     n = 16000
-    base = np.concatenate([rng.uniform(-0.02, 0.02, (10, n)) + call, rng.uniform(-1, 1, (10, n)) * np.logspace(-3, -0.5, 10)[:, None]])
+    base = np.concatenate([rng.uniform(-0.002, 0.002, (10, n)) + call, rng.uniform(-1, 1, (10, n)) * np.logspace(-3, -0.5, 10)[:, None]])
     pcm = np.clip(np.round(base * 32768.0), -32768, 32767).astype(np.int16)
     as_f64 = pcm.astype(np.float64) / 32768.0
     ref = dsp.classify_batch_f64(as_f64, with_trace=True)
