@@ -27,7 +27,7 @@
 // and the bins 64 .. 127 that are not computed are bounded together by Parseval: sum_k c_k |X_k|^2 = 256 E, E = sum_n w_n^2 (y_n - m)^2,
 // so every one of their cells is at most 256 E - sum_{computed k} c_k |X_k|^2, the subtracted sum taken low by the 2-norm of the
 // rounding error (||e|| <= 1.1 * 16 * 2^-8 * sqrt(sum w_n^2 y_n^2): the transform of w * (bf16(y) - y) by Parseval again).  E, the sums
-// and m come from the taps wave in float32 beside the float64 filter.  A segment is "quiet" only when every computed cell is quiet for
+// and m come from the taps wave, which evaluates the filter's taps in float32 (its own error bound ev is added to g, ||e|| and E).  A segment is "quiet" only when every computed cell is quiet for
 // sure AND that remainder is below the threshold; "loud" when one computed cell is loud for sure; otherwise it is listed.
 //
 // Block = 64 clips (lane = clip in the serial parts), four wavefronts -- one per SIMD, so that three blocks share a CU with one wave of
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                 if (p % kCkStep == 0 && seg < T && lane < rows) {
                     d2 *dst = reinterpret_cast<d2 *>(ck + (((long)seg * kCkPerSegF64 + p / kCkStep) * n_clips + clip0 + lane) * 8);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(d2{d[2 * j], d[2 * j + 1]}, dst + j);
+                    for (int j = 0; j < 4; ++j) dst[j] = d2{d[2 * j], d[2 * j + 1]};      // (plain stores: the four 16-byte pieces of a lane's 64 bytes meet in L2; as nt stores they reached HBM as partial lines, 1.7 x the bytes)
                 }
                 const double *xrow = tin[s & 1] + lane * SC_XLD;
                 double xr[SC_TS];
@@ -339,11 +339,21 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         // ================= taps wave (tile s - 1 at step s) and transform wave (tile s - 2) =================
         const bool taps = wv == 2;
         const int xq = wv - 2;                            // table blocks 2 xq, 2 xq + 1 = bins 32 xq .. 32 xq + 31 (and bin 128 with xq = 0)
-        const IirCoefD &c = c_mp;
-        double d[8];                                      // T: v[n-1] .. v[n-8]
+        // T: the taps in FLOAT32.  What they feed is the screening only (every float64 output of this filter that the classifier uses is
+        // recomputed from the restart states): y32 = fl32(sum_j b_j v_j) on float32-rounded v differs from the float64 output by at most
+        // 11 * 2^-24 * sum_j |b_j| |v[n-j]| (two roundings of the inputs, a chain of at most nine fused operations), which enters the
+        // bounds below as ev = 2^-19 * (sum |b_j|) * (sum |v| over the segment and the eight samples before it) -- about 1e-5 of sum |y|
+        // for these band-passes, beside bf16's 2^-8.  Nine float64 operations per sample became one conversion and six float32 ones on
+        // the wave that shares its SIMD with two others.
+        float bf[9], b_abs = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] = 0.0;
+        for (int j = 0; j < 9; ++j) { bf[j] = (float)c_mp.b[j]; b_abs += fabsf(bf[j]); }
+        b_abs *= 1.0001f;
+        float d[8];                                       // T: float32(v[n-1] .. v[n-8])
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = 0.f;
         float s_cur = 0.f, a_cur = 0.f, q_cur = 0.f, s_prev = 0.f, a_prev = 0.f, q_prev = 0.f;       // T: sum y, sum |y|, sum w^2 y^2 of the open segments
+        float v_cur = 0.f, v_prev = 0.f, v_tile = 0.f;    // T: sum |v| of the open segments (from one tile before their start) and of the last tile
         f32x16 acc[2][2];                                 // [table block][clip half], rows = (bin, re / im) pairs
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -399,23 +409,29 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
             request(n_ops > 0 ? ks_of(0) : 0);
             if ((SC_ROLES & 2) && taps && tile_live) {
                 const int ts = tx;                                      // segment tc at tile p; for p < 2 also segment tc - 1 at tile 14 + p
-                if (p == 0) { s_prev = s_cur; a_prev = a_cur; q_prev = q_cur; s_cur = a_cur = q_cur = 0.f; }
+                if (p == 0) { s_prev = s_cur; a_prev = a_cur; q_prev = q_cur; s_cur = a_cur = q_cur = 0.f; v_prev = v_cur; v_cur = v_tile; }
                 const double *vrow = vbuf[ts & 1] + lane_o * SC_XLD;
-                double vr[SC_TS];
-#pragma unroll
-                for (int i = 0; i < SC_TS; i += 2) { const d2 v2 = *reinterpret_cast<const d2 *>(vrow + i); vr[i] = v2.x; vr[i + 1] = v2.y; }
                 float yf[SC_TS];
+                v_tile = 0.f;
 #pragma unroll
-                for (int i = 0; i < SC_TS; ++i) {                       // classifier.c:435-441
-                    double o = c.b[0] * vr[i];
+                for (int i = 0; i < SC_TS; i += 2) {                    // classifier.c:435-441 (in float32: see above)
+                    const d2 v2 = *reinterpret_cast<const d2 *>(vrow + i);
 #pragma unroll
-                    for (int j = 1; j <= 8; ++j)
-                        if (!EVEN_B || j % 2 == 0) o = o + c.b[j] * d[j - 1];
+                    for (int e = 0; e < 2; ++e) {
+                        const float vf = (float)(e ? v2.y : v2.x);
+                        float o = bf[0] * vf;
 #pragma unroll
-                    for (int j = 7; j > 0; --j) d[j] = d[j - 1];
-                    d[0] = vr[i];
-                    yf[i] = (float)o;
+                        for (int j = 1; j <= 8; ++j)
+                            if (!EVEN_B || j % 2 == 0) o = fmaf(bf[j], d[j - 1], o);
+#pragma unroll
+                        for (int j = 7; j > 0; --j) d[j] = d[j - 1];
+                        d[0] = vf;
+                        v_tile += fabsf(vf);
+                        yf[i + e] = o;
+                    }
                 }
+                v_cur += v_tile;
+                if (p < 2) v_prev += v_tile;
                 if (p >= 2) {                                           // the window is 1 here
 #pragma unroll
                     for (int i = 0; i < SC_TS; ++i) { s_cur += yf[i]; a_cur += fabsf(yf[i]); q_cur = fmaf(yf[i], yf[i], q_cur); }
@@ -438,11 +454,13 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                 yrow[0] = lo4; yrow[1] = hi4;
                 if (p == 1 && tc >= 1) {                                // segment tc - 1 is complete: what the verdicts need of it
                     const float m = s_prev * (1.0f / kSpecSeg);
-                    const float e = q_prev + 2.0f * fabsf(m) * a_prev + m * m * tab->win2_sum;      // >= sum w^2 (y - m)^2
+                    const float ev = (1.0f / 524288.0f) * b_abs * v_prev;                            // float32 taps (see above)
+                    const float e32 = q_prev + 2.0f * fabsf(m) * a_prev + m * m * tab->win2_sum;    // >= sum w^2 (y32 - m)^2
+                    const float re = sqrtf(e32 * 1.0001f) + ev;                                      // >= sqrt(sum w^2 (y - m)^2)
                     f_mean[lane_o] = m;
-                    f_g[lane_o] = 1.4142136f * 1.03f * (1.0f / 256.0f) * a_prev;
-                    f_e[lane_o] = (float)kSpecSeg * e * 1.0001f;
-                    f_en[lane_o] = 1.1f * 16.0f * (1.0f / 256.0f) * sqrtf(q_prev);
+                    f_g[lane_o] = 1.4142136f * (1.03f * (1.0f / 256.0f) * a_prev + ev);
+                    f_e[lane_o] = (float)kSpecSeg * re * re * 1.0001f;
+                    f_en[lane_o] = 16.0f * (1.1f * (1.0f / 256.0f) * sqrtf(q_prev) + ev);
                 }
                 wave_sync_lds();                                        // this wave reads the tile and the segment's figures back below
             }
