@@ -94,6 +94,56 @@ def classify_batch(clips: np.ndarray, with_trace: bool = False, config=None):
     return labels, out
 
 
+def _pcm_shape(pcm):
+    if pcm.ndim == 1:
+        pcm = pcm[None, :]
+    if pcm.ndim not in (2, 3) or (pcm.ndim == 3 and pcm.shape[2] != 2):
+        raise ValueError("pcm must be int16 [n_clips][n] or [n_clips][n][2]")
+    return pcm, (2 if pcm.ndim == 3 else 1)
+
+
+def classify_batch_pcm16(pcm: np.ndarray, stereo_mode: int = 0, with_trace: bool = False, config=None):
+    """dsp_classify_batch_pcm16_host: the float32 classify() on int16 PCM [n_clips][n] (mono) or [n_clips][n][2] (interleaved stereo:
+    channel 0 or the channels' average), converted in the kernels' loads as sync/sync.cpp:237-242 does (pcmSample / 32768.0)."""
+    pcm, channels = _pcm_shape(np.ascontiguousarray(pcm, np.int16))
+    n_clips, n = pcm.shape[:2]
+    labels = np.zeros(n_clips, np.int32)
+    tr = (_lib.ClassifyTrace * n_clips)() if with_trace else None
+    cfg = None if config is None else (config if isinstance(config, _lib.ClassifyConfig) else classify_config(config))
+    _lib.check(_lib.load().dsp_classify_batch_pcm16_host(C.byref(cfg) if cfg is not None else None, pcm.ctypes.data, n_clips, n, n, channels, int(stereo_mode),
+                                                          labels.ctypes.data, C.byref(tr) if with_trace else None), "dsp_classify_batch_pcm16_host")
+    if not with_trace:
+        return labels
+    out = []
+    for t in tr:
+        k = t.n_midpoints
+        out.append((np.array(t.midpoints[:k], np.float32),
+                    np.array([[t.sums[i][j] for j in range(3)] for i in range(k)], np.float32).reshape(-1, 3)))
+    return labels, out
+
+
+def classify_device_pcm16(pcm, labels=None, stereo_mode: int = 0, config=None):
+    """pcm: cuda int16 [n_clips][n] or [n_clips][n][2] -> cuda int32 labels (dsp_classify_batch_pcm16_device), stream-ordered."""
+    import torch
+    if not (pcm.is_cuda and pcm.dtype == torch.int16 and pcm.dim() in (2, 3) and pcm.stride(-1) == 1):
+        raise ValueError("pcm must be an int16 CUDA tensor [n_clips][n] or [n_clips][n][2] with unit inner stride")
+    channels = 2 if pcm.dim() == 3 else 1
+    if channels == 2 and (pcm.shape[2] != 2 or pcm.stride(1) != 2 or pcm.stride(0) % 2):
+        raise ValueError("stereo pcm must be interleaved [n_clips][n][2]")
+    n_clips, n = pcm.shape[:2]
+    if labels is None:
+        labels = torch.empty(n_clips, dtype=torch.int32, device=pcm.device)
+    st = C.c_void_p(torch.cuda.current_stream(pcm.device).cuda_stream)
+    cfg = None if config is None else (config if isinstance(config, _lib.ClassifyConfig) else classify_config(config))
+    _lib.check(_lib.load().dsp_classify_batch_pcm16_device(C.byref(cfg) if cfg is not None else None, pcm.data_ptr(), n_clips, n, pcm.stride(0) // channels,
+                                                            channels, int(stereo_mode), labels.data_ptr(), st), "dsp_classify_batch_pcm16_device")
+    return labels
+
+
+def classify_release(device: int = -1) -> None:
+    _lib.check(_lib.load().dsp_classify_release(int(device)), "dsp_classify_release")
+
+
 def classify_batch_f64(clips: np.ndarray, with_trace: bool = False, config=None):
     """The float64 classifier of donut-classifier/classifier.c (:83-192) on the GPU: clips [n_clips][n] float64 (host) -> labels
     int32 (+ per-clip float64 midpoints / band sums).  config: None (the file's thresholds 0.70 / 0.85, 45 dB, 75 / 300 / 100) or a

@@ -11,7 +11,10 @@
 #include <cstdlib>
 #include <cstddef>
 #include <cstring>
+#include <chrono>
 #include <mutex>
+#include <new>
+#include <thread>
 #include <string>
 
 #include "../../include/dsp_amd.h"
@@ -660,8 +663,30 @@ struct ClassifyCtx {
     float keep_min_db = 70.0f;                             // the midpoint threshold d_tab->mp_keep_min was computed for
     bool gate_ok = false;                                  // SpecTables::gate_ok of d_tab
     std::mutex mu;
+    hipEvent_t done = nullptr;                             // recorded behind the last call's work: the workspace is free once it has fired
+    bool pending = false;
+    void wait_idle()
+    {
+        if (pending && done) (void)hipEventSynchronize(done);
+        pending = false;
+    }
 };
-ClassifyCtx g_cls;
+// One context (tables + grow-only workspace + mutex) PER DEVICE: threads that drive different GPUs from one process share nothing, and
+// a device entry point returns once its work is enqueued -- the next call on that device makes its stream wait for the event this one
+// leaves behind.  (Round 3: one process-wide context that moved between GPUs and blocked until the stream was idle.)
+constexpr int kMaxDevices = 64;
+ClassifyCtx g_cls_ctx[kMaxDevices];
+
+// leaves the "workspace busy until here" event behind the call's work on every exit
+struct ClsBusyMark {
+    ClassifyCtx &c;
+    hipStream_t st;
+    ~ClsBusyMark()
+    {
+        if (c.done && hipEventRecord(c.done, st) == hipSuccess) c.pending = true;
+        else { (void)hipGetLastError(); (void)hipStreamSynchronize(st); c.pending = false; }
+    }
+};
 
 // 957 columns = 13.4 s: a midpoint needs a cluster of >= 12 columns (0.15 s at 14 ms per column) followed by a gap of >= 4
 // (0.05 s), so 64 * 15 - 3 columns cannot hold more than the kMaxMidpoints = 64 a trace record has room for
@@ -682,23 +707,23 @@ dsp_classify_config default_classify_cfg()
 
 static_assert(sizeof(dsp::ClassifyTrace) == sizeof(dsp_classify_trace), "trace layouts must match");
 
-void cls_release();
-
-// device < 0: DSP_AMD_DEVICE or 0 (host entry points); otherwise the GPU the caller's buffers live on.  The context
-// (tables + workspace) belongs to one GPU at a time and moves when a call names another one.
-int cls_init(int device = -1)
+// the device of the host entry points: DSP_AMD_DEVICE or 0
+int cls_host_device(int &device)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback");
-    if (device < 0) {
-        const char *dev = std::getenv("DSP_AMD_DEVICE");
-        device = g_cls.d_tab ? g_cls.device : (dev ? std::atoi(dev) : 0);
-    }
-    if (device >= n) return fail(DSP_EINVAL, "device index out of range");
-    if (g_cls.d_tab && g_cls.device == device) return DSP_OK;
-    if (g_cls.d_tab) cls_release();
+    const char *dev = std::getenv("DSP_AMD_DEVICE");
+    device = dev ? std::atoi(dev) : 0;
+    if (device < 0 || device >= n || device >= kMaxDevices) return fail(DSP_EINVAL, "device index out of range");
+    return DSP_OK;
+}
+
+// tables of the context of `device` (the caller holds g_cls.mu and has made the device current)
+int cls_init(ClassifyCtx &g_cls, int device)
+{
+    if (g_cls.d_tab) return DSP_OK;
     g_cls.device = device;
-    DSP_ON_DEVICE(g_cls.device);
+    if (!g_cls.done) DSP_HIP(hipEventCreateWithFlags(&g_cls.done, hipEventDisableTiming));
     dsp::SpecTables t;
     dsp::build_spec_tables(16000, t);
     DSP_HIP(hipMalloc(&g_cls.d_tab, sizeof(t)));
@@ -725,7 +750,7 @@ int cls_init(int device = -1)
 int spec_bins(int n) { return n < dsp::kSpecSeg ? 0 : (n - dsp::kSpecSeg) / dsp::kSpecHop + 1; }
 long cls_row(int n) { return ((long)n + 3) & ~3L; }      // workspace row: n floats rounded up to 16 bytes
 
-void cls_free_workspace()
+void cls_free_workspace(ClassifyCtx &g_cls)
 {
     for (void *p : {(void *)g_cls.d_x, (void *)g_cls.d_sbp, (void *)g_cls.d_ck_bp, (void *)g_cls.d_ck_mp, (void *)g_cls.d_loud, (void *)g_cls.d_gate, (void *)g_cls.d_simd,
                     (void *)g_cls.d_mean_mp, (void *)g_cls.d_labels, (void *)g_cls.d_hits, (void *)g_cls.d_trace, (void *)g_cls.d_minmax})
@@ -735,22 +760,28 @@ void cls_free_workspace()
     g_cls.cap_clips = 0; g_cls.cap_n = 0; g_cls.cap_x = false;
 }
 
-void cls_release()
+void cls_release(ClassifyCtx &g_cls)      // (on g_cls.device, made current by the caller)
 {
-    dsp::DeviceScope dsp_device_scope_(g_cls.device);
-    hipDeviceSynchronize();
-    cls_free_workspace();
+    g_cls.wait_idle();
+    cls_free_workspace(g_cls);
     if (g_cls.d_tab) hipFree(g_cls.d_tab);
     g_cls.d_tab = nullptr;
+    if (g_cls.done) (void)hipEventDestroy(g_cls.done);
+    g_cls.done = nullptr;
+    g_cls.device = -1;
 }
 
 // workspace of one sub-batch; need_x: also a staging buffer for the clips themselves (host entry points)
-int cls_reserve(long clips, int n, bool need_x)
+int cls_reserve(ClassifyCtx &g_cls, long clips, int n, bool need_x)
 {
     if (clips <= g_cls.cap_clips && n <= g_cls.cap_n && (!need_x || g_cls.cap_x)) return DSP_OK;
-    cls_free_workspace();
+    g_cls.wait_idle();
+    need_x = need_x || g_cls.cap_x;
+    clips = std::max(clips, g_cls.cap_clips);
+    n = std::max(n, g_cls.cap_n);
+    cls_free_workspace(g_cls);
     const size_t T = (size_t)std::max(1, spec_bins(n));
-    if (need_x) DSP_HIP(hipMalloc(&g_cls.d_x, (size_t)clips * cls_row(n) * sizeof(float)));
+    if (need_x) DSP_HIP(hipMalloc(&g_cls.d_x, (size_t)clips * cls_row(n) * sizeof(float)));      // (staged int16 rows are at most as long)
     DSP_HIP(hipMalloc(&g_cls.d_sbp, (size_t)clips * dsp::kSpecBins * T * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_ck_bp, (size_t)clips * T * dsp::kCkPerSegBp * 8 * sizeof(float)));
     DSP_HIP(hipMalloc(&g_cls.d_ck_mp, (size_t)clips * T * dsp::kCkPerSegMp * 8 * sizeof(float)));
@@ -775,29 +806,30 @@ dsp::IirCoef coef_f32(double lo, double hi)
     return c;
 }
 
-// one sub-batch already resident at d_x (row stride n): labels (+ trace) into the workspace
-int cls_run(const dsp_classify_config &cfg, const float *d_x, long clips, int n, long stride, hipStream_t st, bool want_trace)
+// one sub-batch already resident at d_x (input kind `in`: 0 float, 1 / 2 / 3 int16 mono / stereo channel 0 / stereo average; row
+// stride in samples per channel): labels (+ trace) into the workspace
+int cls_run(ClassifyCtx &g_cls, const dsp_classify_config &cfg, const void *d_x, int in, long clips, int n, long stride, hipStream_t st, bool want_trace)
 {
     const dsp::IirCoef bp = coef_f32(3000, 7500), mp = coef_f32(1000, 3000);   // classifier.cpp:14-19, 438-442
     if (cfg.midpoint_db != g_cls.keep_min_db) {      // the table's threshold PSD value follows the configured dB threshold
-        DSP_HIP(hipDeviceSynchronize());             // earlier calls (other streams) may still read the old value
+        // (earlier calls on this context are ordered before this one by its event)
         DSP_HIP(dsp::launch_spec_threshold(g_cls.d_tab, cfg.midpoint_db, st));
         g_cls.keep_min_db = cfg.midpoint_db;
     }
     const dsp::ClassifyRule rule{cfg.keep_lo, cfg.keep_hi, cfg.middle_max, cfg.above_min, cfg.below_min};
     // ONE pass over the clips: both recurrences, the delay lines at every segment start, the 1000-3000 Hz segment means and
     // the energy gate.  No filtered signal is written; the spectrogram kernels recompute the segments they transform.
-    DSP_HIP(dsp::launch_iir2_ckpt(d_x, clips, n, stride, bp, mp, g_cls.d_ck_bp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, g_cls.d_tab, st, g_cls.d_simd));
+    DSP_HIP(dsp::launch_iir2_ckpt(d_x, clips, n, stride, bp, mp, g_cls.d_ck_bp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, g_cls.d_tab, st, g_cls.d_simd, in));
     // midpoints first (1000-3000 Hz map, as flags, gated frames only); the 3000-7500 Hz spectrogram and its band sums only for
     // clips that have midpoints
     DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, mp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, nullptr, g_cls.d_tab,
-                                       reinterpret_cast<float *>(g_cls.d_loud), true, st));
+                                       reinterpret_cast<float *>(g_cls.d_loud), true, st, nullptr, nullptr, in));
     // DSP_AMD_CLASSIFY_FULL_MAPS=1: every row of the listed clips' maps is stored and read (the form before the need / minmax hand-over)
     static const bool full_maps = [] { const char *e = std::getenv("DSP_AMD_CLASSIFY_FULL_MAPS"); return e && std::atoi(e) != 0; }();
     unsigned *mm = full_maps ? nullptr : g_cls.d_minmax;
     const int *need = full_maps ? nullptr : g_cls.d_loud;
     DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_loud, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, want_trace, mm));
-    DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, bp, g_cls.d_ck_bp, nullptr, nullptr, g_cls.d_hits, g_cls.d_tab, g_cls.d_sbp, false, st, need, mm));
+    DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, bp, g_cls.d_ck_bp, nullptr, nullptr, g_cls.d_hits, g_cls.d_tab, g_cls.d_sbp, false, st, need, mm, in));
     DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, rule, need, mm));
     return DSP_OK;
 }
@@ -811,10 +843,13 @@ extern "C" {
 
 int dsp_classify_division_check(long long *mismatches)
 {
-    std::lock_guard<std::mutex> lock(g_cls.mu);
-    int rc = cls_init();
+    int device = 0;
+    int rc = cls_host_device(device);
     if (rc < 0) return rc;
-    DSP_ON_DEVICE(g_cls.device);
+    ClassifyCtx &g_cls = g_cls_ctx[device];
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    DSP_ON_DEVICE(device);
+    if ((rc = cls_init(g_cls, device)) < 0) return rc;
     unsigned long long *d_bad = nullptr, bad = 0;
     int on = 0;
     DSP_HIP(hipMalloc(&d_bad, sizeof(bad)));
@@ -833,10 +868,13 @@ int dsp_butter_bandpass_filter_f32(const float *data, long n_clips, int n, long 
 {
     if (!data || !output || !b || !a || n_clips < 0 || n < 0 || (n_clips > 1 && stride < n)) return fail(DSP_EINVAL, "bad argument");
     if (n_clips == 0 || n == 0) return DSP_OK;
-    std::lock_guard<std::mutex> lock(g_cls.mu);
-    int rc = cls_init();
+    int device = 0;
+    int rc = cls_host_device(device);
     if (rc < 0) return rc;
-    DSP_ON_DEVICE(g_cls.device);
+    ClassifyCtx &g_cls = g_cls_ctx[device];
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    DSP_ON_DEVICE(device);
+    if ((rc = cls_init(g_cls, device)) < 0) return rc;
     float *dx = nullptr, *dy = nullptr;
     const size_t bytes = (size_t)n_clips * n * sizeof(float);
     DSP_HIP(hipMalloc(&dx, bytes));
@@ -856,10 +894,13 @@ int dsp_butter_bandpass_filter_f64(const double *data, long n_clips, int n, long
 {
     if (!data || !output || !b || !a || n_clips < 0 || n < 0 || (n_clips > 1 && stride < n)) return fail(DSP_EINVAL, "bad argument");
     if (n_clips == 0 || n == 0) return DSP_OK;
-    std::lock_guard<std::mutex> lock(g_cls.mu);
-    int rc = cls_init();
+    int device = 0;
+    int rc = cls_host_device(device);
     if (rc < 0) return rc;
-    DSP_ON_DEVICE(g_cls.device);
+    ClassifyCtx &g_cls = g_cls_ctx[device];
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    DSP_ON_DEVICE(device);
+    if ((rc = cls_init(g_cls, device)) < 0) return rc;
     double *dx = nullptr, *dy = nullptr;
     const size_t bytes = (size_t)n_clips * n * sizeof(double);
     DSP_HIP(hipMalloc(&dx, bytes));
@@ -883,10 +924,13 @@ int dsp_compute_spectrogram_f32(const float *signal, int n, int fs, float *frequ
     if (times)
         for (int t = 0; t < T; ++t) times[t] = ((float)(t * dsp::kSpecHop + dsp::kSpecSeg / 2)) / (float)fs;     // :254-258
     if (T == 0) return 0;
-    std::lock_guard<std::mutex> lock(g_cls.mu);
-    int rc = cls_init();
+    int device = 0;
+    int rc = cls_host_device(device);
     if (rc < 0) return rc;
-    DSP_ON_DEVICE(g_cls.device);
+    ClassifyCtx &g_cls = g_cls_ctx[device];
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    DSP_ON_DEVICE(device);
+    if ((rc = cls_init(g_cls, device)) < 0) return rc;
     float *dx = nullptr, *ds = nullptr;
     dsp::SpecTables *dt = nullptr;               // fs enters only through the PSD scale U = fs * sum w^2 (classifier.cpp:296-301)
     DSP_HIP(hipMalloc(&dx, (size_t)n * sizeof(float)));
@@ -917,10 +961,13 @@ int dsp_compute_spectrogram_f64(const double *signal, int n, int fs, double *fre
     if (times)
         for (int t = 0; t < T; ++t) times[t] = (double)(t * dsp::kSpecHop + dsp::kSpecSeg / 2) / fs;                    // :474-478
     if (T == 0) return 0;
-    std::lock_guard<std::mutex> lock(g_cls.mu);
-    int rc = cls_init();
+    int device = 0;
+    int rc = cls_host_device(device);
     if (rc < 0) return rc;
-    DSP_ON_DEVICE(g_cls.device);
+    ClassifyCtx &g_cls = g_cls_ctx[device];
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    DSP_ON_DEVICE(device);
+    if ((rc = cls_init(g_cls, device)) < 0) return rc;
     double *dx = nullptr, *ds = nullptr;
     DSP_HIP(hipMalloc(&dx, (size_t)n * sizeof(double)));
     const size_t sb = (size_t)dsp::kSpecBins * T * sizeof(double);
@@ -960,10 +1007,13 @@ int dsp_sum_intense_f32(float lower, float upper, float half_range, const float 
                         const float *times, int time_bins, const float *db, float midpoint, float *out)
 {
     if (!frequencies || !times || !db || !out || freq_bins <= 0 || time_bins <= 0) return fail(DSP_EINVAL, "bad argument");
-    std::lock_guard<std::mutex> lock(g_cls.mu);
-    int rc = cls_init();
+    int device = 0;
+    int rc = cls_host_device(device);
     if (rc < 0) return rc;
-    DSP_ON_DEVICE(g_cls.device);
+    ClassifyCtx &g_cls = g_cls_ctx[device];
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    DSP_ON_DEVICE(device);
+    if ((rc = cls_init(g_cls, device)) < 0) return rc;
     const size_t nf = freq_bins, nt = time_bins, total = nf + nt + nf * nt + 1;
     float *d = nullptr;
     DSP_HIP(hipMalloc(&d, total * sizeof(float)));
@@ -982,8 +1032,19 @@ void dsp_classify_default_config(dsp_classify_config *cfg)
     if (cfg) *cfg = default_classify_cfg();
 }
 
-int dsp_classify_batch_host_cfg(const dsp_classify_config *cfgp, const float *signal, long n_clips, int n, long stride, int *labels,
-                                dsp_classify_trace *trace)
+namespace {
+
+int cls_bytes(int in) { return in == 0 ? 4 : (in == 1 ? 2 : 4); }     // bytes per sample, all channels
+
+int cls_input_kind(int channels, int stereo_mode, int &in)
+{
+    if (channels != 1 && channels != 2) return fail(DSP_EINVAL, "channels must be 1 or 2");
+    if (channels == 2 && stereo_mode != DSP_STEREO_CHANNEL0 && stereo_mode != DSP_STEREO_AVERAGE) return fail(DSP_EINVAL, "bad stereo_mode");
+    in = channels == 1 ? 1 : (stereo_mode == DSP_STEREO_CHANNEL0 ? 2 : 3);
+    return DSP_OK;
+}
+
+int cls_host_entry(const dsp_classify_config *cfgp, const void *signal, int in, long n_clips, int n, long stride, int *labels, dsp_classify_trace *trace)
 {
     if (!signal || !labels || n_clips < 0 || n < 0 || (n_clips > 1 && stride < n)) return fail(DSP_EINVAL, "bad argument");
     const dsp_classify_config cfg = cfgp ? *cfgp : default_classify_cfg();
@@ -994,19 +1055,151 @@ int dsp_classify_batch_host_cfg(const dsp_classify_config *cfgp, const float *si
         if (trace) std::memset(trace, 0, sizeof(*trace) * (size_t)n_clips);
         return DSP_OK;
     }
-    std::lock_guard<std::mutex> lock(g_cls.mu);
-    int rc = cls_init();
+    int device = 0;
+    int rc = cls_host_device(device);
     if (rc < 0) return rc;
-    DSP_ON_DEVICE(g_cls.device);
+    ClassifyCtx &g_cls = g_cls_ctx[device];
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    DSP_ON_DEVICE(device);
+    if ((rc = cls_init(g_cls, device)) < 0) return rc;
+    const int bps = cls_bytes(in);
+    const long row = (((long)n * bps + 15) & ~15L) / bps;            // staged rows start on 16 bytes
+    if ((rc = cls_reserve(g_cls, std::min(kClsSubBatch, n_clips), n, true)) < 0) return rc;
+    g_cls.wait_idle();                                               // the staging buffer is written by copies on the null stream
+    ClsBusyMark mark{g_cls, nullptr};
     for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
         const long cnt = std::min(kClsSubBatch, n_clips - c0);
-        if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n, true)) < 0) return rc;
-        DSP_HIP(hipMemcpy2DAsync(g_cls.d_x, (size_t)cls_row(n) * sizeof(float), signal + c0 * stride, (size_t)stride * sizeof(float),
-                                 (size_t)n * sizeof(float), cnt, hipMemcpyHostToDevice, nullptr));
-        if ((rc = cls_run(cfg, g_cls.d_x, cnt, n, cls_row(n), nullptr, trace != nullptr)) < 0) return rc;
+        DSP_HIP(hipMemcpy2DAsync(g_cls.d_x, (size_t)row * bps, static_cast<const unsigned char *>(signal) + (size_t)c0 * stride * bps, (size_t)stride * bps,
+                                 (size_t)n * bps, cnt, hipMemcpyHostToDevice, nullptr));
+        if ((rc = cls_run(g_cls, cfg, g_cls.d_x, in, cnt, n, row, nullptr, trace != nullptr)) < 0) return rc;
         DSP_HIP(hipMemcpyAsync(labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, nullptr));
         if (trace) DSP_HIP(hipMemcpyAsync(trace + c0, g_cls.d_trace, (size_t)cnt * sizeof(dsp::ClassifyTrace), hipMemcpyDeviceToHost, nullptr));
         DSP_HIP(hipStreamSynchronize(nullptr));
+    }
+    return DSP_OK;
+}
+
+int cls_device_entry(const dsp_classify_config *cfgp, const void *d_signal, int in, long n_clips, int n, long stride, int *d_labels, void *stream,
+                     ClassifyCtx *own = nullptr)
+{
+    if (!d_signal || !d_labels || n_clips < 0 || n < 0 || (n_clips > 1 && stride < n)) return fail(DSP_EINVAL, "bad argument");
+    const dsp_classify_config cfg = cfgp ? *cfgp : default_classify_cfg();
+    if (!valid_classify_cfg(cfg)) return fail(DSP_EINVAL, "classify config: thresholds must be finite with keep_lo < keep_hi");
+    if (spec_bins(n) > kMaxSpecColumns) return fail(DSP_EINVAL, "clip too long (more than 957 spectrogram columns = 13.4 s at 16 kHz)");
+    if (n_clips == 0) return DSP_OK;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, d_signal) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(DSP_EINVAL, "signal is not a device pointer");
+    }
+    if (attr.device < 0 || attr.device >= kMaxDevices) return fail(DSP_EINVAL, "device index out of range");
+    if (own && own->device >= 0 && own->device != attr.device) return fail(DSP_EINVAL, "the context belongs to another device than the signal");
+    ClassifyCtx &g_cls = own ? *own : g_cls_ctx[attr.device];
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    DSP_ON_DEVICE(attr.device);
+    int rc = cls_init(g_cls, attr.device);
+    if (rc < 0) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (spec_bins(n) == 0) { DSP_HIP(hipMemsetAsync(d_labels, 0, (size_t)n_clips * sizeof(int), st)); return DSP_OK; }
+    if ((rc = cls_reserve(g_cls, std::min(kClsSubBatch, n_clips), n, false)) < 0) return rc;
+    if (g_cls.pending) DSP_HIP(hipStreamWaitEvent(st, g_cls.done, 0));      // the previous call's work on this workspace (any stream)
+    ClsBusyMark mark{g_cls, st};
+    for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
+        const long cnt = std::min(kClsSubBatch, n_clips - c0);
+        const void *src = static_cast<const unsigned char *>(d_signal) + (size_t)c0 * stride * cls_bytes(in);
+        if ((rc = cls_run(g_cls, cfg, src, in, cnt, n, stride, st, false)) < 0) return rc;
+        DSP_HIP(hipMemcpyAsync(d_labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, st));
+    }
+    return DSP_OK;
+}
+
+}  // namespace
+
+int dsp_classify_batch_host_cfg(const dsp_classify_config *cfgp, const float *signal, long n_clips, int n, long stride, int *labels,
+                                dsp_classify_trace *trace)
+{
+    return cls_host_entry(cfgp, signal, 0, n_clips, n, stride, labels, trace);
+}
+
+int dsp_classify_batch_pcm16_host(const dsp_classify_config *cfgp, const int16_t *pcm, long n_clips, int n, long stride, int channels, int stereo_mode,
+                                  int *labels, dsp_classify_trace *trace)
+{
+    int in = 0;
+    const int rc = cls_input_kind(channels, stereo_mode, in);
+    return rc < 0 ? rc : cls_host_entry(cfgp, pcm, in, n_clips, n, stride, labels, trace);
+}
+
+int dsp_classify_batch_pcm16_device(const dsp_classify_config *cfgp, const int16_t *d_pcm, long n_clips, int n, long stride, int channels,
+                                    int stereo_mode, int *d_labels, void *stream)
+{
+    int in = 0;
+    const int rc = cls_input_kind(channels, stereo_mode, in);
+    return rc < 0 ? rc : cls_device_entry(cfgp, d_pcm, in, n_clips, n, stride, d_labels, stream);
+}
+
+/* A context of the caller's own: the default entry points share one workspace per device, so two calls on one device run one behind
+ * the other; calls through different contexts (on different streams) may overlap. */
+struct dsp_classify_ctx { ClassifyCtx c; int device; };
+
+int dsp_classify_ctx_create(int device, dsp_classify_ctx **out)
+{
+    if (!out) return fail(DSP_EINVAL, "bad argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback");
+    if (device < 0 || device >= n || device >= kMaxDevices) return fail(DSP_EINVAL, "device index out of range");
+    auto *ctx = new (std::nothrow) dsp_classify_ctx;
+    if (!ctx) return fail(DSP_ENOMEM, "out of memory");
+    ctx->device = device;
+    {
+        std::lock_guard<std::mutex> lock(ctx->c.mu);
+        DSP_ON_DEVICE(device);
+        const int rc = cls_init(ctx->c, device);
+        if (rc < 0) { cls_release(ctx->c); delete ctx; return rc; }
+    }
+    *out = ctx;
+    return DSP_OK;
+}
+
+void dsp_classify_ctx_destroy(dsp_classify_ctx *ctx)
+{
+    if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lock(ctx->c.mu);
+        dsp::DeviceScope on(ctx->device);
+        cls_release(ctx->c);
+    }
+    delete ctx;
+}
+
+int dsp_classify_batch_device_ctx(dsp_classify_ctx *ctx, const dsp_classify_config *cfgp, const float *d_signal, long n_clips, int n, long stride,
+                                  int *d_labels, void *stream)
+{
+    if (!ctx) return fail(DSP_EINVAL, "bad argument");
+    return cls_device_entry(cfgp, d_signal, 0, n_clips, n, stride, d_labels, stream, &ctx->c);
+}
+
+/* Test hook (no HIP call): holds the default classifier context of `device` for hold_ms milliseconds.  tests/test_capi_cpu.py runs it
+ * from two threads: on two devices the holds overlap, on one device they queue. */
+int dsp_debug_hold_classify_ctx(int device, int hold_ms)
+{
+    if (device < 0 || device >= kMaxDevices || hold_ms < 0 || hold_ms > 10000) return fail(DSP_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lock(g_cls_ctx[device].mu);
+    std::this_thread::sleep_for(std::chrono::milliseconds(hold_ms));
+    return DSP_OK;
+}
+
+int dsp_classify_release(int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 0; }
+    for (int d = 0; d < kMaxDevices && d < count; ++d) {
+        if (device >= 0 && d != device) continue;
+        ClassifyCtx &g_cls = g_cls_ctx[d];
+        std::lock_guard<std::mutex> lock(g_cls.mu);
+        if (g_cls.device < 0) continue;
+        DSP_ON_DEVICE(d);
+        cls_release(g_cls);
     }
     return DSP_OK;
 }
@@ -1019,30 +1212,7 @@ int dsp_classify_batch_host(const float *signal, long n_clips, int n, long strid
 int dsp_classify_batch_device_cfg(const dsp_classify_config *cfgp, const float *d_signal, long n_clips, int n, long stride,
                                   int *d_labels, void *stream)
 {
-    if (!d_signal || !d_labels || n_clips < 0 || n < 0 || (n_clips > 1 && stride < n)) return fail(DSP_EINVAL, "bad argument");
-    const dsp_classify_config cfg = cfgp ? *cfgp : default_classify_cfg();
-    if (!valid_classify_cfg(cfg)) return fail(DSP_EINVAL, "classify config: thresholds must be finite with keep_lo < keep_hi");
-    if (spec_bins(n) > kMaxSpecColumns) return fail(DSP_EINVAL, "clip too long (more than 957 spectrogram columns = 13.4 s at 16 kHz)");
-    if (n_clips == 0) return DSP_OK;
-    std::lock_guard<std::mutex> lock(g_cls.mu);
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, d_signal) != hipSuccess || attr.type != hipMemoryTypeDevice) {
-        (void)hipGetLastError();
-        return fail(DSP_EINVAL, "signal is not a device pointer");
-    }
-    int rc = cls_init(attr.device);
-    if (rc < 0) return rc;
-    DSP_ON_DEVICE(g_cls.device);
-    hipStream_t st = (hipStream_t)stream;
-    if (spec_bins(n) == 0) { DSP_HIP(hipMemsetAsync(d_labels, 0, (size_t)n_clips * sizeof(int), st)); DSP_HIP(hipStreamSynchronize(st)); return DSP_OK; }
-    for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
-        const long cnt = std::min(kClsSubBatch, n_clips - c0);
-        if ((rc = cls_reserve(std::min(kClsSubBatch, n_clips), n, false)) < 0) return rc;
-        if ((rc = cls_run(cfg, d_signal + c0 * stride, cnt, n, stride, st, false)) < 0) return rc;
-        DSP_HIP(hipMemcpyAsync(d_labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, st));
-    }
-    DSP_HIP(hipStreamSynchronize(st));      // the workspace is shared: it must be idle before the lock is released
-    return DSP_OK;
+    return cls_device_entry(cfgp, d_signal, 0, n_clips, n, stride, d_labels, stream);
 }
 
 int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long stride, int *d_labels, void *stream)

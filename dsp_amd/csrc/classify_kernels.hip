@@ -427,12 +427,47 @@ hipError_t launch_iir_f32(const float *x, long n_clips, int n, long stride, cons
 // (tools/ab_classify.py, interleaved): three waves 2.58 ms, packed pair 2.79 ms, two SCALAR chains in one wave 2.85 ms.  What limits
 // a recurrence wave is how often ONE wave gets to issue (16 operations per ~110-cycle sample step, ~7 cycles apiece whatever their
 // dependencies); a packed operation issues for twice as long, so one wave doing both filters is slower than two waves doing one each.
+// ---- int16 PCM in the classifier kernels' loads (SURVEY 8f-1's second reader): IN = 0 float samples, 1 int16 mono (s / 32768,
+// sync/sync.cpp:237-242, donut-classifier/classifier.c:55-59), 2 interleaved int16 stereo, channel 0 (classifier.c:286-297), 3 stereo,
+// (L + R) / 65536 (the average of the channels' s / 32768, main_test.c:205-217: exact in float for |L + R| < 2^24).  The conversions are
+// exact, so the kernels see the float path's values bit for bit.  A 16-byte piece holds 4 / 8 / 4 / 4 samples.
+typedef unsigned cls_u4 __attribute__((ext_vector_type(4)));
+template <int IN> struct ClsIn { static constexpr int kBytes = IN == 0 ? 4 : (IN == 1 ? 2 : 4), kPerPiece = 16 / kBytes; };
+template <int IN>
+__device__ __forceinline__ void cls_piece_to_float(const cls_u4 &q, float (&o)[ClsIn<IN>::kPerPiece])
+{
+    if constexpr (IN == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = __uint_as_float(q[k]);
+    } else if constexpr (IN == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[2 * k] = (float)(int)(short)(q[k] & 0xffffu) * (1.0f / 32768.0f);
+            o[2 * k + 1] = (float)((int)q[k] >> 16) * (1.0f / 32768.0f);
+        }
+    } else if constexpr (IN == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (float)(int)(short)(q[k] & 0xffffu) * (1.0f / 32768.0f);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (float)((int)(short)(q[k] & 0xffffu) + ((int)q[k] >> 16)) * (1.0f / 65536.0f);
+    }
+}
+template <int IN>
+__device__ __forceinline__ float cls_sample_at(const void *__restrict__ x, long idx)
+{
+    if constexpr (IN == 0) return reinterpret_cast<const float *>(x)[idx];
+    else if constexpr (IN == 1) return (float)reinterpret_cast<const short *>(x)[idx] * (1.0f / 32768.0f);
+    else if constexpr (IN == 2) return (float)reinterpret_cast<const short *>(x)[2 * idx] * (1.0f / 32768.0f);
+    else return (float)((int)reinterpret_cast<const short *>(x)[2 * idx] + (int)reinterpret_cast<const short *>(x)[2 * idx + 1]) * (1.0f / 65536.0f);
+}
+
 #ifndef DSP_CKPT_DUAL
 #define DSP_CKPT_DUAL 0
 #endif
 typedef float ck_f2 __attribute__((ext_vector_type(2)));
-template <bool EVEN_B, bool DUAL>
-__global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride,
+template <bool EVEN_B, bool DUAL, int IN = 0>
+__global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const void *__restrict__ xv, long n_clips, int n, long stride,
                                                         const IirCoef c_bp, const IirCoef c_mp, float *__restrict__ ck_bp,
                                                         float *__restrict__ ck_mp, float *__restrict__ means_mp,
                                                         int *__restrict__ want_mp, const SpecTables *__restrict__ tab, int vec_ok, int *__restrict__ simd_load,
@@ -518,27 +553,31 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float
     // x tiles: the 128 recurrence threads load them (4 float4 each per full tile), one tile ahead in registers.  (Two tiles
     // ahead in a second register set measured slower, 1.50 vs 1.34 ms per 49 152 clips: the kernel is bound by VALU issue --
     // 17 + 17 + ~26 instructions per sample and clip --, not by the load latency.)
-    constexpr int CH = IIR_TS / 4, NV = 64 * CH / 128;
-    float4 pre[NV];
+    // (a tile row is IIR_TS samples = 8 / 4 / 8 / 8 16-byte pieces for IN = 0 / 1 / 2 / 3)
+    constexpr int PP = ClsIn<IN>::kPerPiece, CH = IIR_TS / PP, NV = 64 * CH / 128;
+    cls_u4 pre[NV];
     auto issue = [&](int t0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * 4;
-            pre[k] = r < rows ? *reinterpret_cast<const float4 *>(x + (clip0 + r) * stride + t0 + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * PP;
+            pre[k] = r < rows ? *reinterpret_cast<const cls_u4 *>(reinterpret_cast<const unsigned char *>(xv) + ((clip0 + r) * stride + t0 + cc) * ClsIn<IN>::kBytes)
+                              : cls_u4{0u, 0u, 0u, 0u};
         }
     };
     auto commit = [&](float *dst) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * 4;
-            dst[r * IIR_LD + cc] = pre[k].x; dst[r * IIR_LD + cc + 1] = pre[k].y;
-            dst[r * IIR_LD + cc + 2] = pre[k].z; dst[r * IIR_LD + cc + 3] = pre[k].w;
+            const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * PP;
+            float o[PP];
+            cls_piece_to_float<IN>(pre[k], o);
+#pragma unroll
+            for (int i = 0; i < PP; ++i) dst[r * IIR_LD + cc + i] = o[i];
         }
     };
     auto load_scalar = [&](int t0, int cols, float *dst) {        // short last tile, or rows that are not 16-byte aligned
         for (int e = tid; e < 64 * IIR_TS; e += 128) {
             const int r = e / IIR_TS, ci = e % IIR_TS;
-            dst[r * IIR_LD + ci] = (r < rows && ci < cols) ? x[(clip0 + r) * stride + t0 + ci] : 0.0f;
+            dst[r * IIR_LD + ci] = (r < rows && ci < cols) ? cls_sample_at<IN>(reinterpret_cast<const unsigned char *>(xv) + (clip0 + r) * stride * ClsIn<IN>::kBytes, t0 + ci) : 0.0f;
         }
     };
     auto tile_cols = [&](int s) { const int t0 = s * IIR_TS; return n - t0 < IIR_TS ? n - t0 : IIR_TS; };
@@ -714,9 +753,9 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const float
 
 static bool even_taps_only(const IirCoef &c) { return c.b[1] == 0.0f && c.b[3] == 0.0f && c.b[5] == 0.0f && c.b[7] == 0.0f; }
 
-hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
+hipError_t launch_iir2_ckpt(const void *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
                             float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream,
-                            int *simd_load)
+                            int *simd_load, int in_kind)
 {
     // DSP_AMD_CKPT_SIMD_AWARE: 0 = fixed parts (A/B runs), 2 = the table for every launch whatever its size (tests)
     static const int simd_mode = [] { const char *e = std::getenv("DSP_AMD_CKPT_SIMD_AWARE"); return e ? std::atoi(e) : 1; }();
@@ -737,14 +776,20 @@ hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, co
         hipError_t e = hipMemsetAsync(want_mp, 0, sizeof(int), stream);
         if (e != hipSuccess) return e;
     }
-    const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    const int bytes = in_kind == 0 ? 4 : (in_kind == 1 ? 2 : 4);
+    const int vec_ok = (stride * bytes) % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
     constexpr bool dual = DSP_CKPT_DUAL != 0;
-    if (even_taps_only(c_mp))
-        hipLaunchKernelGGL((iir2_ckpt_kernel<true, dual>), dim3(blocks), dim3(dual ? 128 : 192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp,
-                           means_mp, want_mp, tables, vec_ok, simd_load, blocks / n_cu);
-    else
-        hipLaunchKernelGGL((iir2_ckpt_kernel<false, dual>), dim3(blocks), dim3(dual ? 128 : 192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp,
-                           means_mp, want_mp, tables, vec_ok, simd_load, blocks / n_cu);
+#define DSP_CKPT_LAUNCH(E, D, I)                                                                                                          \
+    hipLaunchKernelGGL((iir2_ckpt_kernel<E, D, I>), dim3(blocks), dim3(D ? 128 : 192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, \
+                       means_mp, want_mp, tables, vec_ok, simd_load, blocks / n_cu)
+    const bool even = even_taps_only(c_mp);
+    if (in_kind == 0) { if (even) DSP_CKPT_LAUNCH(true, dual, 0); else DSP_CKPT_LAUNCH(false, dual, 0); }
+    else if (!even) return hipErrorInvalidValue;                     // int16 input: the literal tables' even numerators only
+    else if (in_kind == 1) DSP_CKPT_LAUNCH(true, false, 1);
+    else if (in_kind == 2) DSP_CKPT_LAUNCH(true, false, 2);
+    else if (in_kind == 3) DSP_CKPT_LAUNCH(true, false, 3);
+    else return hipErrorInvalidValue;
+#undef DSP_CKPT_LAUNCH
     return hipGetLastError();
 }
 
@@ -1167,8 +1212,8 @@ __device__ __forceinline__ float wave_maxf(float v)
 // is being read from the work list -- phase L of a group is then only the LDS stores (in-kernel stamps of round 2: L took 9.6 k of a
 // block's 56 k cycles, plus the exposed latency of the restart-state loads inside R).  With two restart states per segment (kCkPerSegBp) phase R runs as two
 // 128-sample chains on waves 0 and 1 (restart states at the segment start and at its middle) instead of one 256-sample chain.
-template <int OUT, bool EVEN_B>
-__global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void spec_from_ckpt_kernel(const float *__restrict__ x, long n_clips, int n, long stride, const IirCoef c,
+template <int OUT, bool EVEN_B, int IN = 0>
+__global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4))) void spec_from_ckpt_kernel(const void *__restrict__ xv, long n_clips, int n, long stride, const IirCoef c,
                                                              const float *__restrict__ ck, const float *__restrict__ means,
                                                              const int *__restrict__ wantlist, const int *__restrict__ hits,
                                                              const SpecTables *__restrict__ tab, float *__restrict__ out, int T, int vec_ok,
@@ -1212,9 +1257,10 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     };
     // the loads of a group: its x rows (one wave-instruction = one row = 1 KB contiguous; every load of the block in flight
     // together), the restart states (waves 0 .. kCkPerSeg - 1, lane per frame) and the segment means (flags; wave 0)
+    // (int16 input: a lane's four samples are 8 bytes of a mono row, 16 of a stereo one; converted when they reach the LDS rows)
     constexpr int PER_ROW = kSpecSeg / 4, NL = (RC_FRAMES * PER_ROW + RC_THREADS - 1) / RC_THREADS;
     static_assert(PER_ROW == 64, "one wave-instruction loads one row");
-    float4 v4[NL];
+    cls_u4 v4[NL];
     float4 ckv[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     float mean_pre = 0.0f;
     int need_pre = 1;
@@ -1225,11 +1271,15 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int e = threadIdx.x + RC_THREADS * i, r = e / PER_ROW, c4 = (e % PER_ROW) * 4;      // r is wave-uniform
-            if (r >= RC_FRAMES) { v4[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            if (r >= RC_FRAMES) { v4[i] = cls_u4{0u, 0u, 0u, 0u}; continue; }
             const int rclip = __builtin_amdgcn_readlane(iclip, r);
-            const float *xs = x + (long)(rclip < 0 ? 0 : rclip) * stride + (long)__builtin_amdgcn_readlane(it, r) * kSpecHop + c4;     // unwanted slots: clip 0, t 0
-            if (vec_ok) v4[i] = *reinterpret_cast<const float4 *>(xs);
-            else v4[i] = make_float4(xs[0], xs[1], xs[2], xs[3]);
+            const long s0 = (long)(rclip < 0 ? 0 : rclip) * stride + (long)__builtin_amdgcn_readlane(it, r) * kSpecHop + c4;     // unwanted slots: clip 0, t 0
+            const unsigned char *xs = reinterpret_cast<const unsigned char *>(xv) + s0 * ClsIn<IN>::kBytes;
+            if (IN == 1) {
+                if (vec_ok) { const uint2 q = *reinterpret_cast<const uint2 *>(xs); v4[i] = cls_u4{q.x, q.y, 0u, 0u}; }
+                else { const unsigned short *h = reinterpret_cast<const unsigned short *>(xs); v4[i] = cls_u4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16), 0u, 0u}; }
+            } else if (vec_ok) v4[i] = *reinterpret_cast<const cls_u4 *>(xs);
+            else { const unsigned *w = reinterpret_cast<const unsigned *>(xs); v4[i] = cls_u4{w[0], w[1], w[2], w[3]}; }
         }
         if (role < kCkPerSeg && iclip >= 0) {
             const float4 *src = reinterpret_cast<const float4 *>(ck + (((long)iclip * T + it) * kCkPerSeg + role) * 8);
@@ -1260,7 +1310,14 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
             const int e = threadIdx.x + RC_THREADS * i, r = e / PER_ROW, c4 = (e % PER_ROW) * 4;
             if (r >= RC_FRAMES) continue;
             float *dst = rows + r * RC_ROW + 8 + c4;
-            dst[0] = v4[i].x; dst[1] = v4[i].y; dst[2] = v4[i].z; dst[3] = v4[i].w;
+            if (IN == 1) {
+                dst[0] = (float)(int)(short)(v4[i][0] & 0xffffu) * (1.0f / 32768.0f); dst[1] = (float)((int)v4[i][0] >> 16) * (1.0f / 32768.0f);
+                dst[2] = (float)(int)(short)(v4[i][1] & 0xffffu) * (1.0f / 32768.0f); dst[3] = (float)((int)v4[i][1] >> 16) * (1.0f / 32768.0f);
+            } else {
+                float o[4];
+                cls_piece_to_float<IN == 1 ? 0 : IN>(v4[i], o);
+                dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+            }
         }
         float d[8] = {ckv[0].x, ckv[0].y, ckv[0].z, ckv[0].w, ckv[1].x, ckv[1].y, ckv[1].z, ckv[1].w};
         const float mean_ck = mean_pre;
@@ -1444,9 +1501,9 @@ static int rc_resident_blocks()
     return cached;
 }
 
-hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
+hipError_t launch_spec_from_ckpt(const void *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
                                  const int *wantlist, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream,
-                                 const int *need, unsigned *minmax)
+                                 const int *need, unsigned *minmax, int in_kind)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0 || T <= 0) return hipSuccess;
@@ -1458,14 +1515,24 @@ hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long strid
         const dim3 grid((unsigned)std::min<long>(groups, resident));
         hipLaunchKernelGGL(kernel, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wl, hl, tables, out, T, vec_ok, need, minmax);
     };
+    const bool even = even_taps_only(c);
+    if (in_kind != 0 && (!even || in_kind < 0 || in_kind > 3)) return hipErrorInvalidValue;      // int16 input: the literal tables' even numerators only
     if (flags) {
         hipError_t e = hipMemsetAsync(out, 0, (size_t)total * sizeof(int), stream);      // frames not on the list are not loud
         if (e != hipSuccess) return e;
-        if (even_taps_only(c)) launch(spec_from_ckpt_kernel<SPEC_FLAGS, true>, rc_resident_blocks<SPEC_FLAGS, true>(), wantlist, (const int *)nullptr);
-        else launch(spec_from_ckpt_kernel<SPEC_FLAGS, false>, rc_resident_blocks<SPEC_FLAGS, false>(), wantlist, (const int *)nullptr);
+        const int res = even ? rc_resident_blocks<SPEC_FLAGS, true>() : rc_resident_blocks<SPEC_FLAGS, false>();
+        if (in_kind == 1) launch(spec_from_ckpt_kernel<SPEC_FLAGS, true, 1>, res, wantlist, (const int *)nullptr);
+        else if (in_kind == 2) launch(spec_from_ckpt_kernel<SPEC_FLAGS, true, 2>, res, wantlist, (const int *)nullptr);
+        else if (in_kind == 3) launch(spec_from_ckpt_kernel<SPEC_FLAGS, true, 3>, res, wantlist, (const int *)nullptr);
+        else if (even) launch(spec_from_ckpt_kernel<SPEC_FLAGS, true>, res, wantlist, (const int *)nullptr);
+        else launch(spec_from_ckpt_kernel<SPEC_FLAGS, false>, res, wantlist, (const int *)nullptr);
     } else {
-        if (even_taps_only(c)) launch(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, true>, rc_resident_blocks<SPEC_FRAME_MAJOR, true>(), (const int *)nullptr, hits);
-        else launch(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, false>, rc_resident_blocks<SPEC_FRAME_MAJOR, false>(), (const int *)nullptr, hits);
+        const int res = even ? rc_resident_blocks<SPEC_FRAME_MAJOR, true>() : rc_resident_blocks<SPEC_FRAME_MAJOR, false>();
+        if (in_kind == 1) launch(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, true, 1>, res, (const int *)nullptr, hits);
+        else if (in_kind == 2) launch(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, true, 2>, res, (const int *)nullptr, hits);
+        else if (in_kind == 3) launch(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, true, 3>, res, (const int *)nullptr, hits);
+        else if (even) launch(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, true>, res, (const int *)nullptr, hits);
+        else launch(spec_from_ckpt_kernel<SPEC_FRAME_MAJOR, false>, res, (const int *)nullptr, hits);
     }
     return hipGetLastError();
 }

@@ -78,18 +78,20 @@ hipError_t launch_iir_f64_on_f32(const float *x, long n_clips, int n, long strid
 // simd_load (optional, kSimdLoadCus * kSimdLoadStride ints, zeroed by the launch): per (XCC, SE, SH, CU) the waves of this launch on
 // each SIMD + a block counter; lets every block put its taps wave on its CU's most loaded SIMD (scheduling only, see the kernel).
 constexpr int kSimdLoadCus = 4096, kSimdLoadStride = 8;
-hipError_t launch_iir2_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
+// in_kind: 0 = float samples, 1 = int16 mono (s / 32768), 2 = interleaved int16 stereo channel 0, 3 = stereo (L + R) / 65536; stride
+// counts samples per channel; converted in the kernels' loads (exact: the float path's bits)
+hipError_t launch_iir2_ckpt(const void *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
                             float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream,
-                            int *simd_load = nullptr);
+                            int *simd_load = nullptr, int in_kind = 0);
 // Spectrogram of segments recomputed from those checkpoints (filter c, checkpoints ck: ck_mp's layout for flags = true, ck_bp's
 // otherwise).  flags = true: out = int loud[c][T]
 // (1 = some cell >= mp_keep_min; 0 for every segment not on `wantlist`), means = means_mp; flags = false: out = PSD
 // [c][T][129] of every segment of the clips on the work list `hits` (means computed here) -- with need / minmax (optional, flags =
 // false): only the rows with need[c][t] != 0 are stored, and minmax[c][2] receives the float bits of the smallest / largest positive
 // cell over ALL transformed rows of clip c (atomicMin / atomicMax: the caller resets them to +inf / 0; launch_classify_midpoints does).
-hipError_t launch_spec_from_ckpt(const float *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
+hipError_t launch_spec_from_ckpt(const void *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
                                  const int *wantlist, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream,
-                                 const int *need = nullptr, unsigned *minmax = nullptr);
+                                 const int *need = nullptr, unsigned *minmax = nullptr, int in_kind = 0);
 
 // sxx[c][129][T] (T = (n-256)/224+1) of clip rows y[c][0..n)
 struct ClassifyTrace {           // per clip, for parity tests

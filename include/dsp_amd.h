@@ -201,8 +201,10 @@ typedef struct dsp_classify_trace {
 } dsp_classify_trace;
 
 /* classify() over n_clips clips of n samples (row stride in floats).  labels[n_clips];
- * trace may be NULL.  _host: host pointers; _device: HBM pointers, enqueued on `stream`
- * and synchronised before returning (the workspace is reused across calls).       */
+ * trace may be NULL.  _host: host pointers, blocking.  _device: HBM pointers, STREAM-ORDERED: the call returns once
+ * its work is enqueued on `stream`; the labels are valid when the stream reaches that point.  The library keeps one
+ * grow-only workspace per device (42 KB per one-second clip of the largest pass; dsp_classify_release frees it): calls
+ * on one device are ordered one behind the other whatever their streams, calls on different devices share nothing.  */
 int dsp_classify_batch_host(const float *signal, long n_clips, int n, long stride, int *labels,
                             dsp_classify_trace *trace);
 int dsp_classify_batch_device(const float *d_signal, long n_clips, int n, long stride, int *d_labels,
@@ -227,6 +229,25 @@ int dsp_classify_batch_host_cfg(const dsp_classify_config *cfg, const float *sig
                                 int *labels, dsp_classify_trace *trace);
 int dsp_classify_batch_device_cfg(const dsp_classify_config *cfg, const float *d_signal, long n_clips, int n, long stride,
                                   int *d_labels, void *stream);
+/* The same on int16 PCM, mono or interleaved stereo (DSP_STEREO_CHANNEL0 / DSP_STEREO_AVERAGE as dsp_mfcc_clips_pcm16_device),
+ * converted in the kernels' loads exactly like the reference's capture loop and readers (sync/sync.cpp:237-242 pcmSample / 32768.0,
+ * donut-classifier/classifier.c:55-59, :286-297; the average as main_test.c:205-217): bit-identical to the float entry points on the
+ * same samples at half the input bytes.  n and stride count samples PER CHANNEL.                                              */
+int dsp_classify_batch_pcm16_host(const dsp_classify_config *cfg, const int16_t *pcm, long n_clips, int n, long stride, int channels,
+                                  int stereo_mode, int *labels, dsp_classify_trace *trace);
+int dsp_classify_batch_pcm16_device(const dsp_classify_config *cfg, const int16_t *d_pcm, long n_clips, int n, long stride, int channels,
+                                    int stereo_mode, int *d_labels, void *stream);
+/* A classifier context of the caller's own (tables + workspace on `device`).  The entry points above share one context per device, so
+ * two calls on one device run one behind the other; calls through different contexts, on different streams, may overlap.            */
+typedef struct dsp_classify_ctx dsp_classify_ctx;
+int dsp_classify_ctx_create(int device, dsp_classify_ctx **out);
+void dsp_classify_ctx_destroy(dsp_classify_ctx *ctx);
+int dsp_classify_batch_device_ctx(dsp_classify_ctx *ctx, const dsp_classify_config *cfg, const float *d_signal, long n_clips, int n,
+                                  long stride, int *d_labels, void *stream);
+/* test hook, no GPU call: holds the default context of `device` for hold_ms milliseconds (two devices overlap, one device queues) */
+int dsp_debug_hold_classify_ctx(int device, int hold_ms);
+/* frees the float32 classifier's tables and workspace on `device` (-1: every device) after its pending work has finished */
+int dsp_classify_release(int device);
 
 /* The float64 classifier, donut-classifier/classifier.c (the file's per-clip body :83-192, sum_intense :594-653,
  * find_midpoints :655-830): both Butterworth filters, both spectrograms, dB maps, 45 dB midpoints, normalisation, keep band,

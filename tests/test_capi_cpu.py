@@ -134,3 +134,28 @@ def test_consumer_models_reject_bad_parameters_and_fail_loudly_without_a_gpu():
                      lambda: dsp_amd.upsample_linear(np.zeros(8, np.float32), 16)):
             with pytest.raises(dsp_amd.DspError, match="no HIP device"):
                 make()
+
+
+def test_classifier_contexts_are_per_device_locks():
+    """The classifier keeps one context (tables, workspace, mutex) per device: two threads that drive two GPUs from one process must
+    not queue on one lock, two threads on one device must.  dsp_debug_hold_classify_ctx holds a device's default context for a given
+    time without touching the GPU."""
+    import threading
+    import time
+    L = dl.load()
+    hold = 300
+
+    def run(devices):
+        ts = [threading.Thread(target=lambda d=d: dl.check(L.dsp_debug_hold_classify_ctx(d, hold), "hold")) for d in devices]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return (time.perf_counter() - t0) * 1e3
+
+    two = run([0, 1])
+    one = run([3, 3])
+    assert two < 1.6 * hold, two            # overlapped
+    assert one > 1.9 * hold, one            # queued
+    assert L.dsp_debug_hold_classify_ctx(64, 1) < 0 and L.dsp_debug_hold_classify_ctx(-1, 1) < 0

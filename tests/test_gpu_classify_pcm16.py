@@ -1,0 +1,121 @@
+"""GPU: int16 PCM in front of the float32 classify() (SURVEY 8f-1's second reader: sync/sync.cpp:237-242, donut-classifier/
+classifier.c:55-59, :286-297), the per-device stream-ordered contexts and the caller's own contexts (round 4).  int16 / 32768 is exact
+in float, so the bar is the float entry points' results bit for bit -- which are the compiled reference's (tests/test_gpu_classify.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import signals as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dsp():
+    import dsp_amd
+    return dsp_amd
+
+
+def _same(a, b):
+    (la, ta), (lb, tb) = a, b
+    assert np.array_equal(la, lb)
+    for (m, s), (m2, s2) in zip(ta, tb):
+        assert np.array_equal(m, m2) and np.array_equal(s, s2)
+
+
+def _pcm_batch(seed=7, n=16000):
+    rng = np.random.default_rng(seed)
+    cases = S.classify_cases()
+    call = cases["scrub_a"].astype(np.float64)
+    base = np.concatenate([np.stack([c.astype(np.float64) for c in cases.values()]),
+                           rng.uniform(-0.002, 0.002, (12, n)) + call,
+                           rng.uniform(-1, 1, (20, n)) * np.logspace(-3, -0.3, 20)[:, None]])
+    return np.clip(np.round(base * 32768.0), -32768, 32767).astype(np.int16)
+
+
+def test_pcm16_classify_is_bit_identical_to_the_float_path(dsp, golden):
+    import torch
+    pcm = _pcm_batch()
+    as_f32 = (pcm.astype(np.float32) / np.float32(32768.0))
+    for cfg in (None, dsp.CLASSIFY_MICROPHONE):
+        ref = dsp.classify_batch(as_f32, with_trace=True, config=cfg)
+        _same(dsp.classify_batch_pcm16(pcm, with_trace=True, config=cfg), ref)
+        rng = np.random.default_rng(2)
+        other = rng.integers(-20000, 20000, pcm.shape).astype(np.int16)
+        st = np.stack([pcm, other], axis=2)
+        _same(dsp.classify_batch_pcm16(st, dsp.STEREO_CHANNEL0, with_trace=True, config=cfg), ref)
+        avg = ((pcm.astype(np.int32) + other.astype(np.int32)).astype(np.float32) / np.float32(65536.0))
+        _same(dsp.classify_batch_pcm16(st, dsp.STEREO_AVERAGE, with_trace=True, config=cfg), dsp.classify_batch(avg, with_trace=True, config=cfg))
+        assert np.array_equal(dsp.classify_device_pcm16(torch.from_numpy(pcm).cuda(), config=cfg).cpu().numpy(), ref[0])
+        assert np.array_equal(dsp.classify_device_pcm16(torch.from_numpy(st).cuda(), stereo_mode=dsp.STEREO_CHANNEL0, config=cfg).cpu().numpy(), ref[0])
+    ref = dsp.classify_batch(as_f32, with_trace=True)
+    assert ref[0].any() and not ref[0].all()
+    # rows that are not 16-byte aligned (element-wise loads), odd lengths, a single segment, too short
+    n = pcm.shape[1]
+    padded = torch.zeros((pcm.shape[0], n + 3), dtype=torch.int16, device="cuda")
+    padded[:, :n] = torch.from_numpy(pcm).cuda()
+    assert np.array_equal(dsp.classify_device_pcm16(padded[:, :n]).cpu().numpy(), ref[0])
+    for m in (100, 256, 479, 5001, 15999):
+        _same(dsp.classify_batch_pcm16(pcm[:8, :m], with_trace=True), dsp.classify_batch(as_f32[:8, :m], with_trace=True))
+    # the donut classifier's own recordings as its reader takes them: int16, channel 0
+    g = golden("donut16k_ref.npz")
+    for name in sorted({k.split("__")[0] for k in g.files}):
+        p = g[name + "__pcm"]
+        got = dsp.classify_batch_pcm16(p[None, :, :], dsp.STEREO_CHANNEL0, with_trace=True, config=dsp.CLASSIFY_MICROPHONE)
+        _same(got, dsp.classify_batch((p[:, 0].astype(np.float32) / np.float32(32768.0))[None, :], with_trace=True, config=dsp.CLASSIFY_MICROPHONE))
+
+
+def test_device_entry_is_stream_ordered_and_contexts_overlap(dsp):
+    """Calls on one device through the default context are ordered by an event, whatever their streams; two contexts of the caller's own
+    on two streams run side by side (half-chip batches: both fit at once) with the same labels."""
+    import time
+    import torch
+    from dsp_amd import lib as L
+    lib = L.load()
+    pcm = _pcm_batch(seed=11)
+    clips = torch.from_numpy(pcm.astype(np.float32) / np.float32(32768.0)).cuda()
+    ref = dsp.classify_batch(clips.cpu().numpy())
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for k in range(6):
+        with torch.cuda.stream(s1 if k % 2 == 0 else s2):
+            outs.append(dsp.classify_device(clips if k % 3 else clips.flip(0)))
+    torch.cuda.synchronize()
+    for k, o in enumerate(outs):
+        assert np.array_equal(o.cpu().numpy(), ref if k % 3 else ref[::-1]), k
+    dsp.classify_release(0)
+    assert np.array_equal(dsp.classify_device(clips).cpu().numpy(), ref)
+
+    # two contexts, two streams
+    big = clips.repeat(128, 1)[:8192].contiguous()                  # 128 blocks of the 256-CU chip per call
+    want = np.tile(ref, 128)[:8192]
+    ctxs = []
+    for _ in range(2):
+        h = C.c_void_p()
+        L.check(lib.dsp_classify_ctx_create(0, C.byref(h)), "ctx_create")
+        ctxs.append(h)
+    labs = [torch.empty(8192, dtype=torch.int32, device="cuda") for _ in range(2)]
+
+    def call(i, stream):
+        L.check(lib.dsp_classify_batch_device_ctx(ctxs[i], None, big.data_ptr(), 8192, big.shape[1], big.stride(0), labs[i].data_ptr(),
+                                                  C.c_void_p(stream.cuda_stream)), "batch_device_ctx")
+
+    def timed(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    t_serial = timed(lambda: (call(0, s1), call(1, s1)))
+    t_overlap = timed(lambda: (call(0, s1), call(1, s2)))
+    for lab in labs:
+        assert np.array_equal(lab.cpu().numpy(), want)
+    print(f"two contexts: one stream {t_serial * 1e3:.3f} ms, two streams {t_overlap * 1e3:.3f} ms")
+    assert t_overlap < 0.9 * t_serial, (t_overlap, t_serial)
+    for h in ctxs:
+        lib.dsp_classify_ctx_destroy(h)
+    # a context on the wrong device / a null context are refused
+    assert lib.dsp_classify_batch_device_ctx(None, None, big.data_ptr(), 1, 16000, 16000, labs[0].data_ptr(), None) < 0
