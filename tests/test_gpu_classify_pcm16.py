@@ -88,8 +88,10 @@ def test_device_entry_is_stream_ordered_and_contexts_overlap(dsp):
     assert np.array_equal(dsp.classify_device(clips).cpu().numpy(), ref)
 
     # two contexts, two streams
-    big = clips.repeat(128, 1)[:8192].contiguous()                  # 128 blocks of the 256-CU chip per call
-    want = np.tile(ref, 128)[:8192]
+    reps = -(-8192 // clips.shape[0])
+    big = clips.repeat(reps, 1)[:8192].contiguous()                 # 128 blocks of the 256-CU chip per call
+    want = np.tile(ref, reps)[:8192]
+    assert big.shape[0] == 8192 and want.shape[0] == 8192
     ctxs = []
     for _ in range(2):
         h = C.c_void_p()
