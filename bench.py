@@ -302,7 +302,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         units, unit, bytes_per = n * 98, "frames/s", 64_000 + 98 * 52    # 69 096 B per clip
         what = f"BASELINE configs[3] per-GPU share: {n} x 1 s 16 kHz fp32 clips, frame 400 / hop 160 -> [98][13] per clip"
         kernel = "mfcc512_wave_kernel"
-    elif args.workload == "classify_f64":
+    elif args.workload in ("classify_f64", "classify_f64_pcm16"):
         # the float64 classifier of donut-classifier/classifier.c
         n = args.clips or 49152
         # this classifier's midpoint threshold is 45 dB (classifier.c:660; classifier.cpp's is 70): noise of amplitude 0.05 has
@@ -313,11 +313,34 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         call = torch.from_numpy(S.classify_cases()["scrub_a"]).to(dev).double()
         clips[::4] = call + clips[::4] * 0.1
         labels = torch.empty(n, dtype=torch.int32, device=dev)
-        step = lambda: dsp_amd.classify_device_f64(clips, labels)   # noqa: E731
-        units, unit, bytes_per = n, "clips/s", 128_000 + 4
-        what = (f"{n} x 1 s 16 kHz float64 clips (25 % with a call-like burst pattern) through the float64 classify() of "
-                "donut-classifier/classifier.c")
-        kernel = "iir_kernel<double, two filters> + spectrogram_f64_fft_kernel<flags> + classify_f64_midpoints_kernel + spectrogram_f64_fft_kernel<maps> + classify_f64_bands_kernel"
+        kernel = ("iir2_screen_f64_kernel (both recurrences, restart states, bf16-MFMA screening of the loud bins) + spec_f64_from_ckpt_kernel<flags> "
+                  "(undecided segments) + classify_f64_midpoints_kernel + spec_f64_from_ckpt_kernel<maps> + classify_f64_bands_kernel")
+        if args.workload == "classify_f64_pcm16":
+            pcm = torch.clamp(torch.round(clips * 32768.0), -32768, 32767).to(torch.int16)      # what the reference's reader starts from (classifier.c:55-59)
+            del clips
+            step = lambda: dsp_amd.classify_device_f64_pcm16(pcm, labels)   # noqa: E731
+            units, unit, bytes_per = n, "clips/s", 32_000 + 4
+            what = (f"{n} x 1 s 16 kHz int16 mono clips (25 % with a call-like burst pattern), s / 32768.0 in the kernels' loads, through the float64 "
+                    "classify() of donut-classifier/classifier.c")
+        else:
+            step = lambda: dsp_amd.classify_device_f64(clips, labels)   # noqa: E731
+            units, unit, bytes_per = n, "clips/s", 128_000 + 4
+            what = (f"{n} x 1 s 16 kHz float64 clips (25 % with a call-like burst pattern) through the float64 classify() of "
+                    "donut-classifier/classifier.c")
+    elif args.workload == "classify_pcm16":
+        n = args.clips or 49152
+        clips = (torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1) * 0.05
+        from tests import signals as S
+        call = torch.from_numpy(S.classify_cases()["scrub_a"]).to(dev)
+        clips[::4] = call + clips[::4] * 0.01
+        pcm = torch.clamp(torch.round(clips * 32768.0), -32768, 32767).to(torch.int16)          # sync/sync.cpp:237-242: int16 capture, / 32768.0
+        del clips
+        labels = torch.empty(n, dtype=torch.int32, device=dev)
+        step = lambda: dsp_amd.classify_device_pcm16(pcm, labels)   # noqa: E731
+        units, unit, bytes_per = n, "clips/s", 32_000 + 4
+        what = (f"{n} x 1 s 16 kHz int16 mono clips (25 % with a call-like burst pattern), pcmSample / 32768.0 in the kernels' loads, through classify() "
+                "(2 x IIR, 2 x spectrogram, rule), bit-exact with the reference")
+        kernel = "iir2_ckpt_kernel<IN=1> + spec_from_ckpt_kernel<flags, IN=1> + classify_midpoints_kernel + spec_from_ckpt_kernel<[time][bin], IN=1> + classify_bands_kernel"
     else:
         n = args.clips or 49152
         clips = (torch.rand((n, 16000), device=dev, generator=gen) * 2 - 1) * 0.05
@@ -342,7 +365,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    steps = max(1, args.steps // 10) if args.workload in ("classify", "classify_f64") else args.steps
+    steps = max(1, args.steps // 10) if args.workload.startswith("classify") else args.steps
     s_before = sens.read() if sens else None
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
@@ -370,7 +393,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         print(json.dumps({
             "metric": f"{args.workload}: {unit}", "value": world * units * steps / elapsed, "unit": unit, "n_gpus": world,
             "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.workload == "classify_f64" else "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.workload.startswith("classify_f64") else "f32", "data": "synthetic",
             "config": {"workload": what, "clock_settle_s": args.settle},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr["hbm_bytes_per_launch"] if tr else None,
@@ -491,7 +514,7 @@ def main():
                          "steps end before the GPU's clocks have ramped (first launches after idle run 0.6 ms); reported in config")
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="all-gather the per-rank features every step (RCCL)")
-    ap.add_argument("--workload", choices=["frames", "clips", "classify", "classify_f64", "config3", "config5", "config5_2048", "pcm16", "stop"], default="frames",
+    ap.add_argument("--workload", choices=["frames", "clips", "classify", "classify_pcm16", "classify_f64", "classify_f64_pcm16", "config3", "config5", "config5_2048", "pcm16", "stop"], default="frames",
                     help="frames = BASELINE configs[1] (the headline metric, default); clips = configs[3] per-GPU share "
                          "(12 500 x 1 s clips, reference framing 400/160); classify = the donut classifier on 1 s clips")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step for --workload clips / classify")

@@ -8,7 +8,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.environ.get("DSP_AMD_LIB") or os.path.join(PKG, "libdsp_amd.so")
-SOURCES = ["capi.cpp", "capi_consumers.cpp", "capi_classifier_cxx.cpp", "capi_classify_f64.cpp", "classify_f64_kernels.hip", "classify_f64_ckpt_kernels.hip", "tables.cpp", "mfcc_kernels.hip", "mfcc1024_kernel.hip", "mfcc1024_wave_kernel.hip", "mfcc2048_kernel.hip", "classify_kernels.hip",
+SOURCES = ["capi.cpp", "capi_consumers.cpp", "capi_classifier_cxx.cpp", "capi_classify_f64.cpp", "capi_gather.cpp", "classify_f64_kernels.hip", "classify_f64_ckpt_kernels.hip", "tables.cpp", "mfcc_kernels.hip", "mfcc1024_kernel.hip", "mfcc1024_wave_kernel.hip", "mfcc2048_kernel.hip", "classify_kernels.hip",
            "svm_kernels.hip", "consumer_kernels.hip"]
 # Measured dead ends of the 512-point kernel (row per frame: 0.537 ms, two frames per wavefront step: 0.44-0.45 ms against 0.41 for
 # the default kernel; A/B records in profiles/r02_wave_priority_ab.txt): kept buildable, outside the product library.

@@ -99,6 +99,7 @@ SYMBOLS = [
     "dsp_scrubjay_fused_device", "dsp_stop_model_create", "dsp_stop_model_destroy", "dsp_stop_predict_device", "dsp_classify_signal_batch_device",
     "dsp_classify_signal", "dsp_speaker_model_create", "dsp_speaker_model_destroy", "dsp_speaker_llr_device",
     "dsp_upsample_linear_device", "dsp_upsample_linear_host",
+    "dsp_gather_create", "dsp_gather_destroy", "dsp_gather_n_devices", "dsp_gather_all",
     "dsp_last_error", "dsp_device_count", "dsp_version",
 ]
 
@@ -184,6 +185,10 @@ def load() -> C.CDLL:
     L.dsp_speaker_llr_device.argtypes = [vp, vp, C.c_long, ip, vp, vp, vp, vp, vp]; L.dsp_speaker_llr_device.restype = ip
     L.dsp_upsample_linear_device.argtypes = [vp, C.c_long, ip, C.c_long, vp, ip, C.c_long, vp]; L.dsp_upsample_linear_device.restype = ip
     L.dsp_upsample_linear_host.argtypes = [vp, ip, vp, ip]; L.dsp_upsample_linear_host.restype = ip
+    L.dsp_gather_create.argtypes = [vp, ip, C.POINTER(vp)]; L.dsp_gather_create.restype = ip
+    L.dsp_gather_destroy.argtypes = [vp]; L.dsp_gather_destroy.restype = None
+    L.dsp_gather_n_devices.argtypes = [vp]; L.dsp_gather_n_devices.restype = ip
+    L.dsp_gather_all.argtypes = [vp, vp, vp, C.c_size_t, vp]; L.dsp_gather_all.restype = ip
     L.dsp_last_error.argtypes = []; L.dsp_last_error.restype = C.c_char_p
     L.dsp_device_count.argtypes = []; L.dsp_device_count.restype = ip
     L.dsp_version.argtypes = []; L.dsp_version.restype = C.c_char_p

@@ -305,6 +305,20 @@ int dsp_sum_intense_f32(float lower, float upper, float half_range, const float 
  * holds; longer clips are rejected (DSP_EINVAL) rather than truncated.                 */
 int dsp_find_midpoints(const float *data, int num_frames, int fs, float *midpoints, int max_midpoints);
 
+/* --- several GPUs from one C process ---------------------------------------
+ * Clips shard without any exchange: give device d the clips [d * ceil(N / D), ...) through the entry points above (plans, models and
+ * classifier contexts are per device; calls on different devices share no lock).  The path's one exchange step is the gather of the
+ * per-clip results: one RCCL communicator per listed device (ncclCommInitAll) and ONE grouped all-gather per call over xGMI -- rank r
+ * (= devices[r]) contributes bytes_per_rank bytes at d_send[r] and receives every rank's block, in rank order, at d_recv[r]
+ * (n_devices * bytes_per_rank bytes; pad the last shard so the counts are equal).  Stream-ordered on streams[r] (NULL: the device's
+ * null stream), so the gather of batch k can cross xGMI while batch k + 1 is computed on another stream.  RCCL is loaded at the first
+ * dsp_gather_create (dlopen of librccl.so.1): hosts that never gather do not need it.  INTEGRATION.md, "8 GPUs from C".       */
+typedef struct dsp_gather dsp_gather;
+int dsp_gather_create(const int *devices, int n_devices, dsp_gather **out);
+void dsp_gather_destroy(dsp_gather *g);
+int dsp_gather_n_devices(const dsp_gather *g);
+int dsp_gather_all(dsp_gather *g, const void *const *d_send, void *const *d_recv, size_t bytes_per_rank, void *const *streams);
+
 /* --- pooling + SVM (cepstrum/scrubjay_infer.c:36-66, 105-141; scrubjay_svm.onnx) ------ */
 
 /* mfcc_stats pooling: feat[c][2*n_coef] = per-coefficient mean | population std over the T

@@ -159,3 +159,15 @@ def test_classifier_contexts_are_per_device_locks():
     assert two < 1.6 * hold, two            # overlapped
     assert one > 1.9 * hold, one            # queued
     assert L.dsp_debug_hold_classify_ctx(64, 1) < 0 and L.dsp_debug_hold_classify_ctx(-1, 1) < 0
+
+
+def test_gather_entry_points_reject_bad_arguments_and_fail_loudly_without_a_gpu():
+    L = dl.load()
+    h = C.c_void_p()
+    devs = (C.c_int * 2)(0, 1)
+    assert L.dsp_gather_create(None, 1, C.byref(h)) < 0 and L.dsp_gather_create(devs, 0, C.byref(h)) < 0 and L.dsp_gather_create(devs, 65, C.byref(h)) < 0
+    assert L.dsp_gather_create(devs, 2, None) < 0
+    if L.dsp_device_count() <= 0:
+        assert L.dsp_gather_create(devs, 2, C.byref(h)) == -2 and not h.value        # DSP_ENODEV
+    assert L.dsp_gather_all(None, None, None, 4, None) < 0 and L.dsp_gather_n_devices(None) < 0
+    L.dsp_gather_destroy(None)

@@ -48,7 +48,7 @@ def main():
     units = {"frames": line["config"].get("frames_per_gpu")}.get(workload)
     doc = {"workload": workload, "units_per_launch": units if units else round(alg / {"clips": 69096, "classify": 64004, "config3": 4148,
                                                                                       "config5": 64008, "config5_2048": 64008, "pcm16": 1076, "stop": 64004,
-                                                                                      "classify_f64": 128004}[workload]),
+                                                                                      "classify_f64": 128004, "classify_pcm16": 32004, "classify_f64_pcm16": 32004}[workload]),
            "hbm_bytes_per_launch": fetch + write, "read_bytes": fetch, "write_bytes": write, "algorithmic_bytes_per_launch": alg,
            "ratio_to_algorithmic": (fetch + write) / alg, "fetch_size_kb": res["FETCH_SIZE"], "write_size_kb": res["WRITE_SIZE"],
            "correction": "FETCH_SIZE x2 (gfx950: 128-byte requests tallied as 64), both counters in KB; separate --pmc passes; "
