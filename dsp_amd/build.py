@@ -112,7 +112,7 @@ def _build_locked(verbose: bool) -> str:
         if bad:
             raise RuntimeError(f"hipcc failed on {bad}:\n{log}")
         subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
-                               "-o", tmp] + [obj for _, obj, _ in results], cwd=CSRC)
+                               "-o", tmp] + os.environ.get("DSP_AMD_EXTRA_LDFLAGS", "").split() + [obj for _, obj, _ in results], cwd=CSRC)
         os.replace(tmp, LIB)
         with open(LIB + ".hash", "w") as f:
             f.write(h + "\n")

@@ -59,6 +59,8 @@ bool valid_cfg(const dsp_mfcc_config &c, std::string &why)
 {
     if (c.sample_rate <= 0) { why = "sample_rate must be positive"; return false; }
     if (c.hop_length <= 0) { why = "hop_length must be positive"; return false; }
+    if (c.frame_length < 2) { why = "frame_length must be at least 2"; return false; }
+    if (c.n_mels < 1 || c.n_mfcc < 1) { why = "n_mels and n_mfcc must be positive"; return false; }
     if (c.frame_length & 1) { why = "frame_length must be even (8-byte aligned frame loads)"; return false; }
     if (c.hop_length & 1) { why = "hop_length must be even (8-byte aligned frame loads)"; return false; }
     if (!(c.fmax > c.fmin) || c.fmin < 0) { why = "need 0 <= fmin < fmax"; return false; }
@@ -204,6 +206,11 @@ int dsp_mfcc_frames_for(const dsp_mfcc_config *cfg, int num_samples, int max_fra
 int dsp_mfcc_tables(const dsp_mfcc_config *cfg, float *window, float *mel, float *dct)
 {
     if (!cfg) return fail(DSP_EINVAL, "cfg is NULL");
+    {   // (the sanitizer tier's sweep found this entry point building tables for configurations dsp_mfcc_plan_create refuses --
+        // sample_rate 0, fmin > fmax, n_fft 333: NaN tables rather than an error)
+        std::string why;
+        if (!valid_cfg(*cfg, why)) return fail(DSP_EINVAL, why);
+    }
     if (window) {
         auto w = dsp::make_frame_window(*cfg);
         std::memcpy(window, w.data(), w.size() * sizeof(float));

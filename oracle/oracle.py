@@ -86,7 +86,8 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        # DSP_ORACLE_LIB: another build of the same sources (tools/asan_host.sh: oracle/liboracle_asan.so under AddressSanitizer / UBSan)
+        L = C.CDLL(os.environ.get("DSP_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so"))
         L.orc_mfcc_default_cfg.argtypes = [C.POINTER(MfccCfg)]
         L.orc_window.argtypes = [C.c_int, C.c_int, _F]
         L.orc_mel_filterbank.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _F]
