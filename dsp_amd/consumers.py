@@ -79,6 +79,18 @@ class StopModel:
                    "dsp_classify_signal_batch_device")
         return prob
 
+    def classify_signal_batch_pcm16(self, plan: MfccPlan, pcm, stereo_mode: int = 0):
+        """pcm: cuda int16 [n_clips][samples] or [n_clips][samples][2] -> P("stop") (dsp_classify_signal_batch_pcm16_device: what
+        main_test.c:198-217 decodes in front of classify_signal, converted in the kernel's load)."""
+        import torch
+        assert pcm.dim() in (2, 3) and pcm.dtype == torch.int16 and pcm.stride(-1) == 1
+        channels = 2 if pcm.dim() == 3 else 1
+        prob = torch.empty(pcm.shape[0], dtype=torch.float32, device=pcm.device)
+        _lib.check(self._L.dsp_classify_signal_batch_pcm16_device(plan._h, self._h, pcm.data_ptr(), pcm.shape[0], pcm.shape[1], pcm.stride(0) // channels,
+                                                                  channels, int(stereo_mode), prob.data_ptr(), _stream(pcm)),
+                   "dsp_classify_signal_batch_pcm16_device")
+        return prob
+
     def classify_signal(self, signal: np.ndarray) -> float:
         """The reference's classify_signal(signal, num_samples) on a host buffer."""
         signal = np.ascontiguousarray(signal, np.float32)

@@ -1315,26 +1315,32 @@ void dsp_svm_destroy(dsp_svm *s)
     delete s;
 }
 
-int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signal, long n_clips, int samples_per_clip,
-                              long clip_stride, int max_frames, int *d_labels, float *d_decision, float *d_prob1, float *d_feat,
-                              void *stream)
+}  // extern "C"
+
+// clip -> label in one kernel; in_kind 0 = float samples, 1 / 2 / 3 = int16 mono / stereo channel 0 / stereo average
+static int scrubjay_fused(dsp_mfcc_plan *p, dsp_svm *s, const void *d_signal, int in_kind, long n_clips, int samples_per_clip,
+                          long clip_stride, int max_frames, int *d_labels, float *d_decision, float *d_prob1, float *d_feat, void *stream)
 {
     if (!p || !s || n_clips < 0) return fail(DSP_EINVAL, "bad argument");
     if ((p->cfg.n_fft != 512 && p->cfg.n_fft != 2048) || (p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX && p->cfg.log_mode != DSP_LOG_LOG10_FLOOR) ||
         p->cfg.prefilter != DSP_PREFILTER_NONE || p->kernel != DSP_KERNEL_WAVE)
         return fail(DSP_EINVAL, "the fused clip -> label path runs on the 512- and 2048-point wave-per-frame kernels, per-frame log modes");
+    if (in_kind != 0 && (p->cfg.n_fft != 512 || p->cfg.frame_length != 400 || p->host.mel_gather != 3 ||
+                         !((p->host.dct_split == 4 && p->host.dct_len == 10) || (p->host.dct_split == 2 && p->host.dct_len == 20))))
+        return fail(DSP_EINVAL, "int16 input of the fused clip -> label kernel: the reference framing (n_fft 512, frame 400, 40 mel filters, up to 20 coefficients)");
     if (s->m.n_features != 2 * p->cfg.n_mfcc || s->m.n_features > 64) return fail(DSP_EINVAL, "SVM n_features must equal 2 * n_mfcc (<= 64)");
     const int t = dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
     if (n_clips == 0) return 0;
     if (t == 0) return fail(DSP_EINVAL, "clips shorter than one frame have no features to pool");
     if (!d_signal || !d_labels) return fail(DSP_EINVAL, "NULL buffer");
     if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
-    if ((reinterpret_cast<uintptr_t>(d_signal) & 7) || (n_clips > 1 && (clip_stride & 1))) return fail(DSP_EINVAL, "input must be 8-byte aligned with an even clip stride");
+    if ((reinterpret_cast<uintptr_t>(d_signal) & (in_kind == 1 ? 3 : 7)) || (n_clips > 1 && (clip_stride & 1)))
+        return fail(DSP_EINVAL, "input must be 8-byte aligned (4 for mono int16) with an even clip stride");
     if (s->device != p->device) return fail(DSP_EINVAL, "plan and SVM live on different devices");
     DSP_ON_DEVICE(p->device);
     dsp::Mfcc512Args a{};
     a.in = d_signal;
-    a.in_kind = 0;
+    a.in_kind = in_kind;
     a.out = nullptr;
     a.tables = p->d_tables;
     a.n_frames = n_clips * (long)t;
@@ -1368,11 +1374,32 @@ int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signa
     return t;
 }
 
+extern "C" {
+
+int dsp_scrubjay_fused_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signal, long n_clips, int samples_per_clip,
+                              long clip_stride, int max_frames, int *d_labels, float *d_decision, float *d_prob1, float *d_feat,
+                              void *stream)
+{
+    return scrubjay_fused(p, s, d_signal, 0, n_clips, samples_per_clip, clip_stride, max_frames, d_labels, d_decision, d_prob1, d_feat, stream);
+}
+
+int dsp_scrubjay_fused_pcm16_device(dsp_mfcc_plan *p, dsp_svm *s, const int16_t *d_pcm, long n_clips, int samples_per_clip, long clip_stride,
+                                    int channels, int stereo_mode, int max_frames, int *d_labels, float *d_decision, float *d_prob1, float *d_feat,
+                                    void *stream)
+{
+    if (channels != 1 && channels != 2) return fail(DSP_EINVAL, "channels must be 1 or 2");
+    if (channels == 2 && stereo_mode != DSP_STEREO_CHANNEL0 && stereo_mode != DSP_STEREO_AVERAGE) return fail(DSP_EINVAL, "bad stereo_mode");
+    const int kind = channels == 1 ? 1 : (stereo_mode == DSP_STEREO_CHANNEL0 ? 2 : 3);
+    return scrubjay_fused(p, s, d_pcm, kind, n_clips, samples_per_clip, clip_stride, max_frames, d_labels, d_decision, d_prob1, d_feat, stream);
+}
+
 }  // extern "C"
 
+int dsp::plan_device(const dsp_mfcc_plan *plan) { return plan ? plan->device : -1; }
+
 // capi_util.hpp: the fused form of dsp_classify_signal_batch_device (capi_consumers.cpp)
-int dsp::stop_fused_device(dsp_mfcc_plan *p, const dsp::StopModelDev &m, const float *d_signal, long n_clips, int samples_per_clip,
-                           long clip_stride, int t, float *d_prob, void *stream)
+int dsp::stop_fused_device(dsp_mfcc_plan *p, const dsp::StopModelDev &m, const void *d_signal, long n_clips, int samples_per_clip,
+                           long clip_stride, int t, float *d_prob, void *stream, int in_kind)
 {
     (void)samples_per_clip;
     // the reference's shape on the default kernel: 512-point, per-frame log, 13 coefficients of 40 mel energies, complete frames
@@ -1380,12 +1407,13 @@ int dsp::stop_fused_device(dsp_mfcc_plan *p, const dsp::StopModelDev &m, const f
         p->host.dct_split != 4 || p->host.dct_len != 10 || m.n_coef != p->cfg.n_mfcc || m.units[0] > dsp::kStopFusedUnits || !m.fold_a || t <= 0 ||
         std::getenv("DSP_AMD_STOP_TWO_KERNELS"))
         return 0;
-    if ((reinterpret_cast<uintptr_t>(d_signal) & 7) || (n_clips > 1 && (clip_stride & 1))) return 0;      // the two-kernel path reports it
+    if ((reinterpret_cast<uintptr_t>(d_signal) & (in_kind == 1 ? 3 : 7)) || (n_clips > 1 && (clip_stride & 1))) return 0;      // the two-kernel path reports it
+    if (in_kind != 0 && (p->host.mel_gather != 3 || p->cfg.frame_length != 400)) return 0;
     if (m.max_frames <= 0) return fail(DSP_EINVAL, "stop model without frames");
     DSP_ON_DEVICE(p->device);
     dsp::Mfcc512Args a{};
     a.in = d_signal;
-    a.in_kind = 0;
+    a.in_kind = in_kind;
     a.out = nullptr;
     a.tables = p->d_tables;
     a.n_frames = n_clips * (long)t;

@@ -146,17 +146,24 @@ int dsp_stop_predict_device(dsp_stop_model *m, const float *d_mfcc, long n_clips
     return DSP_OK;
 }
 
-int dsp_classify_signal_batch_device(dsp_mfcc_plan *plan, dsp_stop_model *m, const float *d_signal, long n_clips,
-                                     int samples_per_clip, long clip_stride, float *d_prob, void *stream)
+}  // extern "C"
+
+// classify_signal over a batch; in_kind 0 = float samples, 1 / 2 / 3 = int16 mono / stereo channel 0 / stereo average (what
+// main_test.c:198-217 decodes in front of classify_signal, converted in the kernel's load)
+static int classify_signal_batch(dsp_mfcc_plan *plan, dsp_stop_model *m, const void *d_signal, int in_kind, int channels, int stereo_mode, long n_clips,
+                                 int samples_per_clip, long clip_stride, float *d_prob, void *stream)
 {
     if (!plan || !m || n_clips < 0 || (n_clips > 0 && (!d_signal || !d_prob))) return capi_fail(DSP_EINVAL, "bad argument");
     dsp_mfcc_config cfg;
     dsp_mfcc_plan_config(plan, &cfg);
     if (cfg.n_mfcc != m->m.n_coef) return capi_fail(DSP_EINVAL, "plan n_mfcc differs from the model's n_coef");
+    // (the fused kernel is the default path: it must refuse what the two-kernel path refuses)
+    if (n_clips > 1 && clip_stride < samples_per_clip) return capi_fail(DSP_EINVAL, "clip_stride < samples_per_clip");
+    if (dsp::plan_device(plan) != m->device) return capi_fail(DSP_EINVAL, "plan and stop model live on different devices");
     if (n_clips == 0) return DSP_OK;
     const int t = dsp_mfcc_frames_for(&cfg, samples_per_clip, m->m.max_frames);          // stop_detector.c:18-21
     {   // one kernel from PCM to probability when the plan is the reference's shape: the MFCC matrix is never written
-        const int fused = dsp::stop_fused_device(plan, m->m, d_signal, n_clips, samples_per_clip, clip_stride, t, d_prob, stream);
+        const int fused = dsp::stop_fused_device(plan, m->m, d_signal, n_clips, samples_per_clip, clip_stride, t, d_prob, stream, in_kind);
         if (fused != 0) return fused < 0 ? fused : DSP_OK;
     }
     std::lock_guard<std::mutex> lock(m->mu);
@@ -168,11 +175,30 @@ int dsp_classify_signal_batch_device(dsp_mfcc_plan *plan, dsp_stop_model *m, con
         m->mfcc_cap = need;
     }
     if (t > 0) {
-        const int rc = dsp_mfcc_clips_device(plan, d_signal, n_clips, samples_per_clip, clip_stride, m->d_mfcc, m->m.max_frames, stream);
+        const int rc = in_kind == 0 ? dsp_mfcc_clips_device(plan, static_cast<const float *>(d_signal), n_clips, samples_per_clip, clip_stride, m->d_mfcc, m->m.max_frames, stream)
+                                    : dsp_mfcc_clips_pcm16_device(plan, static_cast<const int16_t *>(d_signal), n_clips, samples_per_clip, clip_stride, channels,
+                                                                  stereo_mode, m->d_mfcc, m->m.max_frames, stream);
         if (rc < 0) return rc;
     }
     DSP_CAPI_HIP(dsp::launch_stop_tail(m->m, m->d_mfcc, n_clips, t, d_prob, (hipStream_t)stream));
     return DSP_OK;
+}
+
+extern "C" {
+
+int dsp_classify_signal_batch_device(dsp_mfcc_plan *plan, dsp_stop_model *m, const float *d_signal, long n_clips,
+                                     int samples_per_clip, long clip_stride, float *d_prob, void *stream)
+{
+    return classify_signal_batch(plan, m, d_signal, 0, 1, 0, n_clips, samples_per_clip, clip_stride, d_prob, stream);
+}
+
+int dsp_classify_signal_batch_pcm16_device(dsp_mfcc_plan *plan, dsp_stop_model *m, const int16_t *d_pcm, long n_clips, int samples_per_clip,
+                                           long clip_stride, int channels, int stereo_mode, float *d_prob, void *stream)
+{
+    if (channels != 1 && channels != 2) return capi_fail(DSP_EINVAL, "channels must be 1 or 2");
+    if (channels == 2 && stereo_mode != DSP_STEREO_CHANNEL0 && stereo_mode != DSP_STEREO_AVERAGE) return capi_fail(DSP_EINVAL, "bad stereo_mode");
+    const int kind = channels == 1 ? 1 : (stereo_mode == DSP_STEREO_CHANNEL0 ? 2 : 3);
+    return classify_signal_batch(plan, m, d_pcm, kind, channels, stereo_mode, n_clips, samples_per_clip, clip_stride, d_prob, stream);
 }
 
 float dsp_classify_signal(dsp_stop_model *m, const float *signal, int num_samples)

@@ -14,8 +14,10 @@ struct StopModelDev;
 // capi.cpp (owner of dsp_mfcc_plan): classify_signal in one kernel -- clip -> MFCC -> stop-word net, the MFCC matrix never written.
 // Returns 1 when the fused kernel was enqueued, 0 when this plan / model shape has no fused form (the caller runs the two-kernel
 // path), < 0 on error.  t = frames per clip (already capped at the model's max_frames).
-int stop_fused_device(dsp_mfcc_plan *plan, const StopModelDev &m, const float *d_signal, long n_clips, int samples_per_clip,
-                      long clip_stride, int t, float *d_prob, void *stream);
+// in_kind: 0 float samples, 1 / 2 / 3 int16 mono / stereo channel 0 / stereo average
+int stop_fused_device(dsp_mfcc_plan *plan, const StopModelDev &m, const void *d_signal, long n_clips, int samples_per_clip,
+                      long clip_stride, int t, float *d_prob, void *stream, int in_kind = 0);
+int plan_device(const dsp_mfcc_plan *plan);          // the GPU a plan lives on
 }
 
 #define DSP_CAPI_HIP(call)                                                                              \

@@ -896,10 +896,26 @@ static hipError_t launch_one(const Mfcc512Args &args, bool clips, int blocks, hi
 
 hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream)
 {
-    if (args.frames_per_clip <= 0 || args.chunk != args.frames_per_clip || args.log_mode != 0 || args.in_kind != 0 || !args.pool.labels ||
+    if (args.frames_per_clip <= 0 || args.chunk != args.frames_per_clip || args.log_mode != 0 || args.in_kind < 0 || args.in_kind > 3 || !args.pool.labels ||
         args.pool.svm.n_features != 2 * args.n_mfcc || args.pool.svm.n_features > 64 || args.pool.svm.n_sv < 1 || args.pool.svm.n_sv > 2048)
         return hipErrorInvalidConfiguration;
     const dim3 g(blocks), b(256);
+    if (args.in_kind != 0) {
+        // int16 PCM in the fused clip -> label kernel: the reference framing (frame 400) on the shapes of 13 and 20
+        // coefficients of 40 mel energies -- what scrubjay_infer.c's and stop_detector.c's callers decode from their WAV files
+#define DSP_LAUNCH_POOL_PCM(S, L, G)                                                                                        \
+        if (dct_split == S && dct_len == L && gather == G && args.frame_len == 400) {                                        \
+            const size_t lds = lds_bytes<S, L>(true, 1, 2 * args.pool.svm.n_features + args.pool.svm.n_sv);                 \
+            if (args.in_kind == 1) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 400, 1, 1, true, 1>), g, b, lds, stream, args);      \
+            else if (args.in_kind == 2) hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 400, 2, 1, true, 1>), g, b, lds, stream, args); \
+            else hipLaunchKernelGGL((mfcc512_wave_kernel<S, L, G, 400, 3, 1, true, 1>), g, b, lds, stream, args);          \
+            return hipGetLastError();                                                                                       \
+        }
+        DSP_LAUNCH_POOL_PCM(4, 10, 3)
+        DSP_LAUNCH_POOL_PCM(2, 20, 3)
+#undef DSP_LAUNCH_POOL_PCM
+        return hipErrorInvalidConfiguration;
+    }
 #define DSP_LAUNCH_POOL(S, L, G)                                                                                            \
     if (dct_split == S && dct_len == L && gather == G) {                                                                    \
         const size_t lds = lds_bytes<S, L>(true, 1, 2 * args.pool.svm.n_features + args.pool.svm.n_sv);                    \
@@ -919,8 +935,8 @@ hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_l
 hipError_t launch_mfcc512_stop(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream)
 {
     const StopModelDev &m = args.stop.m;
-    if (args.frames_per_clip <= 0 || args.chunk != args.frames_per_clip || args.log_mode != 0 || args.in_kind != 0 || !args.stop.prob ||
-        dct_split != 4 || dct_len != 10 || m.n_coef != args.n_mfcc || m.n_coef > 16 || m.units[0] < 1 || m.units[0] > kStopFusedUnits ||
+    if (args.frames_per_clip <= 0 || args.chunk != args.frames_per_clip || args.log_mode != 0 || args.in_kind < 0 || args.in_kind > 3 || !args.stop.prob ||
+        (args.in_kind != 0 && !(gather == 3 && args.frame_len == 400)) || dct_split != 4 || dct_len != 10 || m.n_coef != args.n_mfcc || m.n_coef > 16 || m.units[0] < 1 || m.units[0] > kStopFusedUnits ||
         !m.fold_a || !m.pad_b)
         return hipErrorInvalidConfiguration;
     for (int l = 1; l < 4; ++l)
@@ -934,7 +950,10 @@ hipError_t launch_mfcc512_stop(const Mfcc512Args &args, int dct_split, int dct_l
             blocks = std::min(blocks, per_cu * n_cu);
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, stream, args);
     };
-    if (gather == 3 && args.frame_len == 400) launch(mfcc512_wave_kernel<4, 10, 3, 400, 0, 1, true, 2>);
+    if (args.in_kind == 1) launch(mfcc512_wave_kernel<4, 10, 3, 400, 1, 1, true, 2>);       // int16 PCM: main_test.c's reader feeds classify_signal
+    else if (args.in_kind == 2) launch(mfcc512_wave_kernel<4, 10, 3, 400, 2, 1, true, 2>);
+    else if (args.in_kind == 3) launch(mfcc512_wave_kernel<4, 10, 3, 400, 3, 1, true, 2>);
+    else if (gather == 3 && args.frame_len == 400) launch(mfcc512_wave_kernel<4, 10, 3, 400, 0, 1, true, 2>);
     else if (gather == 3) launch(mfcc512_wave_kernel<4, 10, 3, 0, 0, 1, true, 2>);
     else if (gather == 6) launch(mfcc512_wave_kernel<4, 10, 6, 0, 0, 1, true, 2>);
     else return hipErrorInvalidConfiguration;

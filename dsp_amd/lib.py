@@ -96,7 +96,7 @@ SYMBOLS = [
     "dsp_mfcc_default_config", "dsp_mfcc_scrubjay_infer_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
     "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",
     "dsp_mfcc_clips_host", "dsp_mfcc_clips_pcm16_device", "dsp_mfcc_plan_set_launch", "dsp_mfcc_plan_set_kernel", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables", "dsp_prefilter_scan_check",
-    "dsp_scrubjay_fused_device", "dsp_stop_model_create", "dsp_stop_model_destroy", "dsp_stop_predict_device", "dsp_classify_signal_batch_device",
+    "dsp_scrubjay_fused_device", "dsp_scrubjay_fused_pcm16_device", "dsp_classify_signal_batch_pcm16_device", "dsp_stop_model_create", "dsp_stop_model_destroy", "dsp_stop_predict_device", "dsp_classify_signal_batch_device",
     "dsp_classify_signal", "dsp_speaker_model_create", "dsp_speaker_model_destroy", "dsp_speaker_llr_device",
     "dsp_upsample_linear_device", "dsp_upsample_linear_host",
     "dsp_gather_create", "dsp_gather_destroy", "dsp_gather_n_devices", "dsp_gather_all",
@@ -175,6 +175,8 @@ def load() -> C.CDLL:
     L.dsp_svm_destroy.argtypes = [vp]; L.dsp_svm_destroy.restype = None
     L.dsp_svm_predict_device.argtypes = [vp, vp, C.c_long, vp, vp, vp, vp]; L.dsp_svm_predict_device.restype = ip
     L.dsp_scrubjay_fused_device.argtypes = [vp, vp, vp, C.c_long, ip, C.c_long, ip, vp, vp, vp, vp, vp]; L.dsp_scrubjay_fused_device.restype = ip
+    L.dsp_scrubjay_fused_pcm16_device.argtypes = [vp, vp, vp, C.c_long, ip, C.c_long, ip, ip, ip, vp, vp, vp, vp, vp]; L.dsp_scrubjay_fused_pcm16_device.restype = ip
+    L.dsp_classify_signal_batch_pcm16_device.argtypes = [vp, vp, vp, C.c_long, ip, C.c_long, ip, ip, vp, vp]; L.dsp_classify_signal_batch_pcm16_device.restype = ip
     L.dsp_stop_model_create.argtypes = [C.POINTER(StopModelParams), ip, C.POINTER(vp)]; L.dsp_stop_model_create.restype = ip
     L.dsp_stop_model_destroy.argtypes = [vp]; L.dsp_stop_model_destroy.restype = None
     L.dsp_stop_predict_device.argtypes = [vp, vp, C.c_long, ip, vp, vp]; L.dsp_stop_predict_device.restype = ip

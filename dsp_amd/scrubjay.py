@@ -112,3 +112,20 @@ class ScrubJay:
                                                          int(min(max_frames, 1 << 30)), labels.data_ptr(), dec.data_ptr(), p1.data_ptr(),
                                                          feat.data_ptr(), st), "dsp_scrubjay_fused_device")
         return labels, dec, p1, feat
+
+    def pcm16(self, pcm, max_frames: int = 1 << 20, stereo_mode: int = 0):
+        """The fused clip -> label kernel on int16 PCM [n_clips][n] (mono) or [n_clips][n][2] (interleaved stereo: channel 0 or the
+        channels' average), converted in the kernel's load (dsp_scrubjay_fused_pcm16_device): the float path's results, bit for bit."""
+        import torch
+        assert pcm.dtype == torch.int16 and pcm.dim() in (2, 3) and pcm.stride(-1) == 1
+        channels = 2 if pcm.dim() == 3 else 1
+        n = pcm.shape[0]
+        labels = torch.empty(n, dtype=torch.int32, device=pcm.device)
+        dec = torch.empty(n, dtype=torch.float32, device=pcm.device)
+        p1 = torch.empty(n, dtype=torch.float32, device=pcm.device)
+        feat = torch.empty((n, self.svm.n_features), dtype=torch.float32, device=pcm.device)
+        st = C.c_void_p(torch.cuda.current_stream(pcm.device).cuda_stream)
+        _lib.check(_lib.load().dsp_scrubjay_fused_pcm16_device(self.plan._h, self.svm._h, pcm.data_ptr(), n, pcm.shape[1], pcm.stride(0) // channels,
+                                                               channels, int(stereo_mode), int(min(max_frames, 1 << 30)), labels.data_ptr(), dec.data_ptr(),
+                                                               p1.data_ptr(), feat.data_ptr(), st), "dsp_scrubjay_fused_pcm16_device")
+        return labels, dec, p1, feat

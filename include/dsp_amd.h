@@ -349,6 +349,11 @@ int dsp_svm_predict_device(dsp_svm *svm, const float *d_feat, long n_clips, int 
 int dsp_scrubjay_fused_device(dsp_mfcc_plan *plan, dsp_svm *svm, const float *d_signal, long n_clips,
                               int samples_per_clip, long clip_stride, int max_frames, int *d_labels,
                               float *d_decision, float *d_prob1, float *d_feat, void *stream);
+/* The same from int16 PCM (mono / interleaved stereo, as dsp_mfcc_clips_pcm16_device), converted in the kernel's load: bit-identical
+ * to the float entry point on the same samples.  Plans of the reference framing (n_fft 512, frame 400, 40 mel filters).             */
+int dsp_scrubjay_fused_pcm16_device(dsp_mfcc_plan *plan, dsp_svm *svm, const int16_t *d_pcm, long n_clips, int samples_per_clip,
+                                    long clip_stride, int channels, int stereo_mode, int max_frames, int *d_labels,
+                                    float *d_decision, float *d_prob1, float *d_feat, void *stream);
 
 /* --- consumers of the MFCC matrix and the resampler (8f-4) ------- */
 
@@ -376,6 +381,10 @@ int dsp_stop_predict_device(dsp_stop_model *model, const float *d_mfcc, long n_c
  * n_mfcc = n_coef) -> MFCC matrices in a workspace -> the net.                                  */
 int dsp_classify_signal_batch_device(dsp_mfcc_plan *plan, dsp_stop_model *model, const float *d_signal, long n_clips,
                                      int samples_per_clip, long clip_stride, float *d_prob, void *stream);
+/* ... and from the int16 PCM main_test.c:198-217 decodes in front of classify_signal (mono s / 32768, stereo average or channel 0). */
+int dsp_classify_signal_batch_pcm16_device(dsp_mfcc_plan *plan, dsp_stop_model *model, const int16_t *d_pcm, long n_clips,
+                                           int samples_per_clip, long clip_stride, int channels, int stereo_mode, float *d_prob,
+                                           void *stream);
 /* classify_signal's own contract (stop_detector.h:10) with host buffers: probability in [0, 1];
  * a failure returns 0 with the reason in dsp_last_error().                                       */
 float dsp_classify_signal(dsp_stop_model *model, const float *signal, int num_samples);
