@@ -430,11 +430,12 @@ static int run(dsp_mfcc_plan *p, const void *d_in, float *d_out, long n_frames, 
     const bool single_clip = frames_per_clip > 0 && n_frames == frames_per_clip;   // stride unused
     if ((reinterpret_cast<uintptr_t>(d_in) & (in_kind == 1 ? 3 : 7)) || (!single_clip && (clip_stride & 1)))
         return fail(DSP_EINVAL, "input must be 8-byte aligned (4 for mono int16) with an even clip stride");
-    if (in_kind != 0 && (p->cfg.n_fft != 512 || p->kernel != DSP_KERNEL_WAVE || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX))
-        return fail(DSP_EINVAL, "PCM16 ingestion runs on the 512-point wave-per-frame kernel, per-frame log mode");
+    const bool aub2048 = p->cfg.n_fft == 2048 && (p->cfg.spectrum != DSP_SPECTRUM_POWER || p->cfg.log_mode == DSP_LOG_LOG10_FLOOR || p->cfg.framing == DSP_FRAMING_STREAM);
+    if (in_kind != 0 && !(aub2048 && frames_per_clip > 0) && (p->cfg.n_fft != 512 || p->kernel != DSP_KERNEL_WAVE || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX))
+        return fail(DSP_EINVAL, "PCM16 ingestion runs on the 512-point wave-per-frame kernel (per-frame log mode) and on the 2048-point scrubjay_infer.c front end");
     if (p->cfg.n_fft == 2048) {
         dsp::Mfcc512Args a{};
-        a.in = d_in; a.out = d_out; a.n_frames = n_frames; a.clip_stride = clip_stride; a.frames_per_clip = frames_per_clip;
+        a.in = d_in; a.in_kind = in_kind; a.out = d_out; a.n_frames = n_frames; a.clip_stride = clip_stride; a.frames_per_clip = frames_per_clip;
         a.hop = p->cfg.hop_length; a.frame_len = p->cfg.frame_length; a.chunk = p->chunk > 0 ? p->chunk : 8;
         a.n_mels = p->cfg.n_mels; a.n_mfcc = p->cfg.n_mfcc; a.amin = p->cfg.amin; a.top_db = p->cfg.top_db;
         a.spectrum = p->cfg.spectrum;
@@ -596,7 +597,7 @@ int dsp_mfcc_clips_pcm16_device(dsp_mfcc_plan *p, const int16_t *d_pcm, long n_c
     if (!d_pcm || !d_out) return fail(DSP_EINVAL, "NULL buffer");
     if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
     const int kind = channels == 1 ? 1 : (stereo_mode == DSP_STEREO_CHANNEL0 ? 2 : 3);
-    const int rc = run(p, d_pcm, d_out, n_clips * (long)t, t, clip_stride, stream, kind);
+    const int rc = run(p, d_pcm, d_out, n_clips * (long)t, t, clip_stride, stream, kind, false, samples_per_clip);
     return rc < 0 ? rc : t;
 }
 
@@ -1325,9 +1326,11 @@ static int scrubjay_fused(dsp_mfcc_plan *p, dsp_svm *s, const void *d_signal, in
     if ((p->cfg.n_fft != 512 && p->cfg.n_fft != 2048) || (p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX && p->cfg.log_mode != DSP_LOG_LOG10_FLOOR) ||
         p->cfg.prefilter != DSP_PREFILTER_NONE || p->kernel != DSP_KERNEL_WAVE)
         return fail(DSP_EINVAL, "the fused clip -> label path runs on the 512- and 2048-point wave-per-frame kernels, per-frame log modes");
-    if (in_kind != 0 && (p->cfg.n_fft != 512 || p->cfg.frame_length != 400 || p->host.mel_gather != 3 ||
-                         !((p->host.dct_split == 4 && p->host.dct_len == 10) || (p->host.dct_split == 2 && p->host.dct_len == 20))))
-        return fail(DSP_EINVAL, "int16 input of the fused clip -> label kernel: the reference framing (n_fft 512, frame 400, 40 mel filters, up to 20 coefficients)");
+    const bool aub2048 = p->cfg.n_fft == 2048 && (p->cfg.spectrum != DSP_SPECTRUM_POWER || p->cfg.log_mode == DSP_LOG_LOG10_FLOOR || p->cfg.framing == DSP_FRAMING_STREAM);
+    if (in_kind != 0 && !aub2048 && (p->cfg.n_fft != 512 || p->cfg.frame_length != 400 || p->host.mel_gather != 3 ||
+                                     !((p->host.dct_split == 4 && p->host.dct_len == 10) || (p->host.dct_split == 2 && p->host.dct_len == 20))))
+        return fail(DSP_EINVAL, "int16 input of the fused clip -> label kernel: the reference framing (n_fft 512, frame 400, 40 mel filters, up to 20 coefficients) "
+                                "or the scrubjay_infer.c front end (dsp_mfcc_scrubjay_infer_config)");
     if (s->m.n_features != 2 * p->cfg.n_mfcc || s->m.n_features > 64) return fail(DSP_EINVAL, "SVM n_features must equal 2 * n_mfcc (<= 64)");
     const int t = dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
     if (n_clips == 0) return 0;

@@ -77,7 +77,34 @@ constexpr int Q_BLOCK_BYTES = Q_DCT;               // + 256 B per DCT row (+ POO
 //                             zeros before the clip (the vocoder's empty history) and past its end (the short last read)
 // The filterbank (DSP_MELNORM_AUBIO_SLANEY) is a table like any other.  A separate instantiation: the reference-semantics
 // kernels keep their code and registers.
-template <bool CLIPS, bool POOL, bool AUB = false>
+// IN: 0 float samples; 1 int16 mono, 2 interleaved int16 stereo channel 0, 3 stereo (L + R) / 65536 -- converted
+// in the load (exact: the float path's values), instantiated for the scrubjay_infer.c front end (AUB), whose callers decode int16 files.
+template <int IN>
+__device__ __forceinline__ void load_pair_2048(const void *base, long i, bool cached, float &x0, float &x1)
+{
+    if constexpr (IN == 0) {
+        const f2v x = cached ? *reinterpret_cast<const f2v *>(static_cast<const float *>(base) + i)
+                             : __builtin_nontemporal_load(reinterpret_cast<const f2v *>(static_cast<const float *>(base) + i));
+        x0 = x.x; x1 = x.y;
+    } else if constexpr (IN == 1) {
+        const unsigned q = *reinterpret_cast<const unsigned *>(static_cast<const short *>(base) + i);
+        x0 = (float)(int)(short)(q & 0xffffu) * (1.0f / 32768.0f); x1 = (float)((int)q >> 16) * (1.0f / 32768.0f);
+    } else {
+        const uint2 q = *reinterpret_cast<const uint2 *>(static_cast<const short *>(base) + 2 * i);
+        if constexpr (IN == 2) { x0 = (float)(int)(short)(q.x & 0xffffu) * (1.0f / 32768.0f); x1 = (float)(int)(short)(q.y & 0xffffu) * (1.0f / 32768.0f); }
+        else { x0 = (float)((int)(short)(q.x & 0xffffu) + ((int)q.x >> 16)) * (1.0f / 65536.0f); x1 = (float)((int)(short)(q.y & 0xffffu) + ((int)q.y >> 16)) * (1.0f / 65536.0f); }
+    }
+}
+template <int IN>
+__device__ __forceinline__ float load_one_2048(const void *base, long i)
+{
+    if constexpr (IN == 0) return static_cast<const float *>(base)[i];
+    else if constexpr (IN == 1) return (float)static_cast<const short *>(base)[i] * (1.0f / 32768.0f);
+    else if constexpr (IN == 2) return (float)static_cast<const short *>(base)[2 * i] * (1.0f / 32768.0f);
+    else return (float)((int)static_cast<const short *>(base)[2 * i] + (int)static_cast<const short *>(base)[2 * i + 1]) * (1.0f / 65536.0f);
+}
+
+template <bool CLIPS, bool POOL, bool AUB = false, int IN = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void mfcc2048_kernel(const Mfcc512Args args, const GenTables2048 *__restrict__ G)
 {
     static_assert(!POOL || CLIPS, "pooling is per clip");
@@ -152,7 +179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
         const long f = cur.f, clip_f = cur.clip;
         const bool last_of_chunk = cur.left == 0 || cur.remaining == 1;
         (void)clip_f; (void)last_of_chunk;
-        const float *src = static_cast<const float *>(args.in) + cur.off;
+        long src = cur.off;                                              // first sample of the frame (samples per channel from args.in)
         // samples [lo_i, hi_i) of the frame exist; the rest reads as zero.  Complete frames: [0, frame_len).
         int lo_i = 0, hi_i = frame_len;
         if (AUB && CLIPS && args.stream_framing) {
@@ -170,10 +197,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             const int i = 2 * (lane + 64 * a);
             float x0 = 0.0f, x1 = 0.0f;
             if (i + 1 < hi_i && (!AUB || i >= lo_i)) {                   // lo_i is even: a pair never straddles it
-                const f2v x = CLIPS ? *reinterpret_cast<const f2v *>(src + i) : __builtin_nontemporal_load(reinterpret_cast<const f2v *>(src + i));   // clips re-read samples: cacheable
-                x0 = x.x; x1 = x.y;
+                load_pair_2048<IN>(args.in, src + i, CLIPS, x0, x1);     // clips re-read samples: cacheable
             } else if (i < hi_i && (!AUB || i >= lo_i)) {
-                x0 = src[i];
+                x0 = load_one_2048<IN>(args.in, src + i);
             }
             if (WIN_LDS) {
                 const float2 w = win2[64 * a + lane];
@@ -441,14 +467,21 @@ hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables,
     const size_t Q_BLOCK_BYTES = lds_bytes_2048(args.n_mels, pool);
     const bool aub = args.spectrum != 0 || args.log_mode == 2 || args.stream_framing != 0;
     if (args.stream_framing && (!clips || args.samples_per_clip <= 0 || args.hop > args.frame_len)) return hipErrorInvalidConfiguration;
+    if (args.in_kind != 0 && (!aub || !clips || args.in_kind < 0 || args.in_kind > 3)) return hipErrorInvalidConfiguration;      // int16: the scrubjay_infer.c front end, clips
     if (pool) {
         if (!clips || args.chunk != args.frames_per_clip || !args.pool.labels || args.pool.svm.n_features != 2 * args.n_mfcc ||
             args.pool.svm.n_features > 64 || (args.log_mode != 0 && args.log_mode != 2))
             return hipErrorInvalidConfiguration;
-        if (aub) hipLaunchKernelGGL((mfcc2048_kernel<true, true, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        if (aub && args.in_kind == 1) hipLaunchKernelGGL((mfcc2048_kernel<true, true, true, 1>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        else if (aub && args.in_kind == 2) hipLaunchKernelGGL((mfcc2048_kernel<true, true, true, 2>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        else if (aub && args.in_kind == 3) hipLaunchKernelGGL((mfcc2048_kernel<true, true, true, 3>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        else if (aub) hipLaunchKernelGGL((mfcc2048_kernel<true, true, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);
         else hipLaunchKernelGGL((mfcc2048_kernel<true, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);
     } else if (clips) {
-        if (aub) hipLaunchKernelGGL((mfcc2048_kernel<true, false, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        if (aub && args.in_kind == 1) hipLaunchKernelGGL((mfcc2048_kernel<true, false, true, 1>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        else if (aub && args.in_kind == 2) hipLaunchKernelGGL((mfcc2048_kernel<true, false, true, 2>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        else if (aub && args.in_kind == 3) hipLaunchKernelGGL((mfcc2048_kernel<true, false, true, 3>), g, b, Q_BLOCK_BYTES, stream, args, tables);
+        else if (aub) hipLaunchKernelGGL((mfcc2048_kernel<true, false, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);
         else hipLaunchKernelGGL((mfcc2048_kernel<true, false>), g, b, Q_BLOCK_BYTES, stream, args, tables);
     } else {
         if (aub) hipLaunchKernelGGL((mfcc2048_kernel<false, false, true>), g, b, Q_BLOCK_BYTES, stream, args, tables);

@@ -143,7 +143,8 @@ int dsp_mfcc_clips_device(dsp_mfcc_plan *plan, const float *d_signal, long n_cli
  * converted in the load exactly like the reference's WAV readers: mono s/32768
  * (2fa/audio/word/c/main_test.c:198-203); stereo channel 0 (donut-classifier/classifier.c:292-297)
  * or the channel average 0.5(L/32768 + R/32768) (main_test.c:205-217).  samples_per_clip and
- * clip_stride count samples PER CHANNEL.  Halves (mono) the HBM bytes of the float path.   */
+ * clip_stride count samples PER CHANNEL.  Halves (mono) the HBM bytes of the float path.
+ * Plans: n_fft 512 (per-frame log mode) and dsp_mfcc_scrubjay_infer_config (n_fft 2048).     */
 enum { DSP_STEREO_CHANNEL0 = 0, DSP_STEREO_AVERAGE = 1 };
 int dsp_mfcc_clips_pcm16_device(dsp_mfcc_plan *plan, const int16_t *d_pcm, long n_clips, int samples_per_clip,
                                 long clip_stride, int channels, int stereo_mode, float *d_out, int max_frames,
@@ -350,7 +351,8 @@ int dsp_scrubjay_fused_device(dsp_mfcc_plan *plan, dsp_svm *svm, const float *d_
                               int samples_per_clip, long clip_stride, int max_frames, int *d_labels,
                               float *d_decision, float *d_prob1, float *d_feat, void *stream);
 /* The same from int16 PCM (mono / interleaved stereo, as dsp_mfcc_clips_pcm16_device), converted in the kernel's load: bit-identical
- * to the float entry point on the same samples.  Plans of the reference framing (n_fft 512, frame 400, 40 mel filters).             */
+ * to the float entry point on the same samples.  Plans of the reference framing (n_fft 512, frame 400, 40 mel filters) and of
+ * dsp_mfcc_scrubjay_infer_config (the 2048-point front end cepstrum/scrubjay_infer.c itself runs).                                 */
 int dsp_scrubjay_fused_pcm16_device(dsp_mfcc_plan *plan, dsp_svm *svm, const int16_t *d_pcm, long n_clips, int samples_per_clip,
                                     long clip_stride, int channels, int stereo_mode, int max_frames, int *d_labels,
                                     float *d_decision, float *d_prob1, float *d_feat, void *stream);

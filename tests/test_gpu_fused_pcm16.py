@@ -39,11 +39,23 @@ def test_scrubjay_fused_on_int16_equals_the_float_path(golden):
         want = sj(torch.from_numpy((st[:, :, 0].astype(np.float32) + st[:, :, 1].astype(np.float32)) / np.float32(65536.0)).cuda(), 500, fused=True)
         assert torch.equal(avg[0], want[0]) and torch.allclose(avg[3], want[3], rtol=0, atol=2e-4)
     assert got[0].shape[0] == 3
-    # plans without an int16 form refuse with a reason
+    # the front end scrubjay_infer.c itself runs (2048 / 1024 streaming frames, aubio semantics): fused and plain, from int16
     from dsp_amd.scrubjay import scrubjay_infer_config
     own = ScrubJay(attrs, config=scrubjay_infer_config(16000))
+    for n_clips, n in ((64, 16000), (5, 1024), (6, 15998), (3, 50000)):
+        pcm = _pcm(n_clips, n, 500 + n)
+        as_f = torch.from_numpy(pcm.astype(np.float32) / np.float32(32768.0)).cuda()
+        for a, b in zip(own.pcm16(torch.from_numpy(pcm).cuda(), 500), own(as_f, 500, fused=True)):
+            assert torch.equal(a, b), (n_clips, n)
+        assert torch.equal(own.plan.clips_pcm16(torch.from_numpy(pcm).cuda(), 500), own.plan.clips(as_f, 500))
+        st = _pcm(n_clips, n, 600 + n, stereo=True)
+        for a, b in zip(own.pcm16(torch.from_numpy(st).cuda(), 500, stereo_mode=dsp_amd.STEREO_CHANNEL0),
+                        own(torch.from_numpy(st[:, :, 0].astype(np.float32) / np.float32(32768.0)).cuda(), 500, fused=True)):
+            assert torch.equal(a, b)
+    # plans without an int16 form refuse with a reason (the librosa-semantics 2048-point plan of train.py)
+    other = ScrubJay(attrs, config=scrubjay_infer_config(16000, aubio=False))
     with pytest.raises(dsp_amd.DspError):
-        own.pcm16(torch.from_numpy(_pcm(4, 16000, 1)).cuda(), 500)
+        other.pcm16(torch.from_numpy(_pcm(4, 16000, 1)).cuda(), 500)
 
 
 def test_classify_signal_on_int16_equals_the_float_path_and_the_reference_clips(golden):
