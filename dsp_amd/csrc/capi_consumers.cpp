@@ -316,4 +316,33 @@ int dsp_upsample_linear_host(const float *in, int old_size, float *out, int new_
     return DSP_OK;
 }
 
+int dsp_fft_real_forward_host(const float *in_time, long n_frames, int frame_length, long in_stride, int n_fft, float *out_freq)
+{
+    if (!in_time || !out_freq || n_frames < 0 || (n_frames > 1 && in_stride < frame_length)) return capi_fail(DSP_EINVAL, "bad argument");
+    if (n_fft < 2 || (n_fft & (n_fft - 1)) || n_fft > 4096 || frame_length < 1 || frame_length > n_fft) return capi_fail(DSP_EINVAL, "n_fft: a power of two <= 4096, 1 <= frame_length <= n_fft");
+    if (n_frames == 0) return DSP_OK;
+    int rc = check_device(0);
+    if (rc < 0) return rc;
+    float *d_in = nullptr, *d_out = nullptr;
+    DSP_CAPI_HIP(hipMalloc(&d_in, (size_t)n_frames * frame_length * 4));
+    if (hipMalloc(&d_out, (size_t)n_frames * n_fft * 8) != hipSuccess) { hipFree(d_in); return capi_fail(DSP_ENOMEM, "hipMalloc"); }
+    hipError_t e = hipMemcpy2D(d_in, (size_t)frame_length * 4, in_time, (size_t)(n_frames > 1 ? in_stride : frame_length) * 4, (size_t)frame_length * 4, (size_t)n_frames, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dsp::launch_fft_real_forward(d_in, n_frames, frame_length, frame_length, n_fft, d_out, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_freq, d_out, (size_t)n_frames * n_fft * 8, hipMemcpyDeviceToHost);
+    hipFree(d_in);
+    hipFree(d_out);
+    if (e != hipSuccess) return capi_fail(DSP_EHIP, hipGetErrorString(e));
+    return DSP_OK;
+}
+
+/* 2fa/audio/word/c/mfcc.c:16 (non-static there; SURVEY 8b lists it as an optional same-layer symbol): FRAME_LENGTH = 400 samples in,
+ * MFCC_N_FFT = 512 complex bins out.  Same contract: void; a failure leaves the reason in dsp_last_error() and zeros in out_freq. */
+void fft_real_forward(const float *in_time, float *out_freq)
+{
+    if (out_freq && dsp_fft_real_forward_host(in_time, 1, 400, 400, 512, out_freq) < 0) {
+        std::fprintf(stderr, "libdsp_amd: fft_real_forward: %s\n", dsp_last_error());
+        for (int i = 0; i < 1024; ++i) out_freq[i] = 0.0f;
+    }
+}
+
 }  // extern "C"

@@ -177,4 +177,44 @@ hipError_t launch_upsample_linear(const float *in, long n_clips, int old_size, l
     return hipGetLastError();
 }
 
+// ---- fft_real_forward (2fa/audio/word/c/mfcc.c:16-95) as its own entry point -------------------------------------------------
+// The reference's non-static helper: frame_length real samples, zero-padded to n_fft, forward transform, ALL n_fft complex bins
+// interleaved [re, im].  Inside compute_mfcc the transform lives in the MFCC kernels' registers (mfcc_kernels.hip); this batch kernel
+// serves callers that link the symbol itself: one 256-thread block per frame, radix-2 Stockham through LDS (9 passes at n_fft = 512),
+// twiddles from sincospif (the reference runs a float32 recurrence; the gate is 1e-4 of the frame's L-inf norm, as for the MFCCs).
+__global__ __launch_bounds__(256) void fft_real_forward_kernel(const float *__restrict__ in, long n_frames, int frame_length, long in_stride, int n_fft,
+                                                               float *__restrict__ out)
+{
+    extern __shared__ float2 fbuf[];                       // [2][n_fft]
+    const long fr = blockIdx.x;
+    if (fr >= n_frames) return;
+    float2 *a = fbuf, *b = fbuf + n_fft;
+    for (int i = threadIdx.x; i < n_fft; i += 256) a[i] = make_float2(i < frame_length ? in[fr * in_stride + i] : 0.0f, 0.0f);
+    __syncthreads();
+    for (int ns = 1; ns < n_fft; ns <<= 1) {               // butterfly j: k = j % ns, inputs x[j], x[j + n/2] W_{2 ns}^k, outputs y[(j - k) 2 + k], + ns
+        for (int j = threadIdx.x; j < n_fft / 2; j += 256) {
+            const int k = j % ns;
+            float sn, cs;
+            sincospif(-(float)k / (float)ns, &sn, &cs);
+            const float2 u = a[j], v = a[j + n_fft / 2];
+            const float2 t = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+            const int o = (j - k) * 2 + k;
+            b[o] = make_float2(u.x + t.x, u.y + t.y);
+            b[o + ns] = make_float2(u.x - t.x, u.y - t.y);
+        }
+        __syncthreads();
+        float2 *sw = a; a = b; b = sw;
+    }
+    for (int i = threadIdx.x; i < n_fft; i += 256) reinterpret_cast<float2 *>(out)[fr * n_fft + i] = a[i];
+}
+
+hipError_t launch_fft_real_forward(const float *in, long n_frames, int frame_length, long in_stride, int n_fft, float *out, hipStream_t stream)
+{
+    if (n_frames <= 0) return hipSuccess;
+    if (n_fft < 2 || (n_fft & (n_fft - 1)) || n_fft > 4096 || frame_length < 0 || frame_length > n_fft || n_frames >= (1L << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fft_real_forward_kernel, dim3((unsigned)n_frames), dim3(256), (size_t)2 * n_fft * sizeof(float2), stream, in, n_frames, frame_length,
+                       in_stride, n_fft, out);
+    return hipGetLastError();
+}
+
 }  // namespace dsp

@@ -46,4 +46,7 @@ hipError_t launch_speaker_llr(const GmmDev &target, const GmmDev &ubm, const flo
 hipError_t launch_upsample_linear(const float *in, long n_clips, int old_size, long in_stride, float *out, int new_size,
                                   long out_stride, hipStream_t stream);
 
+// fft_real_forward (mfcc.c:16-95): out[f][n_fft] complex interleaved of the frame_length real samples at in + f * in_stride, zero-padded
+hipError_t launch_fft_real_forward(const float *in, long n_frames, int frame_length, long in_stride, int n_fft, float *out, hipStream_t stream);
+
 }  // namespace dsp

@@ -86,7 +86,7 @@ PREFILTER_NONE, PREFILTER_BUTTER_1000_3000, PREFILTER_BUTTER_3000_7500 = 0, 1, 2
 
 # every symbol include/dsp_amd.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "compute_mfcc", "dsp_classify",
+    "compute_mfcc", "fft_real_forward", "dsp_fft_real_forward_host", "dsp_classify",
     "dsp_classify_default_config_f64", "dsp_classify_batch_host_f64", "dsp_classify_batch_device_f64",
     "dsp_classify_batch_pcm16_host_f64", "dsp_classify_batch_pcm16_device_f64", "dsp_classify_release_f64", "dsp_classify_stats_f64", "dsp_classify_debug_f64",
     "dsp_classify_default_config", "dsp_classify_batch_host_cfg", "dsp_classify_batch_device_cfg", "dsp_sum_intense_f32",
@@ -144,6 +144,8 @@ def load() -> C.CDLL:
     vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.c_int
     cfgp = C.POINTER(MfccConfig)
     L.compute_mfcc.argtypes = [vp, ip, vp, ip]; L.compute_mfcc.restype = ip
+    L.fft_real_forward.argtypes = [vp, vp]; L.fft_real_forward.restype = None
+    L.dsp_fft_real_forward_host.argtypes = [vp, C.c_long, ip, C.c_long, ip, vp]; L.dsp_fft_real_forward_host.restype = ip
     L.dsp_mfcc_default_config.argtypes = [cfgp]; L.dsp_mfcc_default_config.restype = None
     L.dsp_mfcc_scrubjay_infer_config.argtypes = [cfgp, ip]; L.dsp_mfcc_scrubjay_infer_config.restype = None
     L.dsp_mfcc_plan_create.argtypes = [cfgp, ip, C.POINTER(vp)]; L.dsp_mfcc_plan_create.restype = ip

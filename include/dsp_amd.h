@@ -139,6 +139,12 @@ int dsp_mfcc_clips_device(dsp_mfcc_plan *plan, const float *d_signal, long n_cli
                           int samples_per_clip, long clip_stride, float *d_out,
                           int max_frames, void *stream);
 
+/* fft_real_forward (2fa/audio/word/c/mfcc.c:16-95; non-static there, so callers may link it): 400 real samples, zero-padded to 512,
+ * forward transform, all 512 complex bins interleaved [re0, im0, re1, im1, ...].  Host pointers; void like the reference (a failure:
+ * zeros out, reason in dsp_last_error()).  dsp_fft_real_forward_host: the same for a batch and any power-of-two n_fft <= 4096.    */
+void fft_real_forward(const float *in_time, float *out_freq);
+int dsp_fft_real_forward_host(const float *in_time, long n_frames, int frame_length, long in_stride, int n_fft, float *out_freq);
+
 /* PCM16 ingestion on the device: the same framing on interleaved int16 PCM,
  * converted in the load exactly like the reference's WAV readers: mono s/32768
  * (2fa/audio/word/c/main_test.c:198-203); stereo channel 0 (donut-classifier/classifier.c:292-297)

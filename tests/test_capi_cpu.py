@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "dsp_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(compute_mfcc|classify\w*|dsp_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(compute_mfcc|fft_real_forward|classify\w*|dsp_\w+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported():

@@ -451,3 +451,39 @@ print("RCCL-ONE-RANK-OK")
         pytest.skip("RCCL could not bring up a one-rank communicator on this box (before any dsp_amd code ran): "
                     + (r.stderr.strip().splitlines() or ["no stderr"])[-1][:300])
     assert "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_fft_real_forward_entry_point_vs_the_reference():
+    """fft_real_forward (2fa/audio/word/c/mfcc.c:16-95, non-static there): 400 samples -> 512 complex bins, against the compiled
+    reference where oracle/_ref is present and the oracle's reference-order restatement (bit-exact with it on CPU), within the MFCC
+    gate's 1e-4 of the frame's L-inf norm; the batch form for other sizes against numpy's float64 transform."""
+    import ctypes as C
+    from dsp_amd import lib as L
+    from oracle import oracle as O
+    lib = L.load()
+    rng = np.random.default_rng(8)
+    frames = [S.uniform_pm1(400, 3), (S.uniform_pm1(400, 4) * np.float32(1e-3)), np.zeros(400, np.float32),
+              np.sin(2 * np.pi * 1000 * np.arange(400) / 16000).astype(np.float32), rng.standard_normal(400).astype(np.float32) * 5]
+    for x in frames:
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.full(1024, 7.0, np.float32)
+        lib.fft_real_forward(x.ctypes.data, out.ctypes.data)
+        ref = O.fft_real_forward(x)
+        scale = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(out - ref.reshape(-1)).max() <= 1e-4 * scale or scale <= 1e-30
+        try:
+            rl = O.ref_mfcc_lib()
+        except OSError:
+            rl = None                                            # (oracle/_ref is built where /root/reference exists and travels with the tree)
+        if rl is not None:
+            cref = np.empty(1024, np.float32)
+            rl.fft_real_forward(x, cref)
+            assert np.abs(out - cref).max() <= 1e-4 * max(np.abs(cref).max(), 1e-30)
+    for n_fft, flen, n in ((512, 512, 7), (1024, 800, 3), (64, 64, 5), (2048, 2048, 2)):
+        x = rng.standard_normal((n, flen)).astype(np.float32)
+        out = np.empty((n, n_fft, 2), np.float32)
+        L.check(lib.dsp_fft_real_forward_host(x.ctypes.data, n, flen, flen, n_fft, out.ctypes.data), "fft batch")
+        want = np.fft.fft(np.pad(x.astype(np.float64), ((0, 0), (0, n_fft - flen))), axis=1)
+        got = out[..., 0] + 1j * out[..., 1]
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    assert lib.dsp_fft_real_forward_host(x.ctypes.data, 1, 100, 100, 48, out.ctypes.data) < 0
