@@ -543,29 +543,31 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 // =====================================================================================================================================
 // recompute + float64 transform of listed segments
 // =====================================================================================================================================
-// A wavefront takes 16 work items (segments) at a time: lane (f, j) = (item, quarter) loads the restart state of its quarter, runs the
-// filter over its 64 samples -- the recurrence and the taps on each sample as classifier.c:427-441 writes them -- and leaves y in the
-// item's LDS row; then the wave transforms the 16 rows two at a time (fft_frame).  x reaches the rows through coalesced 16-byte loads
-// (a segment is 2 KB of contiguous float64) and is overwritten in place by y.
+// A wavefront takes 8 work items (segments) at a time: lane (f, j) = (item, quarter), 32 lanes, loads the restart state of its quarter,
+// runs the filter over its 64 samples -- the recurrence and the taps on each sample as classifier.c:427-441 writes them -- and leaves y
+// in the item's LDS row; then the wave transforms the 8 rows two at a time, each IN PLACE in its own row (fft_frame_inplace).  x reaches
+// the rows through coalesced 16-byte loads (a segment is 2 KB of contiguous float64), one pass ahead, and is overwritten by y.
+// (First form of this round: 16 items per pass and fft_frame's two buffers -- 159 KB of LDS per block, ONE wave per SIMD, every phase
+// bound by its own latencies: 1.6 ms for the 872 k segments of the bench's listed clips.  Half the items per pass leave half the lanes
+// idle in the filter phase, which is bound by its dependent chain anyway; two waves per SIMD hide each other's latencies.)
 //   MAPS = false  items = the frames on the work list want (want[0] entries, frame numbers clip * T + t): loud[frame] = 0 / 1
 //   MAPS = true   items = all T segments of the clips on the work list hits: sxx[entry][t][129] = U * PSD
-constexpr int RC_FRAMES = 16;                    // items per wave pass
+constexpr int RC_FRAMES = 8;                     // items per wave pass
 constexpr int RC_CHUNK_LD = kCkStrideF64 + 2;     // doubles per quarter in an LDS row (+2: the four lanes of an item start on different banks)
-constexpr int RC_ROW_LD = kCkPerSegF64 * RC_CHUNK_LD + 2;      // 266 doubles per row (16-byte aligned rows)
+constexpr int RC_ROW_LD = 2 * kInplaceCd;         // 268 doubles per row: the transform's in-place image (134 complex slots) fits it
+static_assert(RC_ROW_LD >= kCkPerSegF64 * RC_CHUNK_LD && RC_ROW_LD % 2 == 0, "a row holds the four padded quarters and is 16-byte aligned");
 template <bool MAPS, int IN, bool EVEN_B>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void spec_f64_from_ckpt_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T, const IirCoefD c,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void spec_f64_from_ckpt_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T, const IirCoefD c,
                                                                  const double *__restrict__ ck, const SpecTablesD *__restrict__ tab,
                                                                  const int *__restrict__ worklist, double *__restrict__ sxx, int *__restrict__ loud,
                                                                  double mid_power, double midpoint_db, double guard, int vec_ok)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [wave] rows[16][RC_ROW_LD] doubles, then [wave][half] ping (kPingCd cd), then the twiddles
+    // [wave] rows[8][RC_ROW_LD] doubles, then the twiddles
     double *rows_all = reinterpret_cast<double *>(smem);
-    cd *ping_all = reinterpret_cast<cd *>(smem + (size_t)4 * RC_FRAMES * RC_ROW_LD * sizeof(double));
-    FftTwiddles &tw = *reinterpret_cast<FftTwiddles *>(smem + (size_t)4 * RC_FRAMES * RC_ROW_LD * sizeof(double) + (size_t)8 * kPingCd * sizeof(cd));
+    FftTwiddles &tw = *reinterpret_cast<FftTwiddles *>(smem + (size_t)4 * RC_FRAMES * RC_ROW_LD * sizeof(double));
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, half = lane >> 5, i = lane & 31;
     double *rows = rows_all + (size_t)wib * RC_FRAMES * RC_ROW_LD;
-    cd *b0 = ping_all + (size_t)(wib * 2 + half) * kPingCd;
     fill_twiddles(tw, tab, threadIdx.x);
     __syncthreads();
     FftLane L;
@@ -573,7 +575,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const double U = tab->U;
     const long total = MAPS ? (long)worklist[0] * T : (long)worklist[0];
     const long wave = (long)blockIdx.x * 4 + wib, n_waves = (long)gridDim.x * 4;
-    const int f = lane >> 2, j = lane & 3;                              // recompute role: item f of the pass, quarter j
+    const int f = (lane >> 2) & (RC_FRAMES - 1), j = lane & 3;          // recompute role (lanes 0 .. 31): item f of the pass, quarter j
+    const bool filters = lane < 4 * RC_FRAMES;
     if (wave * RC_FRAMES >= total) return;
     // (clip, t) of work item `it`
     auto item_of = [&](long it, long &clip, int &t) {
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         request(item0 + n_waves * RC_FRAMES);
         wave_sync_lds();
         // ---- the filter over the quarter: classifier.c:427-441 per sample, y over x in place ----
-        {
+        if (filters) {
             double *row = rows + f * RC_ROW_LD + j * RC_CHUNK_LD;
 #pragma unroll 1
             for (int h0 = 0; h0 < kCkStrideF64; h0 += 16) {
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int r = 0; r < 4; ++r) x[r] = *reinterpret_cast<const d2 *>(row + r * RC_CHUNK_LD + 2 * i);
             wave_sync_lds();                                             // the row becomes the transform's second buffer
             double m[4], m128;
-            fft_frame(x, L, tw, b0, reinterpret_cast<cd *>(row), i, m, m128);
+            fft_frame_inplace(x, L, tw, reinterpret_cast<cd *>(row), i, m, m128);
             if (MAPS) {
                 if (it < total) {
                     double *out = sxx + it * (long)kSpecBins;
@@ -843,7 +846,7 @@ hipError_t launch_iir2_screen_f64(const void *x, int in_kind, long n_clips, int 
 
 namespace {
 
-constexpr size_t kRcSmem = (size_t)4 * RC_FRAMES * RC_ROW_LD * sizeof(double) + (size_t)8 * kPingCd * sizeof(cd) + sizeof(FftTwiddles);
+constexpr size_t kRcSmem = (size_t)4 * RC_FRAMES * RC_ROW_LD * sizeof(double) + sizeof(FftTwiddles);
 
 template <bool MAPS, int IN, bool EVEN_B>
 hipError_t launch_rc(const void *x, long n_clips, int n, long stride, const IirCoefD &c, const double *ck, const SpecTablesD *tab, const int *worklist,

@@ -169,6 +169,76 @@ __device__ __forceinline__ void fft_frame(const d2 (&x)[4], const FftLane &L, co
     m128 = r128 * r128;
 }
 
+// fft_frame with ONE buffer: every stage's lane writes its four outputs to the four slots it read, so the transform runs in place in a
+// 134-slot image (the frame's own LDS row, once its samples are in registers) and needs no second buffer -- which is what lets the
+// recompute kernel hold two waves per SIMD.  The butterflies, twiddles and their order are fft_frame's (the data-flow graph of a
+// Stockham autosort FFT and of the in-place form are the same; only where an element lives differs), so the results are fft_frame's
+// bit for bit.  Slot of logical element m after stage p = 1: (m >> 2) + 32 (m & 3); after p = 4: (m >> 4) + 8 ((m >> 2) & 3) + 32 (m & 3);
+// after p = 16 and p = 64: Zslot(m).  Every 32-slot block is shifted by two slots (PA) to spread the lanes that differ in i & 3 over the
+// banks.  Checked against numpy by tools/emulate_f64_inplace_fft.py.
+constexpr int kInplaceCd = kSpecSeg / 2 + 6;
+__device__ __forceinline__ int fft_pa(int a) { return a + 2 * (a >> 5); }
+__device__ __forceinline__ int fft_zslot(int m) { return (m >> 6) + 2 * ((m >> 4) & 3) + 8 * ((m >> 2) & 3) + 32 * (m & 3); }
+__device__ __forceinline__ void fft_frame_inplace(const d2 (&x)[4], const FftLane &L, const FftTwiddles &tw, cd *__restrict__ b, int i,
+                                                  double (&m)[4], double &m128)
+{
+    const double sum = half_wave_sum(((x[0].x + x[0].y) + (x[1].x + x[1].y)) + ((x[2].x + x[2].y) + (x[3].x + x[3].y)));
+    const double mean = sum / (double)kSpecSeg;                      // classifier.c:551-561 detrend
+    cd u[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = {(x[r].x - mean) * L.win[2 * r], (x[r].y - mean) * L.win[2 * r + 1]};
+    // stage p = 1
+    fft4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[fft_pa(i + 32 * r)] = u[r];
+    wave_sync_lds();
+    // stage p = 4
+    const int a4 = (i >> 2) + 32 * (i & 3);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = b[fft_pa(a4 + 8 * r)];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) u[r] = cmul(u[r], L.t4[r - 1].re, L.t4[r - 1].im);
+    fft4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[fft_pa(a4 + 8 * r)] = u[r];
+    wave_sync_lds();
+    // stage p = 16
+    const int a16 = (i >> 4) + 8 * ((i >> 2) & 3) + 32 * (i & 3);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = b[fft_pa(a16 + 2 * r)];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) u[r] = cmul(u[r], L.t16[r - 1].re, L.t16[r - 1].im);
+    fft4(u[0], u[1], u[2], u[3]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[fft_pa(a16 + 2 * r)] = u[r];
+    wave_sync_lds();
+    // stage p = 64, radix 2: butterflies b = i and i + 32 on (x[b], x[b + 64]); element i + 32 q lives in slot a64 + (q >> 1) + 4 (q & 1)
+    const int a64 = 2 * (i >> 4) + 8 * ((i >> 2) & 3) + 32 * (i & 3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) u[q] = b[fft_pa(a64 + (q >> 1) + 4 * (q & 1))];
+    {
+        const cd a0 = cmul(u[2], L.t2[0].re, L.t2[0].im), a1 = cmul(u[3], L.t2[1].re, L.t2[1].im);
+        b[fft_pa(a64)] = u[0] + a0; b[fft_pa(a64 + 1)] = u[0] - a0;              // Z[i], Z[i + 64]
+        b[fft_pa(a64 + 4)] = u[1] + a1; b[fft_pa(a64 + 5)] = u[1] - a1;          // Z[i + 32], Z[i + 96]
+    }
+    wave_sync_lds();
+    // X[k] = (A + B) / 2 + W256^k (A - B) / (2 i), A = Z[k], B = conj(Z[128 - k])
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = i + 32 * r;
+        const cd A = b[fft_pa(fft_zslot(k))], Zb = b[fft_pa(fft_zslot((128 - k) & 127))];
+        const cd e2 = {A.re + Zb.re, A.im - Zb.im}, d = {A.re - Zb.re, A.im + Zb.im};
+        const cd o2 = {d.im, -d.re};
+        const cd w = tw.w256[k];
+        const cd x2 = e2 + cmul(o2, w.re, w.im);
+        const double re = 0.5 * x2.re, im = 0.5 * x2.im;
+        m[r] = (re * re + im * im) * ((r == 0 && i == 0) ? 1.0 : 2.0);
+    }
+    const cd Z0 = b[fft_pa(fft_zslot(0))];
+    const double r128 = Z0.re - Z0.im;                               // X[128] = E[0] - O[0]
+    m128 = r128 * r128;
+}
+
 // "one of this frame's 129 cells is above the midpoint threshold", from the lane's m[] / m128 (U * PSD): above / below the band
 // around U x threshold: decided; inside it (rare): the reference's expression, evaluated in ONE rolled loop (inlined per cell, the
 // float64 log10 cost the kernel 40 VGPRs).  Returns the verdict of this lane's half-wave (the same in its 32 lanes).
