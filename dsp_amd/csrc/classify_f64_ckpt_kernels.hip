@@ -554,8 +554,8 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 //   MAPS = true   items = all T segments of the clips on the work list hits: sxx[entry][t][129] = U * PSD
 constexpr int RC_FRAMES = 8;                     // items per wave pass
 constexpr int RC_CHUNK_LD = kCkStrideF64 + 2;     // doubles per quarter in an LDS row (+2: the four lanes of an item start on different banks)
-constexpr int RC_ROW_LD = 2 * kInplaceCd;         // 268 doubles per row: the transform's in-place image (134 complex slots) fits it
-static_assert(RC_ROW_LD >= kCkPerSegF64 * RC_CHUNK_LD && RC_ROW_LD % 2 == 0, "a row holds the four padded quarters and is 16-byte aligned");
+constexpr int RC_ROW_LD = 296;                    // doubles per row: 2368 B = 64 mod 256, so that the 32 filter lanes (item f, quarter j: f x 2368 + j x 528 bytes) start on different banks
+static_assert(RC_ROW_LD >= kCkPerSegF64 * RC_CHUNK_LD && RC_ROW_LD >= 2 * kInplaceCd && RC_ROW_LD % 2 == 0, "a row holds the four padded quarters / the transform's image and is 16-byte aligned");
 template <bool MAPS, int IN, bool EVEN_B>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void spec_f64_from_ckpt_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T, const IirCoefD c,
                                                                  const double *__restrict__ ck, const SpecTablesD *__restrict__ tab,

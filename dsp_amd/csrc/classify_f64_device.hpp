@@ -174,10 +174,12 @@ __device__ __forceinline__ void fft_frame(const d2 (&x)[4], const FftLane &L, co
 // recompute kernel hold two waves per SIMD.  The butterflies, twiddles and their order are fft_frame's (the data-flow graph of a
 // Stockham autosort FFT and of the in-place form are the same; only where an element lives differs), so the results are fft_frame's
 // bit for bit.  Slot of logical element m after stage p = 1: (m >> 2) + 32 (m & 3); after p = 4: (m >> 4) + 8 ((m >> 2) & 3) + 32 (m & 3);
-// after p = 16 and p = 64: Zslot(m).  Every 32-slot block is shifted by two slots (PA) to spread the lanes that differ in i & 3 over the
-// banks.  Checked against numpy by tools/emulate_f64_inplace_fft.py.
-constexpr int kInplaceCd = kSpecSeg / 2 + 6;
-__device__ __forceinline__ int fft_pa(int a) { return a + 2 * (a >> 5); }
+// after p = 16 and p = 64: Zslot(m).  PA swizzles a slot's low bits by its higher digits (XOR with 5 x digit 6:5 and 4 x digit 4:3, found by
+// the bank model of tools/f64_inplace_banks.py: 240 LDS cycles per transform against 208 conflict-free; a plain shift of two slots per
+// 32-slot block: 348 -- measured with it, half of the kernel's LDS cycles were conflicts).  Checked against numpy by
+// tools/emulate_f64_inplace_fft.py.
+constexpr int kInplaceCd = kSpecSeg / 2;
+__device__ __forceinline__ int fft_pa(int a) { return a ^ ((5 * ((a >> 5) & 3)) & 31) ^ ((4 * ((a >> 3) & 3)) & 7); }
 __device__ __forceinline__ int fft_zslot(int m) { return (m >> 6) + 2 * ((m >> 4) & 3) + 8 * ((m >> 2) & 3) + 32 * (m & 3); }
 __device__ __forceinline__ void fft_frame_inplace(const d2 (&x)[4], const FftLane &L, const FftTwiddles &tw, cd *__restrict__ b, int i,
                                                   double (&m)[4], double &m128)

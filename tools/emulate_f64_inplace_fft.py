@@ -6,8 +6,8 @@ import numpy as np
 N = 128
 
 
-def PA(a):                      # padding of the physical slot: every 32-slot block shifted by two slots (bank spread)
-    return a + 2 * (a >> 5)
+def PA(a):                      # swizzle of the physical slot (bank spread; tools/f64_inplace_banks.py)
+    return a ^ ((5 * ((a >> 5) & 3)) & 31) ^ ((4 * ((a >> 3) & 3)) & 7)
 
 
 def physZ(m):                   # slot of logical element m after stages 3 / 4
@@ -21,7 +21,7 @@ def fft4(u):
 
 
 def run(z):
-    buf = np.zeros(PA(127) + 1, complex)
+    buf = np.zeros(max(PA(a) for a in range(N)) + 1, complex)
     W = lambda num, den: np.exp(-2j * np.pi * num / den)
     # stage p = 1: inputs from registers, outputs r -> slot i + 32 r
     for i in range(32):
@@ -63,4 +63,4 @@ for i in range(32):
     for q in range(4):
         assert (q >> 1) + 2 * (i >> 4) + 4 * (q & 1) + 8 * ((i >> 2) & 3) + 32 * (i & 3) == physZ(i + 32 * q)
 assert sorted(PA(physZ(k)) for k in range(N)) == sorted(PA(a) for a in range(N))
-print("address maps consistent; buffer slots:", PA(127) + 1)
+print("address maps consistent; buffer slots:", max(PA(a) for a in range(N)) + 1)
