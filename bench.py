@@ -76,6 +76,35 @@ def pmc_traffic(workload: str, units_per_launch: int):
     return best
 
 
+def sq_fractions(workload: str):
+    """VALU / LDS busy fractions of the workload's dominant kernel from the committed SQ-counter pass (profiles/*_sq_counters*.json,
+    written by tools/sq_fractions.py on the GPU box: SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CU_CYCLES and SQ_LDS_IDX_ACTIVE / the same).
+    Replayed, like the traffic figure: the line says so."""
+    import glob
+    import re
+    best = None
+    natural = lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(p))]   # noqa: E731
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters*.json")), key=natural):
+        try:
+            d = json.load(open(f))
+            if d.get("workload") == workload:
+                best = dict(d, file=os.path.basename(f))
+        except Exception:  # noqa: BLE001
+            pass
+    return best
+
+
+def roofline_extras(workload: str, units: int):
+    """The replayed parts of the roofline object: HBM traffic of one step (PMC) and the VALU / LDS fractions, each with its source."""
+    tr, sq = pmc_traffic(workload, units), sq_fractions(workload)
+    out = {"traffic": tr["hbm_bytes_per_launch"] if tr else None,
+           "traffic_replayed": bool(tr),
+           "traffic_source": ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same command, profiles/" + tr["file"]) if tr else None}
+    if sq:
+        out.update({"valu_frac": sq.get("valu_frac"), "lds_frac": sq.get("lds_frac"), "sq_source": "replayed: profiles/" + sq["file"]})
+    return out
+
+
 _REF_WORKER = r"""
 import ctypes, sys, time
 import numpy as np
@@ -284,8 +313,10 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
                 + ("two kernels (MFCC matrix written, then the net)" if two else "ONE kernel (the tile epilogue feeds layer 1; the MFCC matrix never reaches HBM)"))
         kernel = "mfcc512_wave_kernel + stop_tail_kernel" if two else "mfcc512_wave_kernel<POOL = 2>"
     elif args.workload == "config3":
-        n = args.clips or 1_000_000
-        frames = torch.rand((n, 1024), device=dev, generator=gen) * 2 - 1
+        n = args.clips or 10_000_000                          # BASELINE configs[2]'s own size: 41 GB of frames in HBM (--clips 1000000: round 3's line)
+        frames = torch.empty((n, 1024), device=dev)
+        for i0 in range(0, n, 1_000_000):                      # filled in pieces: torch.rand's temporaries for 41 GB at once would double it
+            frames[i0:i0 + 1_000_000] = torch.rand((min(1_000_000, n - i0), 1024), device=dev, generator=gen) * 2 - 1
         plan = dsp_amd.MfccPlan(dsp_amd.default_config(n_fft=1024, frame_length=1024, hop_length=1024, n_mels=128, prefilter=2), local)
         out = torch.empty((n, 13), device=dev)
         step = lambda: plan.frames(frames, out)               # noqa: E731
@@ -389,15 +420,13 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
         elapsed = float(t.item())
     if rank == 0:
         achieved = bytes_per * n / (ms * 1e-3) / 1e9
-        tr = pmc_traffic(args.workload, n)
         print(json.dumps({
             "metric": f"{args.workload}: {unit}", "value": world * units * steps / elapsed, "unit": unit, "n_gpus": world,
             "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.workload.startswith("classify_f64") else "f32", "data": "synthetic",
             "config": {"workload": what, "clock_settle_s": args.settle},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                         "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/" + tr["file"]) if tr else None,
+                         **roofline_extras(args.workload, n),
                          "kernel": kernel, "kernel_ms": ms, "kernel_ms_min": kstats["min"], "kernel_ms_median": kstats["median"],
                          "algorithmic_bytes_per_launch": bytes_per * n},
             "sensors": sensor_block(sens, s_before, s_during, s_after),
@@ -651,10 +680,7 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_FRAME * n},
             "sensors": sensor_block(sens, s_before, s_during, s_after),
         }
-        tr = pmc_traffic("frames", n)
-        if tr:
-            line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            line["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/" + tr["file"]
+        line["roofline"].update(roofline_extras("frames", n))
         line["step_calls"] = args.warmup + args.steps if args.settle <= 0 else None      # tools/traffic.py divides by this
         if rehearsal:
             line["rehearsal"] = f"gloo backend, {world} ranks sharing cuda:0 -- control-flow check only, not a measurement"

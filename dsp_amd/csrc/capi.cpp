@@ -4,6 +4,7 @@
 // buffers), validates arguments the way the reference does, and enqueues the
 // gfx950 kernels.  No CPU fallback exists: without a HIP device every compute
 // entry point fails and says why through dsp_last_error().
+#include "diag_guard.hpp"
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -49,6 +49,7 @@ struct Scratch {
     int device = -1;
     dsp::SpecTablesD *tab = nullptr;
     dsp::ScreenTablesD *scr = nullptr;
+    unsigned long long *minmax = nullptr;  // [clip][2]: smallest / largest positive cell of a listed clip's map (double bits)
     int *cu_table = nullptr;               // launch_iir2_screen_f64's per-CU arrival counters
     double U = 0.0;
     // per pass of `cap_clips` clips with `cap_T` columns
@@ -69,8 +70,9 @@ struct Scratch {
 
     void free_pass()
     {
-        for (void *p : {(void *)ck_bp, (void *)ck_mp, (void *)s_bp, (void *)mids, (void *)labels, (void *)loud, (void *)want, (void *)n_mids, (void *)hits, (void *)trace})
+        for (void *p : {(void *)ck_bp, (void *)ck_mp, (void *)s_bp, (void *)mids, (void *)labels, (void *)loud, (void *)want, (void *)n_mids, (void *)hits, (void *)trace, (void *)minmax})
             if (p) (void)hipFree(p);
+        minmax = nullptr;
         ck_bp = ck_mp = s_bp = mids = nullptr; labels = loud = want = n_mids = hits = nullptr; trace = nullptr;
         cap_clips = 0; cap_T = 0;
     }
@@ -139,9 +141,9 @@ int run(const dsp_classify_config_f64 &cfg, Scratch &w, Pipeline pl, const void 
         const double guard = dsp::f64_threshold_guard();
         DSP_CAPI_HIP(dsp::launch_iir2_screen_f64(d_x, in, cnt, n, stride, c_bp, c_mp, w.ck_bp, w.ck_mp, w.scr, w.U, cfg.midpoint_db, guard, w.loud, w.want, w.cu_table, st));
         DSP_CAPI_HIP(dsp::launch_spec_f64_recheck(d_x, in, cnt, n, stride, c_mp, w.ck_mp, w.tab, w.want, cfg.midpoint_db, guard, w.loud, st));
-        DSP_CAPI_HIP(dsp::launch_classify_f64_midpoints(w.loud, cnt, n, 16000, w.mids, w.n_mids, w.hits, w.labels, tr, st));
-        DSP_CAPI_HIP(dsp::launch_spec_f64_listed_from_ckpt(d_x, in, cnt, n, stride, c_bp, w.ck_bp, w.tab, w.hits, w.s_bp, st));
-        DSP_CAPI_HIP(dsp::launch_classify_f64_bands(w.s_bp, w.hits, cnt, n, 16000, w.U, rule, w.mids, w.n_mids, w.labels, tr, st));
+        DSP_CAPI_HIP(dsp::launch_classify_f64_midpoints(w.loud, cnt, n, 16000, w.mids, w.n_mids, w.hits, w.labels, tr, st, w.minmax));
+        DSP_CAPI_HIP(dsp::launch_spec_f64_listed_from_ckpt(d_x, in, cnt, n, stride, c_bp, w.ck_bp, w.tab, w.hits, w.s_bp, st, w.minmax));
+        DSP_CAPI_HIP(dsp::launch_classify_f64_bands(w.s_bp, w.hits, cnt, n, 16000, w.U, rule, w.mids, w.n_mids, w.labels, tr, st, w.minmax));
         return DSP_OK;
     }
     const double *xd = static_cast<const double *>(d_x);
@@ -194,6 +196,7 @@ int reserve(Scratch &w, int device, Pipeline pl, long clips, int n, size_t x_byt
         DSP_CAPI_HIP(hipMalloc(&w.hits, ((size_t)clips + 1) * sizeof(int)));
         DSP_CAPI_HIP(hipMalloc(&w.labels, (size_t)clips * sizeof(int)));
         DSP_CAPI_HIP(hipMalloc(&w.trace, (size_t)clips * sizeof(dsp::ClassifyTraceD)));
+        DSP_CAPI_HIP(hipMalloc(&w.minmax, (size_t)clips * 2 * sizeof(unsigned long long)));
         w.cap_clips = clips; w.cap_T = (int)TT;
     }
     if (x_bytes > w.cap_x) {

@@ -38,6 +38,7 @@
 //         and the MFMAs + verdicts of table rows 0 .. 63 (bins 0 .. 31, 128) on that tile
 //   X     two tiles behind: the MFMAs + verdicts of rows 64 .. 127 (bins 32 .. 63); writes the segments' flags
 // A tile = 16 samples = one MFMA k-step = one full 128-byte line of a float64 row.  One __syncthreads per tile.
+#include "diag_guard.hpp"
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -45,6 +46,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "classify_f64_device.hpp"
@@ -560,7 +562,8 @@ template <bool MAPS, int IN, bool EVEN_B>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void spec_f64_from_ckpt_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T, const IirCoefD c,
                                                                  const double *__restrict__ ck, const SpecTablesD *__restrict__ tab,
                                                                  const int *__restrict__ worklist, double *__restrict__ sxx, int *__restrict__ loud,
-                                                                 double mid_power, double midpoint_db, double guard, int vec_ok)
+                                                                 double mid_power, double midpoint_db, double guard, int vec_ok,
+                                                                 unsigned long long *__restrict__ minmax)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [wave] rows[8][RC_ROW_LD] doubles, then the twiddles
@@ -688,6 +691,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int r = 0; r < 4; ++r) out[i + 32 * r] = m[r];
                     if (i == 0) out[128] = m128;
+                }
+                if (minmax) {
+                    // the clip's smallest / largest positive cell (classifier.c:105-125 needs them of the whole map): this frame's, over
+                    // the 32 lanes of the half, then one atomic pair -- the band kernel no longer scans the map it reads windows of
+                    double lo = __longlong_as_double(0x7FF0000000000000ll), hi = 0.0;
+                    const double c4 = i == 0 ? m128 : 0.0;
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        const double v = r < 4 ? m[r] : c4;
+                        if (v > 0) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+                    }
+                    auto red = [&](auto ctrl_tag) {
+                        constexpr int CTRL = decltype(ctrl_tag)::value;
+                        const double l2 = dpp_f64<CTRL>(lo), h2 = dpp_f64<CTRL>(hi);
+                        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+                    };
+                    red(std::integral_constant<int, 0xB1>{}); red(std::integral_constant<int, 0x4E>{});
+                    red(std::integral_constant<int, 0x141>{}); red(std::integral_constant<int, 0x140>{});
+                    {   // the neighbouring row of 16 lanes (v_permlane16_swap)
+                        const int llo = __double2loint(lo), lhi = __double2hiint(lo), hlo = __double2loint(hi), hhi = __double2hiint(hi);
+                        const auto a = __builtin_amdgcn_permlane16_swap(llo, llo, false, false), b = __builtin_amdgcn_permlane16_swap(lhi, lhi, false, false);
+                        const auto c2 = __builtin_amdgcn_permlane16_swap(hlo, hlo, false, false), d2_ = __builtin_amdgcn_permlane16_swap(hhi, hhi, false, false);
+                        const double l0 = __hiloint2double(b[0], a[0]), l1 = __hiloint2double(b[1], a[1]);
+                        const double h0 = __hiloint2double(d2_[0], c2[0]), h1 = __hiloint2double(d2_[1], c2[1]);
+                        lo = l0 < l1 ? l0 : l1; hi = h0 > h1 ? h0 : h1;
+                    }
+                    if (i == 0 && it < total && hi > 0) {
+                        long clip; int t;
+                        item_of(it, clip, t);
+                        atomicMin(&minmax[2 * clip], (unsigned long long)__double_as_longlong(lo));
+                        atomicMax(&minmax[2 * clip + 1], (unsigned long long)__double_as_longlong(hi));
+                    }
                 }
             } else {
                 const bool hit = frame_is_loud(m, m128, i, half, U, mid_power, midpoint_db, guard);
@@ -850,7 +885,7 @@ constexpr size_t kRcSmem = (size_t)4 * RC_FRAMES * RC_ROW_LD * sizeof(double) + 
 
 template <bool MAPS, int IN, bool EVEN_B>
 hipError_t launch_rc(const void *x, long n_clips, int n, long stride, const IirCoefD &c, const double *ck, const SpecTablesD *tab, const int *worklist,
-                     double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream)
+                     double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream, unsigned long long *minmax)
 {
     auto kernel = spec_f64_from_ckpt_kernel<MAPS, IN, EVEN_B>;
     static bool attr_set[64] = {false};
@@ -867,27 +902,28 @@ hipError_t launch_rc(const void *x, long n_clips, int n, long stride, const IirC
     const long max_items = n_clips * (long)T;                            // the bound: the list's count is read on the device
     const long blocks = std::min<long>((max_items + 4 * RC_FRAMES - 1) / (4 * RC_FRAMES), resident[dev]);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), kRcSmem, stream, x, n_clips, n, stride, T, c, ck, tab, worklist, sxx, loud, mid_power,
-                       midpoint_db, guard, (int)rows_vec_ok<IN>(x, stride));
+                       midpoint_db, guard, (int)rows_vec_ok<IN>(x, stride), minmax);
     return hipGetLastError();
 }
 
 template <bool MAPS, int IN>
 hipError_t launch_rc_b(const void *x, long n_clips, int n, long stride, const IirCoefD &c, const double *ck, const SpecTablesD *tab, const int *worklist,
-                       double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream)
+                       double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream, unsigned long long *minmax)
 {
-    return even_taps_only(c) ? launch_rc<MAPS, IN, true>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream)
-                             : launch_rc<MAPS, IN, false>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream);
+    return even_taps_only(c) ? launch_rc<MAPS, IN, true>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax)
+                             : launch_rc<MAPS, IN, false>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax);
 }
 
 template <bool MAPS>
 hipError_t launch_rc_k(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c, const double *ck, const SpecTablesD *tab,
-                       const int *worklist, double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream)
+                       const int *worklist, double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream,
+                       unsigned long long *minmax = nullptr)
 {
     switch (in_kind) {
-    case 0: return launch_rc_b<MAPS, 0>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream);
-    case 1: return launch_rc_b<MAPS, 1>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream);
-    case 2: return launch_rc_b<MAPS, 2>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream);
-    case 3: return launch_rc_b<MAPS, 3>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream);
+    case 0: return launch_rc_b<MAPS, 0>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax);
+    case 1: return launch_rc_b<MAPS, 1>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax);
+    case 2: return launch_rc_b<MAPS, 2>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax);
+    case 3: return launch_rc_b<MAPS, 3>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax);
     default: return hipErrorInvalidValue;
     }
 }
@@ -903,10 +939,10 @@ hipError_t launch_spec_f64_recheck(const void *x, int in_kind, long n_clips, int
 }
 
 hipError_t launch_spec_f64_listed_from_ckpt(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const double *ck_bp,
-                                            const SpecTablesD *tables, const int *hits, double *sxx, hipStream_t stream)
+                                            const SpecTablesD *tables, const int *hits, double *sxx, hipStream_t stream, unsigned long long *minmax)
 {
     if (n_clips <= 0 || columns_of(n) <= 0) return hipSuccess;
-    return launch_rc_k<true>(x, in_kind, n_clips, n, stride, c_bp, ck_bp, tables, hits, sxx, nullptr, 0.0, 0.0, 0.0, stream);
+    return launch_rc_k<true>(x, in_kind, n_clips, n, stride, c_bp, ck_bp, tables, hits, sxx, nullptr, 0.0, 0.0, 0.0, stream, minmax);
 }
 
 }  // namespace dsp

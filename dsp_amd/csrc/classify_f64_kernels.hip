@@ -249,15 +249,26 @@ struct BandShared {
 // [129][T] or (FM) [T][129]; times[] / mids[] in LDS.  Returns the label (every thread).
 // FM: the map holds U * PSD (spectrogram_f64_fft_kernel<maps>): a cell is divided by U where its value is used, the minimum and
 // the maximum after they are found (x / U is monotonic)
+// mm (optional): the smallest / largest positive cell of the map as double bits, found by the kernel that wrote it -- the scan is skipped
 template <bool FM>
 __device__ __forceinline__ int band_sums_and_rule(const double *__restrict__ bp, int T, const ClassifyRuleD &rule, const BandRows &bands,
-                                                  const double *times, const double *mids, int n_mid, ClassifyTraceD *tr, BandShared &sh, double U)
+                                                  const double *times, const double *mids, int n_mid, ClassifyTraceD *tr, BandShared &sh, double U,
+                                                  const unsigned long long *__restrict__ mm = nullptr)
 {
     const int tid = threadIdx.x;
     const int cells = kSpecBins * T;
     // ---- clip-global minimum / maximum of the dB map (:105-125): the dB of the smallest / largest positive cell (to_db64 is
     // monotonic: one log10 per clip instead of one per cell) ----
     double lo = 1.7976931348623157e308, hi = -1.7976931348623157e308;
+    if (mm) {
+        if (tid == 0) {
+            const unsigned long long lo_b = mm[0], hi_b = mm[1];
+            sh.red_lo[0] = hi_b ? __longlong_as_double((long long)lo_b) : lo;        // (no positive cell: the scan's own initial values)
+            sh.red_hi[0] = hi_b ? __longlong_as_double((long long)hi_b) : hi;
+            sh.hit = 0;
+        }
+        __syncthreads();
+    } else {
     for (int base = tid; base < cells; base += 256 * kTailLoads) {
         double v[kTailLoads];
 #pragma unroll
@@ -280,6 +291,7 @@ __device__ __forceinline__ int band_sums_and_rule(const double *__restrict__ bp,
             sh.red_hi[tid] = sh.red_hi[tid + o] > sh.red_hi[tid] ? sh.red_hi[tid + o] : sh.red_hi[tid];
         }
         __syncthreads();
+    }
     }
     const bool any_cell = sh.red_hi[0] > 0;
     const double mn = any_cell ? to_db64(FM ? sh.red_lo[0] / U : sh.red_lo[0]) : sh.red_lo[0];
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(256) void classify_f64_tail_kernel(const double *__
 // results do not depend on it), mids[clip][] / n_mids[clip] carry them to classify_f64_bands_kernel; the others are label 0.
 __global__ __launch_bounds__(256) void classify_f64_midpoints_kernel(const int *__restrict__ loud, long n_clips, int T, int fs, double *__restrict__ mids,
                                                                      int *__restrict__ n_mids, int *__restrict__ hits, int *__restrict__ labels,
-                                                                     ClassifyTraceD *__restrict__ trace)
+                                                                     ClassifyTraceD *__restrict__ trace, unsigned long long *__restrict__ minmax)
 {
     __shared__ double times[kMaxColsF64];
     for (int j = threadIdx.x; j < T; j += 256) times[j] = column_time(j, fs);
@@ -450,14 +462,18 @@ __global__ __launch_bounds__(256) void classify_f64_midpoints_kernel(const int *
         }
     }
     if (n_mid == 0) labels[clip] = 0;
-    else hits[1 + atomicAdd(hits, 1)] = (int)clip;
+    else {
+        hits[1 + atomicAdd(hits, 1)] = (int)clip;
+        if (minmax) { minmax[2 * clip] = 0x7FF0000000000000ull; minmax[2 * clip + 1] = 0ull; }      // +inf, 0: the map kernel's atomicMin / atomicMax
+    }
 }
 
 // Band sums and rule of the listed clips: block b takes entries b, b + gridDim.x, ... of the work list; entry e's map is
 // sxx[e][T][129] = U * PSD (spectrogram_f64_fft_kernel<maps> walked the same list).
 __global__ __launch_bounds__(256) void classify_f64_bands_kernel(const double *__restrict__ sxx, const int *__restrict__ hits, int T, int fs, double U,
                                                                  ClassifyRuleD rule, BandRows bands, const double *__restrict__ mids_all,
-                                                                 const int *__restrict__ n_mids, int *__restrict__ labels, ClassifyTraceD *__restrict__ trace)
+                                                                 const int *__restrict__ n_mids, int *__restrict__ labels, ClassifyTraceD *__restrict__ trace,
+                                                                 const unsigned long long *__restrict__ minmax)
 {
     __shared__ double times[kMaxColsF64];
     __shared__ double mids[kMaxMidpoints];
@@ -471,7 +487,8 @@ __global__ __launch_bounds__(256) void classify_f64_bands_kernel(const double *_
         __syncthreads();                                                     // times[] written; the previous entry's mids[] read
         if (tid < n_mid) mids[tid] = mids_all[clip * kMaxMidpoints + tid];
         __syncthreads();
-        const int label = band_sums_and_rule<true>(sxx + (long)e * T * kSpecBins, T, rule, bands, times, mids, n_mid, trace ? trace + clip : nullptr, sh, U);
+        const int label = band_sums_and_rule<true>(sxx + (long)e * T * kSpecBins, T, rule, bands, times, mids, n_mid, trace ? trace + clip : nullptr, sh, U,
+                                                       minmax ? minmax + 2 * clip : nullptr);
         if (tid == 0) labels[clip] = label;
     }
 }
@@ -489,7 +506,7 @@ hipError_t launch_classify_f64_tail(const double *sxx_bp, const double *sxx_mp, 
 }
 
 hipError_t launch_classify_f64_midpoints(const int *loud, long n_clips, int n, int fs, double *mids, int *n_mids, int *hits, int *labels,
-                                         ClassifyTraceD *trace, hipStream_t stream)
+                                         ClassifyTraceD *trace, hipStream_t stream, unsigned long long *minmax)
 {
     const int T = columns_of(n);
     if (n_clips <= 0) return hipSuccess;
@@ -497,12 +514,12 @@ hipError_t launch_classify_f64_midpoints(const int *loud, long n_clips, int n, i
     hipError_t e = hipMemsetAsync(hits, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(classify_f64_midpoints_kernel, dim3((unsigned)((n_clips + 255) / 256)), dim3(256), 0, stream, loud, n_clips, T, fs, mids, n_mids,
-                       hits, labels, trace);
+                       hits, labels, trace, minmax);
     return hipGetLastError();
 }
 
 hipError_t launch_classify_f64_bands(const double *sxx, const int *hits, long n_clips, int n, int fs, double U, const ClassifyRuleD &rule, const double *mids,
-                                     const int *n_mids, int *labels, ClassifyTraceD *trace, hipStream_t stream)
+                                     const int *n_mids, int *labels, ClassifyTraceD *trace, hipStream_t stream, const unsigned long long *minmax)
 {
     const int T = columns_of(n);
     if (n_clips <= 0) return hipSuccess;
@@ -510,7 +527,7 @@ hipError_t launch_classify_f64_bands(const double *sxx, const int *hits, long n_
     static int cache[64] = {0};
     const int resident = resident_blocks_of(classify_f64_bands_kernel, cache);
     const long blocks = std::min<long>(n_clips, 4L * resident);              // the bound: the list's count is read on the device
-    hipLaunchKernelGGL(classify_f64_bands_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, sxx, hits, T, fs, U, rule, band_rows(fs), mids, n_mids, labels, trace);
+    hipLaunchKernelGGL(classify_f64_bands_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, sxx, hits, T, fs, U, rule, band_rows(fs), mids, n_mids, labels, trace, minmax);
     return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@
 // window tables come from the reference's own recurrences evaluated on the host.
 // Parallelism is across clips and frames (embarrassing), not inside a recurrence.
 // Round 1: correct and batched, not yet tuned.
+#include "diag_guard.hpp"
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -170,11 +170,14 @@ hipError_t launch_spectrogram_f64_listed(const double *y, long n_clips, int n, l
                                          double *sxx, hipStream_t stream);
 // find_midpoints' clusters (:747-800) from loud[c][t]: mids[c][kMaxMidpoints], n_mids[c]; clips with midpoints on the work list
 // hits[1 + n_clips] (reset here), label 0 for the others; trace (optional): midpoints, sums zeroed
+// minmax (optional, 2 x n_clips words): reset to (+inf, 0) for the clips with midpoints; launch_spec_f64_listed_from_ckpt then keeps the
+// smallest / largest positive cell of each listed clip's map there (double bits, atomicMin / atomicMax) and launch_classify_f64_bands reads
+// them instead of scanning the map
 hipError_t launch_classify_f64_midpoints(const int *loud, long n_clips, int n, int fs, double *mids, int *n_mids, int *hits, int *labels,
-                                         ClassifyTraceD *trace, hipStream_t stream);
+                                         ClassifyTraceD *trace, hipStream_t stream, unsigned long long *minmax = nullptr);
 // band sums and rule (:105-190) of the listed clips over their frame-major U * PSD maps: labels[c], trace sums
 hipError_t launch_classify_f64_bands(const double *sxx, const int *hits, long n_clips, int n, int fs, double U, const ClassifyRuleD &rule, const double *mids,
-                                     const int *n_mids, int *labels, ClassifyTraceD *trace, hipStream_t stream);
+                                     const int *n_mids, int *labels, ClassifyTraceD *trace, hipStream_t stream, const unsigned long long *minmax = nullptr);
 // the whole tail in one kernel per clip over [c][129][T] float64 PSD maps of the 3000-7500 Hz / 1000-3000 Hz filtered clips
 // (launch_spectrogram_f64): labels[c] = the rule's verdict (classifier.c:184), trace (optional): midpoints and band sums per clip
 hipError_t launch_classify_f64_tail(const double *sxx_bp, const double *sxx_mp, long n_clips, int n, int fs, const ClassifyRuleD &rule,
@@ -209,7 +212,7 @@ hipError_t launch_spec_f64_recheck(const void *x, int in_kind, long n_clips, int
                                    const SpecTablesD *tables, const int *want, double midpoint_db, double guard, int *loud, hipStream_t stream);
 // sxx[entry][t][129] = U * PSD of the 3000-7500 Hz output of the clips on the work list hits, recomputed from ck_bp
 hipError_t launch_spec_f64_listed_from_ckpt(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const double *ck_bp,
-                                            const SpecTablesD *tables, const int *hits, double *sxx, hipStream_t stream);
+                                            const SpecTablesD *tables, const int *hits, double *sxx, hipStream_t stream, unsigned long long *minmax = nullptr);
 // DSP_AMD_F64_GUARD (read per call; tests): the half-width of the band around the threshold inside which the reference's own expression
 // decides, default 2e-9
 double f64_threshold_guard();

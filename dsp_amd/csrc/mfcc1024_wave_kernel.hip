@@ -17,6 +17,7 @@
 //
 // The general Stockham kernel (mfcc1024_kernel.hip) stays as the fallback for filterbanks that need more than three
 // chunk slots per lane.  Reference chain: 2fa/audio/word/c/mfcc.c:142-221 with the constants as parameters.
+#include "diag_guard.hpp"
 #include <hip/hip_runtime.h>
 
 #include "mfcc_device.hpp"

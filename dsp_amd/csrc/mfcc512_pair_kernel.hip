@@ -9,6 +9,7 @@
 // here unchanged, with slot q = q' + 4 f.  The frames never mix: no value of one frame enters an operation of the other.
 // Afterwards lane l holds bins j + 32 r (r = 0..7) of frame f = (l >> 2) & 1, j = (l & 3) + 4 (l >> 3).
 // Tail (untangling, power, sparse mel, 16-frame tile with log + DCT on v_mfma_f32_16x16x4_f32): as in mfcc_kernels.hip.
+#include "diag_guard.hpp"
 #include <hip/hip_runtime.h>
 
 #include "mfcc_device.hpp"

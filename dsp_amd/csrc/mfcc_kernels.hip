@@ -26,6 +26,7 @@
 //
 // The FFT and the 494-non-zero mel product stay on the VALU: they are not dense
 // contractions.  The bound is HBM (2048 B in + 52 B out per frame).
+#include "diag_guard.hpp"
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
