@@ -91,6 +91,23 @@ class StopModel:
                    "dsp_classify_signal_batch_pcm16_device")
         return prob
 
+    def classify_signal_ragged(self, plan: MfccPlan, signal, offsets, stereo_mode: int = 0):
+        """Clips of different lengths in ONE launch (the files main_test.c:254-331 loops over): `signal` is a flat cuda buffer (float32
+        [total], int16 [total] or stereo int16 [total][2]), clip c = samples [offsets[c], offsets[c + 1]) -> P("stop") per clip."""
+        import torch
+        off, n = _lib.c_offsets(offsets)
+        assert signal.is_cuda and signal.stride(-1) == 1 and int(offsets[-1]) <= signal.shape[0]
+        prob = torch.empty(n, dtype=torch.float32, device=signal.device)
+        if signal.dtype == torch.float32:
+            assert signal.dim() == 1
+            _lib.check(self._L.dsp_classify_signal_batch_ragged_device(plan._h, self._h, signal.data_ptr(), n, off, prob.data_ptr(), _stream(signal)),
+                       "dsp_classify_signal_batch_ragged_device")
+        else:
+            assert signal.dtype == torch.int16 and signal.dim() in (1, 2)
+            _lib.check(self._L.dsp_classify_signal_batch_ragged_pcm16_device(plan._h, self._h, signal.data_ptr(), n, off, signal.dim(), int(stereo_mode),
+                                                                             prob.data_ptr(), _stream(signal)), "dsp_classify_signal_batch_ragged_pcm16_device")
+        return prob
+
     def classify_signal(self, signal: np.ndarray) -> float:
         """The reference's classify_signal(signal, num_samples) on a host buffer."""
         signal = np.ascontiguousarray(signal, np.float32)

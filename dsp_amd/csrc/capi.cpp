@@ -126,6 +126,7 @@ struct dsp_mfcc_plan {
     // a workspace (prefilter, DSP_LOG_GLOBAL_REF1 over clips, the *_host entry points) serves ONE stream at a time;
     // the workspace-free paths (frames / clips / pcm16 / fused, per-frame log mode) may be driven from several streams.
     std::recursive_mutex mu;
+    dsp::SpanRing spans;      // ragged batches of the fused clip kernels: the clips' spans on their way to the GPU (capi_util.hpp)
 };
 
 extern "C" {
@@ -383,6 +384,7 @@ void dsp_mfcc_plan_destroy(dsp_mfcc_plan *p)
     if (p->d_clip_floor) hipFree(p->d_clip_floor);
     if (p->d_in) hipFree(p->d_in);
     if (p->d_out) hipFree(p->d_out);
+    p->spans.release();
     delete p;
 }
 
@@ -1319,9 +1321,32 @@ void dsp_svm_destroy(dsp_svm *s)
 
 }  // extern "C"
 
-// clip -> label in one kernel; in_kind 0 = float samples, 1 / 2 / 3 = int16 mono / stereo channel 0 / stereo average
+// Ragged batch -> spans in a ring slot (uploaded on `stream`).  offsets[n_clips + 1]: clip c is samples [offsets[c], offsets[c + 1]) per
+// channel of the buffer; every clip must hold at least one frame.  *t_max: frames of the longest clip.
+static int ragged_spans(dsp_mfcc_plan *p, const long *offsets, long n_clips, int max_frames, dsp::SpanRing::Slot **slot, int *t_max, void *stream)
+{
+    if (!offsets) return fail(DSP_EINVAL, "offsets is NULL");
+    DSP_HIP(p->spans.acquire((size_t)n_clips * sizeof(dsp::ClipSpan), slot));
+    dsp::ClipSpan *h = static_cast<dsp::ClipSpan *>((*slot)->h);
+    int tm = 0;
+    for (long c = 0; c < n_clips; ++c) {
+        const long n = offsets[c + 1] - offsets[c];
+        if (offsets[c] < 0 || n < 0 || n > INT32_MAX) return fail(DSP_EINVAL, "offsets must be non-negative and non-decreasing, clips shorter than 2^31 samples");
+        const int t = dsp_mfcc_frames_for(&p->cfg, (int)n, max_frames);
+        if (t == 0) return fail(DSP_EINVAL, "clip " + std::to_string(c) + " of the ragged batch is shorter than one frame");
+        h[c] = dsp::ClipSpan{offsets[c], (int)n, t};
+        tm = std::max(tm, t);
+    }
+    DSP_HIP(dsp::SpanRing::upload(*slot, (size_t)n_clips * sizeof(dsp::ClipSpan), (hipStream_t)stream));
+    *t_max = tm;
+    return DSP_OK;
+}
+
+// clip -> label in one kernel; in_kind 0 = float samples, 1 / 2 / 3 = int16 mono / stereo channel 0 / stereo average.
+// offsets != nullptr: a ragged batch (clips of different lengths back to back or anywhere in the buffer; samples_per_clip / clip_stride unused)
 static int scrubjay_fused(dsp_mfcc_plan *p, dsp_svm *s, const void *d_signal, int in_kind, long n_clips, int samples_per_clip,
-                          long clip_stride, int max_frames, int *d_labels, float *d_decision, float *d_prob1, float *d_feat, void *stream)
+                          long clip_stride, int max_frames, int *d_labels, float *d_decision, float *d_prob1, float *d_feat, void *stream,
+                          const long *offsets = nullptr)
 {
     if (!p || !s || n_clips < 0) return fail(DSP_EINVAL, "bad argument");
     if ((p->cfg.n_fft != 512 && p->cfg.n_fft != 2048) || (p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX && p->cfg.log_mode != DSP_LOG_LOG10_FLOOR) ||
@@ -1333,22 +1358,30 @@ static int scrubjay_fused(dsp_mfcc_plan *p, dsp_svm *s, const void *d_signal, in
         return fail(DSP_EINVAL, "int16 input of the fused clip -> label kernel: the reference framing (n_fft 512, frame 400, 40 mel filters, up to 20 coefficients) "
                                 "or the scrubjay_infer.c front end (dsp_mfcc_scrubjay_infer_config)");
     if (s->m.n_features != 2 * p->cfg.n_mfcc || s->m.n_features > 64) return fail(DSP_EINVAL, "SVM n_features must equal 2 * n_mfcc (<= 64)");
-    const int t = dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
+    const bool ragged = offsets != nullptr;
+    int t = ragged ? 1 : dsp_mfcc_frames_for(&p->cfg, samples_per_clip, max_frames);
     if (n_clips == 0) return 0;
     if (t == 0) return fail(DSP_EINVAL, "clips shorter than one frame have no features to pool");
     if (!d_signal || !d_labels) return fail(DSP_EINVAL, "NULL buffer");
-    if (n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
-    if ((reinterpret_cast<uintptr_t>(d_signal) & (in_kind == 1 ? 3 : 7)) || (n_clips > 1 && (clip_stride & 1)))
+    if (!ragged && n_clips > 1 && clip_stride < samples_per_clip) return fail(DSP_EINVAL, "clip_stride < samples_per_clip");
+    if ((reinterpret_cast<uintptr_t>(d_signal) & (in_kind == 1 ? 3 : 7)) || (!ragged && n_clips > 1 && (clip_stride & 1)))
         return fail(DSP_EINVAL, "input must be 8-byte aligned (4 for mono int16) with an even clip stride");
     if (s->device != p->device) return fail(DSP_EINVAL, "plan and SVM live on different devices");
     DSP_ON_DEVICE(p->device);
+    dsp::SpanRing::Slot *slot = nullptr;
+    if (ragged) {
+        const int rc = ragged_spans(p, offsets, n_clips, max_frames, &slot, &t, stream);
+        if (rc < 0) return rc;
+    }
     dsp::Mfcc512Args a{};
     a.in = d_signal;
     a.in_kind = in_kind;
     a.out = nullptr;
     a.tables = p->d_tables;
     a.n_frames = n_clips * (long)t;
-    a.clip_stride = clip_stride;
+    a.n_clips = n_clips;
+    a.spans = ragged ? static_cast<const dsp::ClipSpan *>(slot->d) : nullptr;
+    a.clip_stride = ragged ? 0 : clip_stride;
     a.frames_per_clip = t;
     a.hop = p->cfg.hop_length;
     a.frame_len = p->cfg.frame_length;
@@ -1360,21 +1393,24 @@ static int scrubjay_fused(dsp_mfcc_plan *p, dsp_svm *s, const void *d_signal, in
     a.log_mode = p->cfg.log_mode;
     a.spectrum = p->cfg.spectrum;
     a.stream_framing = p->cfg.framing == DSP_FRAMING_STREAM;
-    a.samples_per_clip = samples_per_clip;
+    a.samples_per_clip = ragged ? 0 : samples_per_clip;
     a.pool.svm = s->m;
     a.pool.labels = d_labels;
     a.pool.decision = d_decision;
     a.pool.prob1 = d_prob1;
     a.pool.feat = d_feat;
+    hipError_t e;
     if (p->cfg.n_fft == 2048) {      // scrubjay_infer.c's own framing (WIN_SIZE 2048, HOP_SIZE 1024): mfcc2048_kernel<POOL>
         const int per_cu2 = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks_2048_pool;
         const long blocks2 = std::max(1L, std::min((long)p->n_cu * per_cu2, (n_clips + 3) / 4));
-        DSP_HIP(dsp::launch_mfcc2048(a, p->d_tables2048, (int)blocks2, (hipStream_t)stream, true));
-        return t;
+        e = dsp::launch_mfcc2048(a, p->d_tables2048, (int)blocks2, (hipStream_t)stream, true);
+    } else {
+        const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks;
+        const long blocks = std::max(1L, std::min((long)p->n_cu * per_cu, (n_clips + 3) / 4));
+        e = dsp::launch_mfcc512_pool(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream);
     }
-    const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks;
-    long blocks = std::max(1L, std::min((long)p->n_cu * per_cu, (n_clips + 3) / 4));
-    DSP_HIP(dsp::launch_mfcc512_pool(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+    if (slot) dsp::SpanRing::mark(slot, (hipStream_t)stream);
+    DSP_HIP(e);
     return t;
 }
 
@@ -1397,15 +1433,35 @@ int dsp_scrubjay_fused_pcm16_device(dsp_mfcc_plan *p, dsp_svm *s, const int16_t 
     return scrubjay_fused(p, s, d_pcm, kind, n_clips, samples_per_clip, clip_stride, max_frames, d_labels, d_decision, d_prob1, d_feat, stream);
 }
 
+int dsp_scrubjay_fused_ragged_device(dsp_mfcc_plan *p, dsp_svm *s, const float *d_signal, long n_clips, const long *offsets, int max_frames,
+                                     int *d_labels, float *d_decision, float *d_prob1, float *d_feat, void *stream)
+{
+    if (!offsets) return fail(DSP_EINVAL, "offsets is NULL");
+    return scrubjay_fused(p, s, d_signal, 0, n_clips, 0, 0, max_frames, d_labels, d_decision, d_prob1, d_feat, stream, offsets);
+}
+
+int dsp_scrubjay_fused_ragged_pcm16_device(dsp_mfcc_plan *p, dsp_svm *s, const int16_t *d_pcm, long n_clips, const long *offsets, int channels,
+                                           int stereo_mode, int max_frames, int *d_labels, float *d_decision, float *d_prob1, float *d_feat,
+                                           void *stream)
+{
+    if (!offsets) return fail(DSP_EINVAL, "offsets is NULL");
+    if (channels != 1 && channels != 2) return fail(DSP_EINVAL, "channels must be 1 or 2");
+    if (channels == 2 && stereo_mode != DSP_STEREO_CHANNEL0 && stereo_mode != DSP_STEREO_AVERAGE) return fail(DSP_EINVAL, "bad stereo_mode");
+    const int kind = channels == 1 ? 1 : (stereo_mode == DSP_STEREO_CHANNEL0 ? 2 : 3);
+    return scrubjay_fused(p, s, d_pcm, kind, n_clips, 0, 0, max_frames, d_labels, d_decision, d_prob1, d_feat, stream, offsets);
+}
+
 }  // extern "C"
 
 int dsp::plan_device(const dsp_mfcc_plan *plan) { return plan ? plan->device : -1; }
 
 // capi_util.hpp: the fused form of dsp_classify_signal_batch_device (capi_consumers.cpp)
 int dsp::stop_fused_device(dsp_mfcc_plan *p, const dsp::StopModelDev &m, const void *d_signal, long n_clips, int samples_per_clip,
-                           long clip_stride, int t, float *d_prob, void *stream, int in_kind)
+                           long clip_stride, int t, float *d_prob, void *stream, int in_kind, const long *offsets)
 {
     (void)samples_per_clip;
+    const bool ragged = offsets != nullptr;
+    if (ragged) { t = 1; clip_stride = 0; }
     // the reference's shape on the default kernel: 512-point, per-frame log, 13 coefficients of 40 mel energies, complete frames
     if (p->cfg.n_fft != 512 || p->cfg.log_mode != DSP_LOG_PER_FRAME_MAX || p->cfg.prefilter != DSP_PREFILTER_NONE || p->kernel != DSP_KERNEL_WAVE ||
         p->host.dct_split != 4 || p->host.dct_len != 10 || m.n_coef != p->cfg.n_mfcc || m.units[0] > dsp::kStopFusedUnits || !m.fold_a || t <= 0 ||
@@ -1415,12 +1471,19 @@ int dsp::stop_fused_device(dsp_mfcc_plan *p, const dsp::StopModelDev &m, const v
     if (in_kind != 0 && (p->host.mel_gather != 3 || p->cfg.frame_length != 400)) return 0;
     if (m.max_frames <= 0) return fail(DSP_EINVAL, "stop model without frames");
     DSP_ON_DEVICE(p->device);
+    dsp::SpanRing::Slot *slot = nullptr;
+    if (ragged) {      // frames past the model's max_frames are dropped (stop_detector.c:26-30): a clip's walk ends there
+        const int rc = ragged_spans(p, offsets, n_clips, m.max_frames, &slot, &t, stream);
+        if (rc < 0) return rc;
+    }
     dsp::Mfcc512Args a{};
     a.in = d_signal;
     a.in_kind = in_kind;
     a.out = nullptr;
     a.tables = p->d_tables;
     a.n_frames = n_clips * (long)t;
+    a.n_clips = n_clips;
+    a.spans = ragged ? static_cast<const dsp::ClipSpan *>(slot->d) : nullptr;
     a.clip_stride = clip_stride;
     a.frames_per_clip = t;
     a.hop = p->cfg.hop_length;
@@ -1435,7 +1498,9 @@ int dsp::stop_fused_device(dsp_mfcc_plan *p, const dsp::StopModelDev &m, const v
     a.stop.prob = d_prob;
     const int per_cu = p->blocks_per_cu > 0 ? p->blocks_per_cu : p->resident_blocks;
     const long blocks = std::max(1L, std::min((long)p->n_cu * per_cu, (n_clips + 3) / 4));
-    DSP_HIP(dsp::launch_mfcc512_stop(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream));
+    const hipError_t e = dsp::launch_mfcc512_stop(a, p->host.dct_split, p->host.dct_len, p->host.mel_gather, (int)blocks, (hipStream_t)stream);
+    if (slot) dsp::SpanRing::mark(slot, (hipStream_t)stream);
+    DSP_HIP(e);
     return 1;
 }
 

@@ -201,6 +201,38 @@ int dsp_classify_signal_batch_pcm16_device(dsp_mfcc_plan *plan, dsp_stop_model *
     return classify_signal_batch(plan, m, d_pcm, kind, channels, stereo_mode, n_clips, samples_per_clip, clip_stride, d_prob, stream);
 }
 
+// Ragged batches (main_test.c:254-331 loops over files of different lengths): one launch of the fused kernel, every clip with the
+// frames its own length gives (capped at the model's max_frames).  The fused kernel only: plans outside its shape are refused.
+static int classify_signal_batch_ragged(dsp_mfcc_plan *plan, dsp_stop_model *m, const void *d_signal, int in_kind, long n_clips, const long *offsets,
+                                        float *d_prob, void *stream)
+{
+    if (!plan || !m || n_clips < 0 || !offsets || (n_clips > 0 && (!d_signal || !d_prob))) return capi_fail(DSP_EINVAL, "bad argument");
+    dsp_mfcc_config cfg;
+    dsp_mfcc_plan_config(plan, &cfg);
+    if (cfg.n_mfcc != m->m.n_coef) return capi_fail(DSP_EINVAL, "plan n_mfcc differs from the model's n_coef");
+    if (dsp::plan_device(plan) != m->device) return capi_fail(DSP_EINVAL, "plan and stop model live on different devices");
+    if (n_clips == 0) return DSP_OK;
+    const int fused = dsp::stop_fused_device(plan, m->m, d_signal, n_clips, 0, 0, 1, d_prob, stream, in_kind, offsets);
+    if (fused == 0) return capi_fail(DSP_EINVAL, "ragged batches run on the fused clip -> probability kernel: the reference's MFCC shape (dsp_mfcc_default_config), "
+                                                 "a model with at most 4 first-layer units, an 8-byte aligned buffer (4 for mono int16)");
+    return fused < 0 ? fused : DSP_OK;
+}
+
+int dsp_classify_signal_batch_ragged_device(dsp_mfcc_plan *plan, dsp_stop_model *m, const float *d_signal, long n_clips, const long *offsets,
+                                            float *d_prob, void *stream)
+{
+    return classify_signal_batch_ragged(plan, m, d_signal, 0, n_clips, offsets, d_prob, stream);
+}
+
+int dsp_classify_signal_batch_ragged_pcm16_device(dsp_mfcc_plan *plan, dsp_stop_model *m, const int16_t *d_pcm, long n_clips, const long *offsets,
+                                                  int channels, int stereo_mode, float *d_prob, void *stream)
+{
+    if (channels != 1 && channels != 2) return capi_fail(DSP_EINVAL, "channels must be 1 or 2");
+    if (channels == 2 && stereo_mode != DSP_STEREO_CHANNEL0 && stereo_mode != DSP_STEREO_AVERAGE) return capi_fail(DSP_EINVAL, "bad stereo_mode");
+    const int kind = channels == 1 ? 1 : (stereo_mode == DSP_STEREO_CHANNEL0 ? 2 : 3);
+    return classify_signal_batch_ragged(plan, m, d_pcm, kind, n_clips, offsets, d_prob, stream);
+}
+
 float dsp_classify_signal(dsp_stop_model *m, const float *signal, int num_samples)
 {
     if (!m || !signal || num_samples < 0) { capi_fail(DSP_EINVAL, "bad argument"); return 0.0f; }

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <mutex>
 #include <string>
 
 #include "../../include/dsp_amd.h"
@@ -16,8 +17,60 @@ struct StopModelDev;
 // path), < 0 on error.  t = frames per clip (already capped at the model's max_frames).
 // in_kind: 0 float samples, 1 / 2 / 3 int16 mono / stereo channel 0 / stereo average
 int stop_fused_device(dsp_mfcc_plan *plan, const StopModelDev &m, const void *d_signal, long n_clips, int samples_per_clip,
-                      long clip_stride, int t, float *d_prob, void *stream, int in_kind = 0);
+                      long clip_stride, int t, float *d_prob, void *stream, int in_kind = 0, const long *offsets = nullptr);
+// offsets != nullptr: a ragged batch (clip c = samples [offsets[c], offsets[c + 1]) per channel; samples_per_clip, clip_stride and t unused)
 int plan_device(const dsp_mfcc_plan *plan);          // the GPU a plan lives on
+}
+
+// Ragged batches: the clips' spans (mfcc_kernels.hpp ClipSpan: start, samples, frames -- 16 bytes per clip) travel to the GPU through a
+// small ring of pinned host / device buffer pairs, so that a call neither waits for the stream it enqueues on nor shares a buffer with
+// the call before it (which may still be running, on this stream or another).  A slot is reused only after the event recorded behind
+// the kernels that read it.
+namespace dsp {
+struct ClipSpan;
+struct SpanRing {
+    static constexpr int kSlots = 4;
+    struct Slot { void *h = nullptr, *d = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool used = false; };
+    Slot slot[kSlots];
+    int next = 0;
+    std::mutex mu;
+    // a slot with room for `bytes`, its previous user finished; fill slot->h, then upload(), launch, then mark()
+    hipError_t acquire(size_t bytes, Slot **out)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        Slot &s = slot[next];
+        next = (next + 1) % kSlots;
+        hipError_t e;
+        if (!s.done && (e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) return e;
+        if (s.used && (e = hipEventSynchronize(s.done)) != hipSuccess) return e;
+        s.used = false;
+        if (s.cap < bytes) {
+            if (s.h) (void)hipHostFree(s.h);
+            if (s.d) (void)hipFree(s.d);
+            s.h = s.d = nullptr; s.cap = 0;
+            const size_t cap = bytes + bytes / 2 + 4096;
+            if ((e = hipHostMalloc(&s.h, cap, hipHostMallocDefault)) != hipSuccess) return e;
+            if ((e = hipMalloc(&s.d, cap)) != hipSuccess) return e;
+            s.cap = cap;
+        }
+        *out = &s;
+        return hipSuccess;
+    }
+    static hipError_t upload(Slot *s, size_t bytes, hipStream_t st) { return hipMemcpyAsync(s->d, s->h, bytes, hipMemcpyHostToDevice, st); }
+    // after the last kernel that reads the slot has been enqueued (also on error exits once upload() ran)
+    static void mark(Slot *s, hipStream_t st) { s->used = hipEventRecord(s->done, st) == hipSuccess; if (!s->used) (void)hipStreamSynchronize(st); }
+    void release()      // on the owner's device
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (Slot &s : slot) {
+            if (s.used) (void)hipEventSynchronize(s.done);
+            if (s.h) (void)hipHostFree(s.h);
+            if (s.d) (void)hipFree(s.d);
+            if (s.done) (void)hipEventDestroy(s.done);
+            s = Slot{};
+        }
+    }
+};
 }
 
 #define DSP_CAPI_HIP(call)                                                                              \

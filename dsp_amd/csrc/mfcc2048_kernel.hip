@@ -166,8 +166,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     const int frame_len = args.frame_len;
     (void)feat;
 
-    WaveCursor<CLIPS> cur;
-    cur.init(wave, n_waves, args.chunk, args.n_frames, args.frames_per_clip, CLIPS ? args.hop : frame_len, args.clip_stride);
+    // (the fused clip kernel walks whole clips, uniform or ragged: ClipCursor)
+    std::conditional_t<POOL, ClipCursor, WaveCursor<CLIPS>> cur;
+    if constexpr (POOL) cur.init(wave, n_waves, args.n_clips, args.frames_per_clip, args.hop, args.clip_stride, args.spans, args.samples_per_clip);
+    else cur.init(wave, n_waves, args.chunk, args.n_frames, args.frames_per_clip, CLIPS ? args.hop : frame_len, args.clip_stride);
     if (!cur.valid()) return;
 
     // POOL: lane 2 c keeps the running sums of coefficient c for the clip this wave is walking
@@ -186,7 +188,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             const int start = (cur.t + 1) * args.hop - frame_len;        // first sample of the frame inside its clip (even; < 0: history)
             src += args.hop - frame_len;                                 // cur.off = clip_off + t * hop
             lo_i = start < 0 ? -start : 0;
-            hi_i = min(frame_len, args.samples_per_clip - start);
+            int n_clip = args.samples_per_clip;                          // ragged batches: the clip's own length
+            if constexpr (POOL) n_clip = cur.n_samples;
+            hi_i = min(frame_len, n_clip - start);
         }
         cur.next();
 

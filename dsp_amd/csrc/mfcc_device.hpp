@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "mfcc_kernels.hpp"
 
 namespace dsp {
@@ -247,6 +249,42 @@ struct WaveCursor {
             chunk_off += in_chunk ? 0 : stride_off;
             off = in_chunk ? off + hop : chunk_off;
         }
+    }
+};
+
+// Cursor of the fused clip kernels (one wavefront walks one clip from its first frame to its last; clips dealt round-robin to the
+// waves).  Uniform batches: clip c starts at c * clip_stride and has fpc frames; ragged batches (spans != nullptr): start, samples and
+// frame count come from the clip's ClipSpan, one 16-byte scalar load per clip.  Same members as WaveCursor where the kernels read them.
+struct ClipCursor {
+    long f, off, clip;
+    long n_clips, n_waves, clip_stride;
+    const ClipSpan *spans;
+    int left, remaining, t, hop, fpc, n_samples;
+    __device__ __forceinline__ void enter()
+    {
+        t = 0;
+        if (clip >= n_clips) { remaining = 0; return; }
+        remaining = 2;                              // "not the wave's last frame": a clip's end is left == 0
+        if (spans) {
+            const ClipSpan s = spans[clip];
+            off = s.off; n_samples = s.n; left = s.frames - 1;
+        } else {
+            off = clip * clip_stride; left = fpc - 1;
+        }
+    }
+    __device__ __forceinline__ void init(long wave, long n_waves_, long n_clips_, int fpc_, int hop_, long clip_stride_, const ClipSpan *spans_,
+                                         int samples_per_clip)
+    {
+        n_clips = n_clips_; n_waves = n_waves_; clip_stride = clip_stride_; spans = spans_; hop = hop_; fpc = fpc_; n_samples = samples_per_clip;
+        f = 0; off = 0; left = 0; clip = wave;
+        enter();
+    }
+    __device__ __forceinline__ bool valid() const { return remaining > 0; }
+    __device__ __forceinline__ void next()
+    {
+        ++f;
+        if (left > 0) { --left; ++t; off += hop; }
+        else { clip += n_waves; enter(); }
     }
 };
 

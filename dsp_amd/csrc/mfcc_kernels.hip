@@ -280,8 +280,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
     // Software prefetch, PF frames deep.  ONE cursor (`pre`) walks this wave's frames
     // and issues their loads; the frame index (and clip) of each ring buffer waits in `fq`
     // until the frame is consumed, so the consumer side needs no cursor of its own.
-    WaveCursor<CLIPS> pre;
-    pre.init(wave, n_waves, args.chunk, n_frames, args.frames_per_clip, CLIPS ? args.hop : frame_len, args.clip_stride);
+    // (the fused clip kernels walk whole clips, uniform or ragged: ClipCursor)
+    std::conditional_t<POOL != 0, ClipCursor, WaveCursor<CLIPS>> pre;
+    if constexpr (POOL != 0) pre.init(wave, n_waves, args.n_clips, args.frames_per_clip, args.hop, args.clip_stride, args.spans, args.samples_per_clip);
+    else pre.init(wave, n_waves, args.chunk, n_frames, args.frames_per_clip, CLIPS ? args.hop : frame_len, args.clip_stride);
     c32 ring[PF][4] = {};
     long fq[PF], cq[PF];
     bool lastq[PF];           // POOL: the frame closes its chunk (= its clip)

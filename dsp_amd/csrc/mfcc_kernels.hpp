@@ -28,6 +28,15 @@ struct StopNetArgs {
     float *prob;           // [n_clips]
 };
 
+// One clip of a ragged batch (the reference's callers loop over files of different lengths -- cepstrum/scrubjay_infer.c:158-176,
+// 2fa/audio/word/c/main_test.c:254-331): where it starts in the input buffer, its samples, and the frames the host counted for it
+// (dsp_mfcc_frames_for: the kernels divide nothing).  16 bytes: one scalar load per clip.
+struct ClipSpan {
+    long off;      // first sample (per channel) from Mfcc512Args::in
+    int n;         // samples per channel
+    int frames;    // >= 1
+};
+
 struct Mfcc512Args {
     const void *in;                // HBM: frames or clips; float32, or int16 PCM (in_kind)
     int in_kind;                   // 0 float32 | 1 int16 mono | 2 int16 stereo ch 0 | 3 int16 stereo average
@@ -54,6 +63,10 @@ struct Mfcc512Args {
     int samples_per_clip = 0;
     float *frame_max;
     const float *clip_floor;
+    // the fused clip kernels (POOL; one wavefront walks one clip): the clip count, and for a ragged batch the clips' spans
+    // (spans == nullptr: clip c starts at c * clip_stride and has frames_per_clip frames of samples_per_clip samples)
+    long n_clips = 0;
+    const ClipSpan *spans = nullptr;
     PoolSvmArgs pool;              // only read by the POOL instantiations (launch_mfcc512_pool)
     StopNetArgs stop{};            // only read by the stop-net instantiations (launch_mfcc512_stop)
 };

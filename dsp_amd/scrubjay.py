@@ -129,3 +129,27 @@ class ScrubJay:
                                                                channels, int(stereo_mode), int(min(max_frames, 1 << 30)), labels.data_ptr(), dec.data_ptr(),
                                                                p1.data_ptr(), feat.data_ptr(), st), "dsp_scrubjay_fused_pcm16_device")
         return labels, dec, p1, feat
+
+    def ragged(self, signal, offsets, max_frames: int = 1 << 20, stereo_mode: int = 0):
+        """Clips of different lengths in ONE launch (the files scrubjay_infer.c:158-176 loops over): `signal` is a flat cuda buffer --
+        float32 [total], int16 [total] or interleaved stereo int16 [total][2] -- and clip c is samples [offsets[c], offsets[c + 1]).
+        Results as a one-clip call per clip gives them (dsp_scrubjay_fused_ragged_device / _pcm16_device)."""
+        import torch
+        off, n = _lib.c_offsets(offsets)
+        assert signal.is_cuda and signal.stride(-1) == 1 and int(offsets[-1]) <= signal.shape[0]
+        labels = torch.empty(n, dtype=torch.int32, device=signal.device)
+        dec = torch.empty(n, dtype=torch.float32, device=signal.device)
+        p1 = torch.empty(n, dtype=torch.float32, device=signal.device)
+        feat = torch.empty((n, self.svm.n_features), dtype=torch.float32, device=signal.device)
+        st = C.c_void_p(torch.cuda.current_stream(signal.device).cuda_stream)
+        mf = int(min(max_frames, 1 << 30))
+        if signal.dtype == torch.float32:
+            assert signal.dim() == 1
+            _lib.check(_lib.load().dsp_scrubjay_fused_ragged_device(self.plan._h, self.svm._h, signal.data_ptr(), n, off, mf, labels.data_ptr(), dec.data_ptr(),
+                                                                    p1.data_ptr(), feat.data_ptr(), st), "dsp_scrubjay_fused_ragged_device")
+        else:
+            assert signal.dtype == torch.int16 and signal.dim() in (1, 2)
+            _lib.check(_lib.load().dsp_scrubjay_fused_ragged_pcm16_device(self.plan._h, self.svm._h, signal.data_ptr(), n, off, signal.dim(), int(stereo_mode), mf,
+                                                                          labels.data_ptr(), dec.data_ptr(), p1.data_ptr(), feat.data_ptr(), st),
+                       "dsp_scrubjay_fused_ragged_pcm16_device")
+        return labels, dec, p1, feat

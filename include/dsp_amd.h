@@ -362,6 +362,17 @@ int dsp_scrubjay_fused_device(dsp_mfcc_plan *plan, dsp_svm *svm, const float *d_
 int dsp_scrubjay_fused_pcm16_device(dsp_mfcc_plan *plan, dsp_svm *svm, const int16_t *d_pcm, long n_clips, int samples_per_clip,
                                     long clip_stride, int channels, int stereo_mode, int max_frames, int *d_labels,
                                     float *d_decision, float *d_prob1, float *d_feat, void *stream);
+/* RAGGED batches -- clips of different lengths in ONE launch (the reference's callers loop over files: cepstrum/scrubjay_infer.c:158-176,
+ * 2fa/audio/word/c/main_test.c:254-331).  offsets is a HOST array of n_clips + 1 sample positions (per channel) into the device buffer:
+ * clip c is [offsets[c], offsets[c + 1]), non-decreasing, any parity (the buffer itself 8-byte aligned, 4 for mono int16); every clip
+ * must hold at least one frame (DSP_EINVAL names the first that does not).  Clip c gets the frames ITS length gives
+ * (dsp_mfcc_frames_for(cfg, offsets[c + 1] - offsets[c], max_frames)) and the results of a one-clip call on it, bit for bit.  The array
+ * is read before the call returns.  Returns the frame count of the longest clip.                                                        */
+int dsp_scrubjay_fused_ragged_device(dsp_mfcc_plan *plan, dsp_svm *svm, const float *d_signal, long n_clips, const long *offsets,
+                                     int max_frames, int *d_labels, float *d_decision, float *d_prob1, float *d_feat, void *stream);
+int dsp_scrubjay_fused_ragged_pcm16_device(dsp_mfcc_plan *plan, dsp_svm *svm, const int16_t *d_pcm, long n_clips, const long *offsets,
+                                           int channels, int stereo_mode, int max_frames, int *d_labels, float *d_decision,
+                                           float *d_prob1, float *d_feat, void *stream);
 
 /* --- consumers of the MFCC matrix and the resampler (8f-4) ------- */
 
@@ -393,6 +404,12 @@ int dsp_classify_signal_batch_device(dsp_mfcc_plan *plan, dsp_stop_model *model,
 int dsp_classify_signal_batch_pcm16_device(dsp_mfcc_plan *plan, dsp_stop_model *model, const int16_t *d_pcm, long n_clips,
                                            int samples_per_clip, long clip_stride, int channels, int stereo_mode, float *d_prob,
                                            void *stream);
+/* Ragged batches (offsets as dsp_scrubjay_fused_ragged_device): one launch of the fused clip -> probability kernel, every clip with its
+ * own frame count (capped at the model's max_frames, stop_detector.c:26-30).  Plans of the reference's shape only (the fused kernel's).   */
+int dsp_classify_signal_batch_ragged_device(dsp_mfcc_plan *plan, dsp_stop_model *model, const float *d_signal, long n_clips,
+                                            const long *offsets, float *d_prob, void *stream);
+int dsp_classify_signal_batch_ragged_pcm16_device(dsp_mfcc_plan *plan, dsp_stop_model *model, const int16_t *d_pcm, long n_clips,
+                                                  const long *offsets, int channels, int stereo_mode, float *d_prob, void *stream);
 /* classify_signal's own contract (stop_detector.h:10) with host buffers: probability in [0, 1];
  * a failure returns 0 with the reason in dsp_last_error().                                       */
 float dsp_classify_signal(dsp_stop_model *model, const float *signal, int num_samples);

@@ -7,6 +7,7 @@ import dsp_amd
 from tests import signals as S
 n = 49152
 launches = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+torch.manual_seed(0)
 clips = (torch.rand((n, 16000), device="cuda", dtype=torch.float64) * 2 - 1) * 0.005
 call = torch.from_numpy(S.classify_cases()["scrub_a"]).cuda().double()
 clips[::4] = call + clips[::4] * 0.1
