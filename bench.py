@@ -78,7 +78,8 @@ def pmc_traffic(workload: str, units_per_launch: int):
 
 def sq_fractions(workload: str):
     """VALU / LDS busy fractions of the workload's dominant kernel from the committed SQ-counter pass (profiles/*_sq_counters*.json,
-    written by tools/sq_fractions.py on the GPU box: SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CU_CYCLES and SQ_LDS_IDX_ACTIVE / the same).
+    written by tools/sq_fractions.py on the GPU box: vector instructions x 4 issue cycles, and LDS-array cycles, over the dispatch's own
+    cycles x 256 CUs (x 4 SIMDs); the clock the kernel ran at comes with them).
     Replayed, like the traffic figure: the line says so."""
     import glob
     import re
@@ -101,7 +102,7 @@ def roofline_extras(workload: str, units: int):
            "traffic_replayed": bool(tr),
            "traffic_source": ("NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same command, profiles/" + tr["file"]) if tr else None}
     if sq:
-        out.update({"valu_frac": sq.get("valu_frac"), "lds_frac": sq.get("lds_frac"), "sq_source": "replayed: profiles/" + sq["file"]})
+        out.update({"valu_frac": sq.get("valu_frac"), "lds_frac": sq.get("lds_frac"), "clock_ghz": sq.get("clock_ghz"), "sq_source": "replayed: profiles/" + sq["file"]})
     return out
 
 

@@ -470,7 +470,7 @@ hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables,
     const dim3 g(blocks), b(256);
     const size_t Q_BLOCK_BYTES = lds_bytes_2048(args.n_mels, pool);
     const bool aub = args.spectrum != 0 || args.log_mode == 2 || args.stream_framing != 0;
-    if (args.stream_framing && (!clips || args.samples_per_clip <= 0 || args.hop > args.frame_len)) return hipErrorInvalidConfiguration;
+    if (args.stream_framing && (!clips || (args.samples_per_clip <= 0 && !(pool && args.spans)) || args.hop > args.frame_len)) return hipErrorInvalidConfiguration;      // (ragged: lengths in the spans)
     if (args.in_kind != 0 && (!aub || !clips || args.in_kind < 0 || args.in_kind > 3)) return hipErrorInvalidConfiguration;      // int16: the scrubjay_infer.c front end, clips
     if (pool) {
         if (!clips || args.chunk != args.frames_per_clip || !args.pool.labels || args.pool.svm.n_features != 2 * args.n_mfcc ||

@@ -44,9 +44,12 @@ def summarize(d, workload, extra, tag):
                 kernels[k]["valu_frac_of_wall"] = c["SQ_INSTS_VALU"] / (cyc * 256.0)      # 256 CUs x 4 SIMDs x (cycles / 4) issue slots
                 kernels[k]["lds_frac_of_wall"] = c["SQ_LDS_IDX_ACTIVE"] / (cyc * 256.0)
     top = max(kernels, key=lambda k: kernels[k]["busy_cu_cycles"]) if kernels else None
-    doc = {"workload": workload, "dominant_kernel": top, "valu_frac": kernels[top]["valu_frac"] if top else None,
-           "lds_frac": kernels[top]["lds_frac"] if top else None, "per_kernel": kernels,
-           "definition": "valu_frac = SQ_INSTS_VALU / SQ_BUSY_CU_CYCLES: a wave64 vector instruction holds its SIMD's issue for 4 cycles and a CU has 4 SIMDs, "
+    # the quoted fractions: against the dispatch's own cycles (GRBM_GUI_ACTIVE) when that counter was collected -- SQ_BUSY_CU_CYCLES runs
+    # ~7 % short on a kernel that fills every CU for its whole duration (the 512-point frame kernel reads 1.07 against it, 1.00 against the wall)
+    pick = lambda k, a: kernels[k].get(a + "_of_wall", kernels[k][a])
+    doc = {"workload": workload, "dominant_kernel": top, "valu_frac": pick(top, "valu_frac") if top else None,
+           "lds_frac": pick(top, "lds_frac") if top else None, "clock_ghz": kernels[top].get("clock_ghz") if top else None, "per_kernel": kernels,
+           "definition": "valu_frac (top level, *_of_wall) = SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 x 256 CUs), lds_frac likewise; per kernel also against SQ_BUSY_CU_CYCLES: a wave64 vector instruction holds its SIMD's issue for 4 cycles and a CU has 4 SIMDs, "
                          "so instructions x 4 / (busy CU cycles x 4) is the share of vector issue slots used (float64 and float32 alike; transcendentals "
                          "hold the pipe longer and make this a lower bound).  SQ_ACTIVE_INST_VALU (quad-cycles a wave is in a vector instruction, "
                          "issue to completion) runs 3 - 12 % above SQ_INSTS_VALU and is not an occupancy of the pipe.  lds_frac = SQ_LDS_IDX_ACTIVE / "
