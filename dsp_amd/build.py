@@ -15,7 +15,7 @@ SOURCES = ["capi.cpp", "capi_consumers.cpp", "capi_classifier_cxx.cpp", "capi_cl
 # DSP_AMD_EXPERIMENTS=1 python -m dsp_amd.build adds them (dsp_version() then carries "+experiments", DSP_KERNEL_ROW / _PAIR work).
 EXPERIMENT_SOURCES = ["mfcc_row_kernel.hip", "mfcc512_pair_kernel.hip"]
 EXPERIMENTS = os.environ.get("DSP_AMD_EXPERIMENTS", "") not in ("", "0")
-HEADERS = ["exports.map", "tables.hpp", "mfcc_kernels.hpp", "mfcc_device.hpp", "classify_kernels.hpp", "svm_kernels.hpp", "classify_f64_device.hpp", "diag_guard.hpp", "consumer_kernels.hpp", "capi_util.hpp",
+HEADERS = ["exports.map", "tables.hpp", "clip_span.hpp", "mfcc_kernels.hpp", "mfcc_device.hpp", "classify_kernels.hpp", "svm_kernels.hpp", "classify_f64_device.hpp", "diag_guard.hpp", "consumer_kernels.hpp", "capi_util.hpp",
            os.path.join("..", "..", "include", "dsp_amd.h"), os.path.join("..", "..", "include", "dsp_amd_classifier.h")]
 
 

@@ -140,6 +140,58 @@ def classify_device_pcm16(pcm, labels=None, stereo_mode: int = 0, config=None):
     return labels
 
 
+def _traces(tr):
+    out = []
+    for t in tr:
+        k = t.n_midpoints
+        out.append((np.array(t.midpoints[:k], np.float32),
+                    np.array([[t.sums[i][j] for j in range(3)] for i in range(k)], np.float32).reshape(-1, 3)))
+    return out
+
+
+def classify_ragged(signal: np.ndarray, offsets, stereo_mode: int = 0, with_trace: bool = False, config=None):
+    """Clips of different lengths in ONE call (dsp_classify_batch_ragged_host / _pcm16_host): `signal` is a flat host buffer -- float32
+    [total], int16 [total] or interleaved stereo int16 [total][2] -- and clip c is samples [offsets[c], offsets[c + 1]).  Labels (and
+    traces) as one classify() per clip gives them."""
+    signal = np.ascontiguousarray(signal)
+    off, n_clips = _lib.c_offsets(offsets)
+    assert int(offsets[-1]) <= signal.shape[0]
+    labels = np.zeros(n_clips, np.int32)
+    tr = (_lib.ClassifyTrace * max(n_clips, 1))() if with_trace else None
+    cfg = None if config is None else (config if isinstance(config, _lib.ClassifyConfig) else classify_config(config))
+    cp = C.byref(cfg) if cfg is not None else None
+    if signal.dtype == np.int16:
+        assert signal.ndim in (1, 2)
+        _lib.check(_lib.load().dsp_classify_batch_ragged_pcm16_host(cp, signal.ctypes.data, n_clips, off, signal.ndim, int(stereo_mode), labels.ctypes.data,
+                                                                     C.byref(tr) if with_trace else None), "dsp_classify_batch_ragged_pcm16_host")
+    else:
+        signal = np.ascontiguousarray(signal, np.float32)
+        assert signal.ndim == 1
+        _lib.check(_lib.load().dsp_classify_batch_ragged_host(cp, signal.ctypes.data, n_clips, off, labels.ctypes.data, C.byref(tr) if with_trace else None),
+                   "dsp_classify_batch_ragged_host")
+    return (labels, _traces(tr)[:n_clips]) if with_trace else labels
+
+
+def classify_device_ragged(signal, offsets, labels=None, stereo_mode: int = 0, config=None):
+    """The same on a flat cuda buffer (float32 [total], int16 [total] or [total][2]) -> cuda int32 labels, stream-ordered."""
+    import torch
+    off, n_clips = _lib.c_offsets(offsets)
+    assert signal.is_cuda and signal.stride(-1) == 1 and int(offsets[-1]) <= signal.shape[0]
+    if labels is None:
+        labels = torch.empty(n_clips, dtype=torch.int32, device=signal.device)
+    st = C.c_void_p(torch.cuda.current_stream(signal.device).cuda_stream)
+    cfg = None if config is None else (config if isinstance(config, _lib.ClassifyConfig) else classify_config(config))
+    cp = C.byref(cfg) if cfg is not None else None
+    if signal.dtype == torch.int16:
+        assert signal.dim() in (1, 2)
+        _lib.check(_lib.load().dsp_classify_batch_ragged_pcm16_device(cp, signal.data_ptr(), n_clips, off, signal.dim(), int(stereo_mode), labels.data_ptr(), st),
+                   "dsp_classify_batch_ragged_pcm16_device")
+    else:
+        assert signal.dtype == torch.float32 and signal.dim() == 1
+        _lib.check(_lib.load().dsp_classify_batch_ragged_device(cp, signal.data_ptr(), n_clips, off, labels.data_ptr(), st), "dsp_classify_batch_ragged_device")
+    return labels
+
+
 def classify_release(device: int = -1) -> None:
     _lib.check(_lib.load().dsp_classify_release(int(device)), "dsp_classify_release")
 

@@ -676,6 +676,7 @@ struct ClassifyCtx {
     std::mutex mu;
     hipEvent_t done = nullptr;                             // recorded behind the last call's work: the workspace is free once it has fired
     bool pending = false;
+    dsp::SpanRing spans;                                   // ragged batches: the clips' spans on their way to the GPU (capi_util.hpp)
     void wait_idle()
     {
         if (pending && done) (void)hipEventSynchronize(done);
@@ -779,6 +780,7 @@ void cls_release(ClassifyCtx &g_cls)      // (on g_cls.device, made current by t
     g_cls.d_tab = nullptr;
     if (g_cls.done) (void)hipEventDestroy(g_cls.done);
     g_cls.done = nullptr;
+    g_cls.spans.release();
     g_cls.device = -1;
 }
 
@@ -819,7 +821,10 @@ dsp::IirCoef coef_f32(double lo, double hi)
 
 // one sub-batch already resident at d_x (input kind `in`: 0 float, 1 / 2 / 3 int16 mono / stereo channel 0 / stereo average; row
 // stride in samples per channel): labels (+ trace) into the workspace
-int cls_run(ClassifyCtx &g_cls, const dsp_classify_config &cfg, const void *d_x, int in, long clips, int n, long stride, hipStream_t st, bool want_trace)
+// spans != nullptr: a ragged sub-batch (clip c at spans[c].off samples from d_x with spans[c].frames whole segments; n = the longest
+// clip of the BATCH, total = samples in the buffer)
+int cls_run(ClassifyCtx &g_cls, const dsp_classify_config &cfg, const void *d_x, int in, long clips, int n, long stride, hipStream_t st, bool want_trace,
+            const dsp::ClipSpan *spans = nullptr, long total = 0)
 {
     const dsp::IirCoef bp = coef_f32(3000, 7500), mp = coef_f32(1000, 3000);   // classifier.cpp:14-19, 438-442
     if (cfg.midpoint_db != g_cls.keep_min_db) {      // the table's threshold PSD value follows the configured dB threshold
@@ -830,18 +835,18 @@ int cls_run(ClassifyCtx &g_cls, const dsp_classify_config &cfg, const void *d_x,
     const dsp::ClassifyRule rule{cfg.keep_lo, cfg.keep_hi, cfg.middle_max, cfg.above_min, cfg.below_min};
     // ONE pass over the clips: both recurrences, the delay lines at every segment start, the 1000-3000 Hz segment means and
     // the energy gate.  No filtered signal is written; the spectrogram kernels recompute the segments they transform.
-    DSP_HIP(dsp::launch_iir2_ckpt(d_x, clips, n, stride, bp, mp, g_cls.d_ck_bp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, g_cls.d_tab, st, g_cls.d_simd, in));
+    DSP_HIP(dsp::launch_iir2_ckpt(d_x, clips, n, stride, bp, mp, g_cls.d_ck_bp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, g_cls.d_tab, st, g_cls.d_simd, in, spans, total));
     // midpoints first (1000-3000 Hz map, as flags, gated frames only); the 3000-7500 Hz spectrogram and its band sums only for
     // clips that have midpoints
     DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, mp, g_cls.d_ck_mp, g_cls.d_mean_mp, g_cls.d_gate, nullptr, g_cls.d_tab,
-                                       reinterpret_cast<float *>(g_cls.d_loud), true, st, nullptr, nullptr, in));
+                                       reinterpret_cast<float *>(g_cls.d_loud), true, st, nullptr, nullptr, in, spans));
     // DSP_AMD_CLASSIFY_FULL_MAPS=1: every row of the listed clips' maps is stored and read (the form before the need / minmax hand-over)
     static const bool full_maps = [] { const char *e = std::getenv("DSP_AMD_CLASSIFY_FULL_MAPS"); return e && std::atoi(e) != 0; }();
     unsigned *mm = full_maps ? nullptr : g_cls.d_minmax;
     const int *need = full_maps ? nullptr : g_cls.d_loud;
-    DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_loud, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, want_trace, mm));
-    DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, bp, g_cls.d_ck_bp, nullptr, nullptr, g_cls.d_hits, g_cls.d_tab, g_cls.d_sbp, false, st, need, mm, in));
-    DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, rule, need, mm));
+    DSP_HIP(dsp::launch_classify_midpoints(g_cls.d_loud, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, want_trace, mm, spans));
+    DSP_HIP(dsp::launch_spec_from_ckpt(d_x, clips, n, stride, bp, g_cls.d_ck_bp, nullptr, nullptr, g_cls.d_hits, g_cls.d_tab, g_cls.d_sbp, false, st, need, mm, in, spans));
+    DSP_HIP(dsp::launch_classify_bands(g_cls.d_sbp, clips, n, 16000, g_cls.d_labels, g_cls.d_trace, g_cls.d_hits, st, rule, need, mm, spans));
     return DSP_OK;
 }
 
@@ -1124,6 +1129,93 @@ int cls_device_entry(const dsp_classify_config *cfgp, const void *d_signal, int 
     return DSP_OK;
 }
 
+// Ragged batches (donut-classifier/classifier.c:286-297 reads one file of any length per run; its callers loop over files): the clips'
+// spans from the host's offsets[n_clips + 1] (samples per channel from the buffer's start), every clip with the segments ITS length
+// holds.  d_signal: the whole buffer on the GPU.  labels / trace (host, optional) are copied back when given, d_labels (device) otherwise.
+int cls_ragged(const dsp_classify_config *cfgp, const void *d_signal, int device, int in, long n_clips, const long *offsets, int *d_labels, int *labels,
+               dsp_classify_trace *trace, void *stream)
+{
+    const dsp_classify_config cfg = cfgp ? *cfgp : default_classify_cfg();
+    if (!valid_classify_cfg(cfg)) return fail(DSP_EINVAL, "classify config: thresholds must be finite with keep_lo < keep_hi");
+    int n_max = 0;
+    for (long c = 0; c < n_clips; ++c) {
+        const long n = offsets[c + 1] - offsets[c];
+        if (offsets[c] < 0 || n < 0 || n > INT32_MAX) return fail(DSP_EINVAL, "offsets must be non-negative and non-decreasing, clips shorter than 2^31 samples");
+        if (spec_bins((int)n) > kMaxSpecColumns) return fail(DSP_EINVAL, "clip " + std::to_string(c) + " too long (more than 957 spectrogram columns = 13.4 s at 16 kHz)");
+        n_max = std::max(n_max, (int)n);
+    }
+    ClassifyCtx &g_cls = g_cls_ctx[device];
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    DSP_ON_DEVICE(device);
+    int rc = cls_init(g_cls, device);
+    if (rc < 0) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (spec_bins(n_max) == 0) {                        // no clip holds a segment: no midpoints, label 0 (classifier.cpp:93-114)
+        if (d_labels) DSP_HIP(hipMemsetAsync(d_labels, 0, (size_t)n_clips * sizeof(int), st));
+        if (labels) std::memset(labels, 0, (size_t)n_clips * sizeof(int));
+        if (trace) std::memset(trace, 0, (size_t)n_clips * sizeof(dsp_classify_trace));
+        return DSP_OK;
+    }
+    if ((rc = cls_reserve(g_cls, std::min(kClsSubBatch, n_clips), n_max, false)) < 0) return rc;
+    dsp::SpanRing::Slot *slot = nullptr;
+    DSP_HIP(g_cls.spans.acquire((size_t)n_clips * sizeof(dsp::ClipSpan), &slot));
+    dsp::ClipSpan *h = static_cast<dsp::ClipSpan *>(slot->h);
+    for (long c = 0; c < n_clips; ++c) h[c] = dsp::ClipSpan{offsets[c], (int)(offsets[c + 1] - offsets[c]), spec_bins((int)(offsets[c + 1] - offsets[c]))};
+    if (g_cls.pending) DSP_HIP(hipStreamWaitEvent(st, g_cls.done, 0));      // the previous call's work on this workspace (any stream)
+    DSP_HIP(dsp::SpanRing::upload(slot, (size_t)n_clips * sizeof(dsp::ClipSpan), st));
+    struct SlotMark { dsp::SpanRing::Slot *s; hipStream_t st; ~SlotMark() { dsp::SpanRing::mark(s, st); } } slot_mark{slot, st};
+    ClsBusyMark mark{g_cls, st};
+    const dsp::ClipSpan *d_spans = static_cast<const dsp::ClipSpan *>(slot->d);
+    for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
+        const long cnt = std::min(kClsSubBatch, n_clips - c0);
+        if ((rc = cls_run(g_cls, cfg, d_signal, in, cnt, n_max, 0, st, trace != nullptr, d_spans + c0, offsets[n_clips])) < 0) return rc;
+        if (d_labels) DSP_HIP(hipMemcpyAsync(d_labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, st));
+        if (labels) DSP_HIP(hipMemcpyAsync(labels + c0, g_cls.d_labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (trace) DSP_HIP(hipMemcpyAsync(trace + c0, g_cls.d_trace, (size_t)cnt * sizeof(dsp::ClassifyTrace), hipMemcpyDeviceToHost, st));
+        if (labels || trace) DSP_HIP(hipStreamSynchronize(st));
+    }
+    return DSP_OK;
+}
+
+int cls_ragged_device_entry(const dsp_classify_config *cfgp, const void *d_signal, int in, long n_clips, const long *offsets, int *d_labels, void *stream)
+{
+    if (!d_signal || !d_labels || !offsets || n_clips < 0) return fail(DSP_EINVAL, "bad argument");
+    if (n_clips == 0) return DSP_OK;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, d_signal) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(DSP_EINVAL, "signal is not a device pointer");
+    }
+    if (attr.device < 0 || attr.device >= kMaxDevices) return fail(DSP_EINVAL, "device index out of range");
+    return cls_ragged(cfgp, d_signal, attr.device, in, n_clips, offsets, d_labels, nullptr, nullptr, stream);
+}
+
+int cls_ragged_host_entry(const dsp_classify_config *cfgp, const void *signal, int in, long n_clips, const long *offsets, int *labels, dsp_classify_trace *trace)
+{
+    if (!signal || !labels || !offsets || n_clips < 0) return fail(DSP_EINVAL, "bad argument");
+    if (n_clips == 0) return DSP_OK;
+    if (offsets[n_clips] < offsets[0] || offsets[0] < 0) return fail(DSP_EINVAL, "offsets must be non-negative and non-decreasing, clips shorter than 2^31 samples");
+    int device = 0;
+    int rc = cls_host_device(device);
+    if (rc < 0) return rc;
+    // the whole buffer travels once (a buffer of its own: the contexts' staging rows are laid out for equal clips)
+    void *d_flat = nullptr;
+    const size_t bytes = (size_t)offsets[n_clips] * cls_bytes(in);
+    {
+        DSP_ON_DEVICE(device);
+        DSP_HIP(hipMalloc(&d_flat, bytes + 16));
+        const hipError_t e = hipMemcpy(d_flat, signal, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d_flat); DSP_HIP(e); }
+    }
+    rc = cls_ragged(cfgp, d_flat, device, in, n_clips, offsets, nullptr, labels, trace, nullptr);
+    {
+        dsp::DeviceScope on(device);
+        (void)hipStreamSynchronize(nullptr);
+        (void)hipFree(d_flat);
+    }
+    return rc;
+}
+
 }  // namespace
 
 int dsp_classify_batch_host_cfg(const dsp_classify_config *cfgp, const float *signal, long n_clips, int n, long stride, int *labels,
@@ -1146,6 +1238,33 @@ int dsp_classify_batch_pcm16_device(const dsp_classify_config *cfgp, const int16
     int in = 0;
     const int rc = cls_input_kind(channels, stereo_mode, in);
     return rc < 0 ? rc : cls_device_entry(cfgp, d_pcm, in, n_clips, n, stride, d_labels, stream);
+}
+
+int dsp_classify_batch_ragged_device(const dsp_classify_config *cfgp, const float *d_signal, long n_clips, const long *offsets, int *d_labels, void *stream)
+{
+    return cls_ragged_device_entry(cfgp, d_signal, 0, n_clips, offsets, d_labels, stream);
+}
+
+int dsp_classify_batch_ragged_pcm16_device(const dsp_classify_config *cfgp, const int16_t *d_pcm, long n_clips, const long *offsets, int channels,
+                                           int stereo_mode, int *d_labels, void *stream)
+{
+    int in = 0;
+    const int rc = cls_input_kind(channels, stereo_mode, in);
+    return rc < 0 ? rc : cls_ragged_device_entry(cfgp, d_pcm, in, n_clips, offsets, d_labels, stream);
+}
+
+int dsp_classify_batch_ragged_host(const dsp_classify_config *cfgp, const float *signal, long n_clips, const long *offsets, int *labels,
+                                   dsp_classify_trace *trace)
+{
+    return cls_ragged_host_entry(cfgp, signal, 0, n_clips, offsets, labels, trace);
+}
+
+int dsp_classify_batch_ragged_pcm16_host(const dsp_classify_config *cfgp, const int16_t *pcm, long n_clips, const long *offsets, int channels,
+                                         int stereo_mode, int *labels, dsp_classify_trace *trace)
+{
+    int in = 0;
+    const int rc = cls_input_kind(channels, stereo_mode, in);
+    return rc < 0 ? rc : cls_ragged_host_entry(cfgp, pcm, in, n_clips, offsets, labels, trace);
 }
 
 /* A context of the caller's own: the default entry points share one workspace per device, so two calls on one device run one behind

@@ -467,13 +467,18 @@ __device__ __forceinline__ float cls_sample_at(const void *__restrict__ x, long 
 #define DSP_CKPT_DUAL 0
 #endif
 typedef float ck_f2 __attribute__((ext_vector_type(2)));
-template <bool EVEN_B, bool DUAL, int IN = 0>
-__global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const void *__restrict__ xv, long n_clips, int n, long stride,
+// RAGGED: clips of different lengths (spans[clip]: start, segments).  The workspaces keep the uniform [clip][n_seg(n)] layout, n = the
+// longest clip; a block walks as many tiles as its own longest clip's WHOLE segments cover (a multiple of the tile: a tail past the last
+// whole segment feeds nothing, see the taps wave) and a lane simply stops keeping states / means / gates at its clip's last segment --
+// what it computes past that point (the next clip's samples, zeros past the buffer's end) is never looked at.
+template <bool EVEN_B, bool DUAL, int IN = 0, bool RAGGED = false>
+__global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const void *__restrict__ xv, long n_clips, int n_arg, long stride,
                                                         const IirCoef c_bp, const IirCoef c_mp, float *__restrict__ ck_bp,
                                                         float *__restrict__ ck_mp, float *__restrict__ means_mp,
                                                         int *__restrict__ want_mp, const SpecTables *__restrict__ tab, int vec_ok, int *__restrict__ simd_load,
-                                                        int blocks_per_cu)
+                                                        int blocks_per_cu, const ClipSpan *__restrict__ spans = nullptr, long total = 0)
 {
+    static_assert(!(RAGGED && DUAL), "the ragged form exists for the three-wave kernel");
     __shared__ float tin[2][64 * IIR_LD];
     __shared__ float vbuf[2][64 * IIR_LD];             // v tiles of the 1000-3000 Hz filter, [tile parity]
     // The 1000-3000 Hz restart states wait in LDS until the taps wave has the segment's energy gate: only the gated-in segments
@@ -531,8 +536,23 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const void 
     float *__restrict__ ck = (DUAL || wv != 0) ? ck_mp : ck_bp;
     const long clip0 = (long)blockIdx.x * 64;
     const int rows = (int)((n_clips - clip0) < 64 ? (n_clips - clip0) : 64);
+    const int n_seg = n_arg < kSpecSeg ? 0 : (n_arg - kSpecSeg) / kSpecHop + 1;      // the workspaces' row length (RAGGED: the longest clip's)
+    __shared__ long s_base[RAGGED ? 64 : 1];
+    __shared__ int s_nseg[RAGGED ? 64 : 1], s_cover;
+    int n = n_arg, my_nseg = n_seg;                     // RAGGED: samples this block walks, segments of this lane's clip
+    if (RAGGED) {
+        if (threadIdx.x == 0) s_cover = 0;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            ClipSpan sp{0, 0, 0};
+            if ((int)threadIdx.x < rows) sp = spans[clip0 + threadIdx.x];
+            s_base[threadIdx.x] = sp.off; s_nseg[threadIdx.x] = sp.frames;
+            if (sp.frames > 0) atomicMax(&s_cover, (sp.frames - 1) * kSpecHop + kSpecSeg);
+        }
+        __syncthreads();
+        n = s_cover; my_nseg = s_nseg[lane];
+    }
     const int n_tiles = (n + IIR_TS - 1) / IIR_TS;
-    const int n_seg = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     static_assert(kSpecHop % IIR_TS == 0 && kSpecSeg - kSpecHop == IIR_TS, "segments start on tile boundaries and overlap by one tile");
     constexpr int kTilesPerHop = kSpecHop / IIR_TS;
     float d[8];                                         // v[n-1] .. v[n-8] of this lane's clip
@@ -561,6 +581,11 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const void 
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e = tid + 128 * k, r = e / CH, cc = (e % CH) * PP;
+            if (RAGGED) {      // any alignment (the hardware's unaligned loads); a piece that would cross the buffer's end lies past every whole segment
+                const long idx = s_base[r] + t0 + cc;
+                pre[k] = (r < rows && idx + PP <= total) ? *reinterpret_cast<const cls_u4 *>(reinterpret_cast<const unsigned char *>(xv) + idx * ClsIn<IN>::kBytes)
+                                                         : cls_u4{0u, 0u, 0u, 0u};
+            } else
             pre[k] = r < rows ? *reinterpret_cast<const cls_u4 *>(reinterpret_cast<const unsigned char *>(xv) + ((clip0 + r) * stride + t0 + cc) * ClsIn<IN>::kBytes)
                               : cls_u4{0u, 0u, 0u, 0u};
         }
@@ -582,7 +607,7 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const void 
         }
     };
     auto tile_cols = [&](int s) { const int t0 = s * IIR_TS; return n - t0 < IIR_TS ? n - t0 : IIR_TS; };
-    auto fast = [&](int s) { return vec_ok && tile_cols(s) == IIR_TS; };
+    auto fast = [&](int s) { return RAGGED || (vec_ok && tile_cols(s) == IIR_TS); };      // (RAGGED: every tile is whole)
     if (loader) {                                                  // tile 0 into tin[0], tile 1 in flight
         if (fast(0)) { issue(0); commit(tin[0]); } else load_scalar(0, tile_cols(0), tin[0]);
         if (n_tiles > 1 && fast(1)) issue(IIR_TS);
@@ -604,7 +629,7 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const void 
                 static_assert(kSpecSeg / 2 % IIR_TS == 0 && kMidTile < kTilesPerHop, "the segment's middle lies on a tile boundary");
                 const int ck_n = (DUAL || wv != 0) ? kCkPerSegMp : kCkPerSegBp;      // states per segment of `ck`
                 const bool at_start = seg_tile == 0, at_mid = seg_tile == kMidTile && (DUAL ? (kCkPerSegBp == 2 || kCkPerSegMp == 2) : ck_n == 2);
-                if ((at_start || at_mid) && seg < n_seg && lane < rows) {
+                if ((at_start || at_mid) && seg < my_nseg && lane < rows) {
                     const long slot = (((clip0 + lane) * n_seg + seg) * ck_n + (at_mid ? 1 : 0)) * 8;
                     float4 *dst = reinterpret_cast<float4 *>(ck + slot);
                     if (DUAL) {
@@ -720,7 +745,7 @@ __global__ __launch_bounds__(DUAL ? 128 : 192) void iir2_ckpt_kernel(const void 
                     }
                 }
                 if (seg_start) c_first = cur;
-                if (seg_both && seg_k - 1 < n_seg) {
+                if (seg_both && seg_k - 1 < my_nseg) {
                     const float m = prev / (float)kSpecSeg;
                     means_mp[(clip0 + lane) * n_seg + seg_k - 1] = m;
                     int g = 1;
@@ -756,7 +781,7 @@ static bool even_taps_only(const IirCoef &c) { return c.b[1] == 0.0f && c.b[3] =
 
 hipError_t launch_iir2_ckpt(const void *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
                             float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream,
-                            int *simd_load, int in_kind)
+                            int *simd_load, int in_kind, const ClipSpan *spans, long total)
 {
     // DSP_AMD_CKPT_SIMD_AWARE: 0 = fixed parts (A/B runs), 2 = the table for every launch whatever its size (tests)
     static const int simd_mode = [] { const char *e = std::getenv("DSP_AMD_CKPT_SIMD_AWARE"); return e ? std::atoi(e) : 1; }();
@@ -784,6 +809,18 @@ hipError_t launch_iir2_ckpt(const void *x, long n_clips, int n, long stride, con
     hipLaunchKernelGGL((iir2_ckpt_kernel<E, D, I>), dim3(blocks), dim3(D ? 128 : 192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, \
                        means_mp, want_mp, tables, vec_ok, simd_load, blocks / n_cu)
     const bool even = even_taps_only(c_mp);
+    if (spans) {                                                     // ragged batches: the literal tables' even numerators, three-wave form
+#define DSP_CKPT_LAUNCH_RAGGED(I)                                                                                                         \
+    hipLaunchKernelGGL((iir2_ckpt_kernel<true, false, I, true>), dim3(blocks), dim3(192), 0, stream, x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, \
+                       means_mp, want_mp, tables, 1, simd_load, blocks / n_cu, spans, total)
+        if (!even || in_kind < 0 || in_kind > 3) return hipErrorInvalidValue;
+        if (in_kind == 0) DSP_CKPT_LAUNCH_RAGGED(0);
+        else if (in_kind == 1) DSP_CKPT_LAUNCH_RAGGED(1);
+        else if (in_kind == 2) DSP_CKPT_LAUNCH_RAGGED(2);
+        else DSP_CKPT_LAUNCH_RAGGED(3);
+#undef DSP_CKPT_LAUNCH_RAGGED
+        return hipGetLastError();
+    }
     if (in_kind == 0) { if (even) DSP_CKPT_LAUNCH(true, dual, 0); else DSP_CKPT_LAUNCH(false, dual, 0); }
     else if (!even) return hipErrorInvalidValue;                     // int16 input: the literal tables' even numerators only
     else if (in_kind == 1) DSP_CKPT_LAUNCH(true, false, 1);
@@ -1218,8 +1255,10 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                                                              const float *__restrict__ ck, const float *__restrict__ means,
                                                              const int *__restrict__ wantlist, const int *__restrict__ hits,
                                                              const SpecTables *__restrict__ tab, float *__restrict__ out, int T, int vec_ok,
-                                                             const int *__restrict__ need, unsigned *__restrict__ minmax)
+                                                             const int *__restrict__ need, unsigned *__restrict__ minmax,
+                                                             const ClipSpan *__restrict__ spans = nullptr)
 {
+    // spans (ragged batches): clip c starts at spans[c].off instead of c * stride; T stays the workspaces' row length.
     // SPEC_FRAME_MAJOR with need / minmax (classify): a row is stored only when need[clip][t] says a band window of one of the clip's
     // midpoints covers time bin t (classify_midpoints_kernel), and the smallest / largest positive cell of every transformed frame
     // goes into minmax[clip][2] (float bits, atomicMin / atomicMax; reset by classify_midpoints_kernel) -- what the band kernel's dB
@@ -1253,6 +1292,7 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
                 const long slotc = gid / T;
                 dt = (int)(gid - slotc * T);
                 dclip = hits[1 + slotc];
+                if (spans && dt >= spans[dclip].frames) dclip = -1;      // ragged batches: past the clip's last segment
             }
         }
     };
@@ -1274,7 +1314,8 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
             const int e = threadIdx.x + RC_THREADS * i, r = e / PER_ROW, c4 = (e % PER_ROW) * 4;      // r is wave-uniform
             if (r >= RC_FRAMES) { v4[i] = cls_u4{0u, 0u, 0u, 0u}; continue; }
             const int rclip = __builtin_amdgcn_readlane(iclip, r);
-            const long s0 = (long)(rclip < 0 ? 0 : rclip) * stride + (long)__builtin_amdgcn_readlane(it, r) * kSpecHop + c4;     // unwanted slots: clip 0, t 0
+            const long rc0 = rclip < 0 ? 0 : rclip;                                                                          // unwanted slots: clip 0, t 0
+            const long s0 = (spans ? (rclip < 0 ? 0 : spans[rc0].off) : rc0 * stride) + (long)__builtin_amdgcn_readlane(it, r) * kSpecHop + c4;
             const unsigned char *xs = reinterpret_cast<const unsigned char *>(xv) + s0 * ClsIn<IN>::kBytes;
             if (IN == 1) {
                 if (vec_ok) { const uint2 q = *reinterpret_cast<const uint2 *>(xs); v4[i] = cls_u4{q.x, q.y, 0u, 0u}; }
@@ -1504,17 +1545,18 @@ static int rc_resident_blocks()
 
 hipError_t launch_spec_from_ckpt(const void *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
                                  const int *wantlist, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream,
-                                 const int *need, unsigned *minmax, int in_kind)
+                                 const int *need, unsigned *minmax, int in_kind, const ClipSpan *spans)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0 || T <= 0) return hipSuccess;
     if (n_clips >= (1L << 31)) return hipErrorInvalidValue;      // clip numbers travel as ints
     const long total = n_clips * T;                       // the bound: the work lists' counts are read on the device
-    const int vec_ok = stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    // (ragged batches: rows start anywhere; the 16-byte loads go out unaligned, which the hardware serves)
+    const int vec_ok = spans ? 1 : (stride % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0);
     const long groups = (total + RC_FRAMES - 1) / RC_FRAMES;
     auto launch = [&](auto kernel, int resident, const int *wl, const int *hl) {
         const dim3 grid((unsigned)std::min<long>(groups, resident));
-        hipLaunchKernelGGL(kernel, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wl, hl, tables, out, T, vec_ok, need, minmax);
+        hipLaunchKernelGGL(kernel, grid, dim3(RC_THREADS), 0, stream, x, n_clips, n, stride, c, ck, means, wl, hl, tables, out, T, vec_ok, need, minmax, spans);
     };
     const bool even = even_taps_only(c);
     if (in_kind != 0 && (!even || in_kind < 0 || in_kind > 3)) return hipErrorInvalidValue;      // int16 input: the literal tables' even numerators only
@@ -1790,10 +1832,13 @@ hipError_t launch_spec_threshold(SpecTables *tables, float threshold_db, hipStre
 //   classify_bands_kernel      (band-pass spectrogram, clips with midpoints only)  dB map, normalisation, the three
 //                              band sums per midpoint in the reference's order, the rule
 constexpr int kMidClipsPerWave = 4;       // clips one wavefront walks: one atomic on the work-list counter per 16 clips, not per clip
-__global__ __launch_bounds__(256) void classify_midpoints_kernel(int *loud, long n_clips, int T, int fs,
+__global__ __launch_bounds__(256) void classify_midpoints_kernel(int *loud, long n_clips, const int T, int fs,
                                                                  int *__restrict__ labels, ClassifyTrace *__restrict__ trace,
-                                                                 int *__restrict__ hits, int full_records, unsigned *__restrict__ minmax)
+                                                                 int *__restrict__ hits, int full_records, unsigned *__restrict__ minmax,
+                                                                 const ClipSpan *__restrict__ spans = nullptr)
 {
+    // spans (ragged batches): clip c has spans[c].frames time bins (the head of its row of T_row); everything below sees that count.
+    const int T_row = T;
     // minmax != nullptr (classify): once a clip's flags are read, its row of loud[] is rewritten as need[t] = "time bin t lies in a
     // band window (+- 0.18 s or +- 0.05 s, sum_intense's own search) of one of the clip's midpoints" -- the rows the band sums will
     // read and the only ones spec_from_ckpt_kernel<[time][bin]> stores -- and minmax[clip] is reset for that kernel's atomics.
@@ -1814,11 +1859,12 @@ __global__ __launch_bounds__(256) void classify_midpoints_kernel(int *loud, long
     for (int ci = 0; ci < kMidClipsPerWave; ++ci) {
         const long clip = first + ci;
         if (clip >= n_clips) break;
+        const int T = spans ? spans[clip].frames : T_row;
         // blob times of the flagged bins, in order (ballot ranks), then the greedy clustering on one lane
         int nb = 0;
         for (int j0 = 0; j0 < T; j0 += 64) {
             const int j = j0 + lane;
-            const bool flag = j < T && loud[clip * T + j] != 0;
+            const bool flag = j < T && loud[clip * T_row + j] != 0;
             const unsigned long long m = __ballot(flag);
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
             if (flag) blob[nb + rank] = ((float)(j * kSpecHop + kSpecSeg / 2)) / (float)fs;
@@ -1869,7 +1915,7 @@ __global__ __launch_bounds__(256) void classify_midpoints_kernel(int *loud, long
                 const int j = j0 + lane;
                 int nd = 0;
                 for (int w = 0; w < 2 * count; ++w) nd |= (j >= win_lo[wib][w] && j <= win_hi[wib][w]) ? 1 : 0;
-                if (j < T) loud[clip * T + j] = nd;
+                if (j < T) loud[clip * T_row + j] = nd;
             }
             if (lane == 0) { minmax[2 * clip] = 0x7F800000u; minmax[2 * clip + 1] = 0u; }      // + inf, 0: nothing seen yet
         }
@@ -1906,8 +1952,9 @@ constexpr int kTailPerThread = (kTailLdsCells + 255) / 256;
 template <bool USE_LDS>
 __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, long clip, int T, int fs, int *__restrict__ labels,
                                                     ClassifyTrace *__restrict__ trace, float *map_lds, const ClassifyRule &rule,
-                                                    bool partial, const int (&need_regs)[USE_LDS ? 1 : 4], const unsigned (&minmax_regs)[2])
+                                                    bool partial, const int (&need_regs)[USE_LDS ? 1 : 4], const unsigned (&minmax_regs)[2], int T_row)
 {
+    // T_row: time bins per clip in sxx_bp's layout (ragged batches: the longest clip's; this clip's map is the first T of them)
     // partial: need_regs = this thread's words of need[clip][] (time bins tid + 256 k) and minmax_regs = minmax[clip][], fetched by
     // the caller while the previous clip was being worked on (read here they cost each clip two exposed round trips to memory)
     __shared__ float red_mn[4], red_mx[4];
@@ -1923,7 +1970,7 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
     const int n_mids = trace[clip].n_midpoints;
     const int tid = threadIdx.x;
     const int cells = kSpecBins * T;
-    float *bp_g = sxx_bp + clip * (long)cells;
+    float *bp_g = sxx_bp + clip * (long)kSpecBins * T_row;
     if (tid < n_mids) mids[tid] = trace[clip].midpoints[tid];
     BD_STAMP(0);
 
@@ -2075,7 +2122,8 @@ __device__ __forceinline__ void classify_bands_clip(float *__restrict__ sxx_bp, 
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void classify_bands_kernel(float *__restrict__ sxx_bp, int T, int fs, int *__restrict__ labels,
                                                              ClassifyTrace *__restrict__ trace, const int *__restrict__ hits,
-                                                             const ClassifyRule rule, const int *__restrict__ need, const unsigned *__restrict__ minmax)
+                                                             const ClassifyRule rule, const int *__restrict__ need, const unsigned *__restrict__ minmax,
+                                                             const ClipSpan *__restrict__ spans = nullptr)
 {
     extern __shared__ float map_lds[];
     const int count = hits[0];
@@ -2098,25 +2146,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
         for (int k = 0; k < NK; ++k) nd[k] = nd_next[k];
         mm2[0] = mm2_next[0]; mm2[1] = mm2_next[1];
         fetch(it + gridDim.x, nd_next, mm2_next);            // the next clip's, in flight during this one
-        classify_bands_clip<USE_LDS>(sxx_bp, hits[1 + it], T, fs, labels, trace, map_lds, rule, partial, nd, mm2);
+        const long bclip = hits[1 + it];
+        classify_bands_clip<USE_LDS>(sxx_bp, bclip, spans ? spans[bclip].frames : T, fs, labels, trace, map_lds, rule, partial, nd, mm2, T);
         __syncthreads();                                     // the block's LDS is reused by the next clip
     }
 }
 
 hipError_t launch_classify_midpoints(int *loud, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, int *hits,
-                                     hipStream_t stream, bool full_records, unsigned *minmax)
+                                     hipStream_t stream, bool full_records, unsigned *minmax, const ClipSpan *spans)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0) return hipSuccess;
     if (T <= 0 || T > 1024 || !trace || !hits) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(hits, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(classify_midpoints_kernel, dim3((unsigned)((n_clips + 4 * kMidClipsPerWave - 1) / (4 * kMidClipsPerWave))), dim3(256), 0, stream, loud, n_clips, T, fs, labels, trace, hits, full_records ? 1 : 0, minmax);
+    hipLaunchKernelGGL(classify_midpoints_kernel, dim3((unsigned)((n_clips + 4 * kMidClipsPerWave - 1) / (4 * kMidClipsPerWave))), dim3(256), 0, stream, loud, n_clips, T, fs, labels, trace, hits, full_records ? 1 : 0, minmax, spans);
     return hipGetLastError();
 }
 
 hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, const int *hits,
-                                 hipStream_t stream, const ClassifyRule &rule, const int *need, const unsigned *minmax)
+                                 hipStream_t stream, const ClassifyRule &rule, const int *need, const unsigned *minmax, const ClipSpan *spans)
 {
     const int T = n < kSpecSeg ? 0 : (n - kSpecSeg) / kSpecHop + 1;
     if (n_clips <= 0) return hipSuccess;
@@ -2124,9 +2173,9 @@ hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int
     const unsigned blocks = (unsigned)(n_clips < 2048 ? n_clips : 2048);      // 256 CUs x 4 resident blocks x 2
     if (kSpecBins * T <= kTailLdsCells)
         hipLaunchKernelGGL(classify_bands_kernel<true>, dim3(blocks), dim3(256), (size_t)kSpecBins * T * sizeof(float), stream, sxx_bp, T, fs,
-                           labels, trace, hits, rule, need, minmax);
+                           labels, trace, hits, rule, need, minmax, spans);
     else
-        hipLaunchKernelGGL(classify_bands_kernel<false>, dim3(blocks), dim3(256), 0, stream, sxx_bp, T, fs, labels, trace, hits, rule, need, minmax);
+        hipLaunchKernelGGL(classify_bands_kernel<false>, dim3(blocks), dim3(256), 0, stream, sxx_bp, T, fs, labels, trace, hits, rule, need, minmax, spans);
     return hipGetLastError();
 }
 

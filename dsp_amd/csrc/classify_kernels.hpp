@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "clip_span.hpp"
+
 namespace dsp {
 
 constexpr int kSpecSeg = 256;    // nperseg            classifier.cpp:223
@@ -82,7 +84,10 @@ constexpr int kSimdLoadCus = 4096, kSimdLoadStride = 8;
 // counts samples per channel; converted in the kernels' loads (exact: the float path's bits)
 hipError_t launch_iir2_ckpt(const void *x, long n_clips, int n, long stride, const IirCoef &c_bp, const IirCoef &c_mp,
                             float *ck_bp, float *ck_mp, float *means_mp, int *want_mp, const SpecTables *tables, hipStream_t stream,
-                            int *simd_load = nullptr, int in_kind = 0);
+                            int *simd_load = nullptr, int in_kind = 0, const ClipSpan *spans = nullptr, long total = 0);
+// RAGGED batches (spans != nullptr; every launcher of the classify() pipeline takes them): clip c starts at spans[c].off samples from x
+// and has spans[c].frames whole segments; n is then the LONGEST clip's length (the workspaces keep the uniform [clip][T(n)] layout, a
+// shorter clip uses the head of its rows), stride is unused, and `total` = samples in the buffer (loads past it read as zero).
 // Spectrogram of segments recomputed from those checkpoints (filter c, checkpoints ck: ck_mp's layout for flags = true, ck_bp's
 // otherwise).  flags = true: out = int loud[c][T]
 // (1 = some cell >= mp_keep_min; 0 for every segment not on `wantlist`), means = means_mp; flags = false: out = PSD
@@ -91,7 +96,7 @@ hipError_t launch_iir2_ckpt(const void *x, long n_clips, int n, long stride, con
 // cell over ALL transformed rows of clip c (atomicMin / atomicMax: the caller resets them to +inf / 0; launch_classify_midpoints does).
 hipError_t launch_spec_from_ckpt(const void *x, long n_clips, int n, long stride, const IirCoef &c, const float *ck, const float *means,
                                  const int *wantlist, const int *hits, const SpecTables *tables, float *out, bool flags, hipStream_t stream,
-                                 const int *need = nullptr, unsigned *minmax = nullptr, int in_kind = 0);
+                                 const int *need = nullptr, unsigned *minmax = nullptr, int in_kind = 0, const ClipSpan *spans = nullptr);
 
 // sxx[c][129][T] (T = (n-256)/224+1) of clip rows y[c][0..n)
 struct ClassifyTrace {           // per clip, for parity tests
@@ -127,12 +132,13 @@ hipError_t launch_spectrogram_flags(const float *y, long n_clips, int n, long st
 // one of the clip's midpoints covers time bin t", and minmax[c] is reset (+inf, 0) for launch_spec_from_ckpt's atomics; pass both to
 // launch_spec_from_ckpt and launch_classify_bands: only the needed rows of the map are then stored and read.
 hipError_t launch_classify_midpoints(int *loud, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, int *hits,
-                                     hipStream_t stream, bool full_records = true, unsigned *minmax = nullptr);
+                                     hipStream_t stream, bool full_records = true, unsigned *minmax = nullptr, const ClipSpan *spans = nullptr);
 // the thresholds of classify() the reference's variants differ in (dsp_classify_config): keep band of the normalised dB
 // map (classifier.cpp:67-68) and the rule middle < . && above > . && below > . (classifier.cpp:109)
 struct ClassifyRule { float keep_lo, keep_hi, middle_max, above_min, below_min; };
 hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, const int *hits,
-                                 hipStream_t stream, const ClassifyRule &rule, const int *need = nullptr, const unsigned *minmax = nullptr);
+                                 hipStream_t stream, const ClassifyRule &rule, const int *need = nullptr, const unsigned *minmax = nullptr,
+                                 const ClipSpan *spans = nullptr);
 // Counts, into *mismatches (device, zeroed by the caller), the floats p in [kDivFastLo, kDivFastHi] for which the three-instruction
 // form of p / tables->U (see SpecTables::rU) differs from the division: every bit pattern in the range is tried.
 hipError_t launch_spec_div_verify(const SpecTables *tables, unsigned long long *mismatches, hipStream_t stream);

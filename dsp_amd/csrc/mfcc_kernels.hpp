@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "clip_span.hpp"
 #include "consumer_kernels.hpp"
 #include "svm_kernels.hpp"
 #include "tables.hpp"
@@ -26,15 +27,6 @@ struct PoolSvmArgs {
 struct StopNetArgs {
     StopModelDev m;        // units[0] <= kStopFusedUnits, n_coef = n_mfcc <= 16
     float *prob;           // [n_clips]
-};
-
-// One clip of a ragged batch (the reference's callers loop over files of different lengths -- cepstrum/scrubjay_infer.c:158-176,
-// 2fa/audio/word/c/main_test.c:254-331): where it starts in the input buffer, its samples, and the frames the host counted for it
-// (dsp_mfcc_frames_for: the kernels divide nothing).  16 bytes: one scalar load per clip.
-struct ClipSpan {
-    long off;      // first sample (per channel) from Mfcc512Args::in
-    int n;         // samples per channel
-    int frames;    // >= 1
 };
 
 struct Mfcc512Args {

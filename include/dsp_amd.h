@@ -244,6 +244,20 @@ int dsp_classify_batch_pcm16_host(const dsp_classify_config *cfg, const int16_t 
                                   int stereo_mode, int *labels, dsp_classify_trace *trace);
 int dsp_classify_batch_pcm16_device(const dsp_classify_config *cfg, const int16_t *d_pcm, long n_clips, int n, long stride, int channels,
                                     int stereo_mode, int *d_labels, void *stream);
+/* RAGGED batches: clips of different lengths in one call (donut-classifier/classifier.c:286-297 reads a file of any length; its callers
+ * loop over files).  offsets is a HOST array of n_clips + 1 sample positions (per channel) into the buffer: clip c is
+ * [offsets[c], offsets[c + 1]), non-decreasing, any parity; a clip shorter than 256 samples holds no spectrogram segment and gets label
+ * 0, one of more than 13.4 s is refused like in the uniform entry points.  Every clip gets the label (and trace record) of a one-clip
+ * call on it, bit for bit.  The array is read before the call returns.  _device: the whole buffer in HBM, stream-ordered; _host: the
+ * buffer signal[offsets[n_clips]] is copied to the GPU once, trace may be NULL.                                                       */
+int dsp_classify_batch_ragged_device(const dsp_classify_config *cfg, const float *d_signal, long n_clips, const long *offsets,
+                                     int *d_labels, void *stream);
+int dsp_classify_batch_ragged_pcm16_device(const dsp_classify_config *cfg, const int16_t *d_pcm, long n_clips, const long *offsets,
+                                           int channels, int stereo_mode, int *d_labels, void *stream);
+int dsp_classify_batch_ragged_host(const dsp_classify_config *cfg, const float *signal, long n_clips, const long *offsets, int *labels,
+                                   dsp_classify_trace *trace);
+int dsp_classify_batch_ragged_pcm16_host(const dsp_classify_config *cfg, const int16_t *pcm, long n_clips, const long *offsets,
+                                         int channels, int stereo_mode, int *labels, dsp_classify_trace *trace);
 /* A classifier context of the caller's own (tables + workspace on `device`).  The entry points above share one context per device, so
  * two calls on one device run one behind the other; calls through different contexts, on different streams, may overlap.            */
 typedef struct dsp_classify_ctx dsp_classify_ctx;

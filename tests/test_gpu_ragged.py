@@ -7,6 +7,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def dsp():
+    import dsp_amd
+    return dsp_amd
+
+
 def _lengths(rng, count, lo, hi):
     n = rng.integers(lo, hi, count)
     n[0], n[1] = lo, hi          # the shortest clip that still has a frame, and the longest
@@ -146,3 +152,110 @@ def test_many_ragged_calls_in_flight_share_no_buffer(golden):
     for a, q in zip(alone, queued):
         for x, y in zip(a, q):
             assert torch.equal(x, y)
+
+
+def _trace_equal(a, b):
+    return np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def _classify_clips(rng, count):
+    """clips of 0.01 s .. 5 s cut from the classifier's test signals (calls, bursts, noise) with offsets, gains and tails of noise"""
+    from tests import signals as S
+    cases = S.classify_cases()
+    names = ("scrub_a", "scrub_b", "jay_like", "burst_2k", "noise", "silence")
+    clips = []
+    for i in range(count):
+        base = cases[names[i % len(names)]]
+        n = int(rng.integers(160, 80000))
+        reps = -(-n // base.size)
+        x = np.tile(base, reps)[:n] * np.float32(rng.choice([1.0, 0.5, 2.0]))
+        x = x + (rng.standard_normal(n) * 1e-3).astype(np.float32)
+        clips.append(x.astype(np.float32))
+    clips[0] = clips[0][:255]            # no segment at all
+    clips[1] = np.tile(cases["scrub_a"], 2)[:256 + 224 * 3 + 7]      # a tail past the last whole segment
+    clips[2] = cases["scrub_a"][:15999]  # odd length: later clips start at odd samples
+    return clips
+
+
+def test_classify_ragged_equals_one_call_per_clip(dsp, golden):
+    """dsp_classify_batch_ragged_host / _device: labels, midpoints and band sums of every clip as a one-clip call returns them, under the
+    sync/lib thresholds and the microphone firmware's (where the test signals have midpoints and band sums)."""
+    import torch
+    rng = np.random.default_rng(90)
+    clips = _classify_clips(rng, 150)
+    flat, off = _pack(clips)
+    for cfg in (None, dsp.CLASSIFY_MICROPHONE):
+        labels, trace = dsp.classify_ragged(flat, off, with_trace=True, config=cfg)
+        dev = dsp.classify_device_ragged(torch.from_numpy(flat).cuda(), off, config=cfg).cpu().numpy()
+        assert np.array_equal(dev, labels)
+        seen = 0
+        for c, x in enumerate(clips):
+            l1, t1 = dsp.classify_batch(x[None, :], with_trace=True, config=cfg)
+            assert labels[c] == l1[0] and _trace_equal(trace[c], t1[0]), (c, x.size, cfg)
+            seen += len(t1[0][0])
+        assert seen > 40 and labels.sum() > 5
+    # int16: mono, stereo channel 0, stereo average
+    pcm = [np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16) for x in clips[:60]]
+    flat, off = _pack(pcm)
+    labels, trace = dsp.classify_ragged(flat, off, with_trace=True, config=dsp.CLASSIFY_MICROPHONE)
+    assert np.array_equal(dsp.classify_device_ragged(torch.from_numpy(flat).cuda(), off, config=dsp.CLASSIFY_MICROPHONE).cpu().numpy(), labels)
+    for c, x in enumerate(pcm):
+        l1, t1 = dsp.classify_batch_pcm16(x[None, :], with_trace=True, config=dsp.CLASSIFY_MICROPHONE)
+        assert labels[c] == l1[0] and _trace_equal(trace[c], t1[0]), (c, x.size)
+    st = [np.stack([x, (x // 3).astype(np.int16)], axis=1) for x in pcm]
+    flat, off = _pack(st)
+    for mode in (dsp.STEREO_CHANNEL0, dsp.STEREO_AVERAGE):
+        labels, trace = dsp.classify_ragged(flat, off, stereo_mode=mode, with_trace=True, config=dsp.CLASSIFY_MICROPHONE)
+        for c, x in enumerate(st):
+            l1, t1 = dsp.classify_batch_pcm16(x[None], stereo_mode=mode, with_trace=True, config=dsp.CLASSIFY_MICROPHONE)
+            assert labels[c] == l1[0] and _trace_equal(trace[c], t1[0]), (mode, c)
+    # nothing but clips without a segment; an empty batch; a clip of more than 13.4 s; offsets that run backwards
+    assert not dsp.classify_ragged(flat[:, 0].copy(), np.array([0, 100, 355])).any()
+    assert dsp.classify_ragged(flat[:, 0].copy(), np.array([0])).size == 0
+    with pytest.raises(dsp.DspError, match="too long"):
+        dsp.classify_ragged(np.zeros(300000, np.float32), np.array([0, 1000, 300000]))
+    with pytest.raises(dsp.DspError, match="non-decreasing"):
+        dsp.classify_ragged(np.zeros(30000, np.float32), np.array([0, 16000, 1000]))
+
+
+def test_classify_ragged_on_the_donut_recordings(dsp, golden):
+    """The donut classifier's own 16 kHz recordings (0.15 s .. 3 s, stereo int16; donut-classifier/16k/*.wav) in ONE call, as its reader
+    takes them (channel 0): labels and midpoints as the compiled reference returned them, band sums under the microphone firmware's
+    thresholds as the oracle gives them."""
+    g = golden("donut16k_ref.npz")
+    names = sorted({k.split("__")[0] for k in g.files})
+    flat, off = _pack([np.ascontiguousarray(g[n + "__pcm"]) for n in names])
+    labels, trace = dsp.classify_ragged(flat, off, stereo_mode=dsp.STEREO_CHANNEL0, with_trace=True)
+    mlabels, mtrace = dsp.classify_ragged(flat, off, stereo_mode=dsp.STEREO_CHANNEL0, with_trace=True, config=dsp.CLASSIFY_MICROPHONE)
+    for c, n in enumerate(names):
+        assert labels[c] == int(g[n + "__label"]) and np.array_equal(trace[c][0], g[n + "__midpoints"]), n
+        assert mlabels[c] == int(g[n + "__mic_label"]), n
+        assert np.array_equal(mtrace[c][0], g[n + "__mic_midpoints"]) and np.array_equal(mtrace[c][1], g[n + "__mic_sums"]), n
+
+
+def test_classify_ragged_across_sub_batches_and_block_edges(dsp):
+    """More clips than one pass through the workspace holds (65 536), lengths that differ inside every 64-clip block: labels against the
+    uniform entry point on the same clips grouped by length."""
+    import torch
+    from tests import signals as S
+    cases = S.classify_cases()
+    rng = np.random.default_rng(91)
+    lens = (4000, 9000, 16000)
+    n_clips = 70000
+    which = rng.integers(0, 3, n_clips)
+    kind = rng.integers(0, 4, n_clips)
+    src = [cases["scrub_a"], cases["noise"], cases["jay_like"], cases["scrub_b"]]
+    off = np.zeros(n_clips + 1, dtype=np.int64)
+    off[1:] = np.cumsum(np.asarray(lens)[which])
+    flat = torch.empty(int(off[-1]), device="cuda")
+    srcs = [[torch.from_numpy(s[:n].copy()).cuda() for n in lens] for s in src]
+    want = np.zeros(n_clips, np.int32)
+    for k in range(4):
+        for w, n in enumerate(lens):
+            one = int(dsp.classify_device(srcs[k][w][None, :]).cpu()[0])
+            idx = np.nonzero((kind == k) & (which == w))[0]
+            want[idx] = one
+            pos = torch.from_numpy(off[idx]).cuda()[:, None] + torch.arange(n, device="cuda")[None, :]
+            flat[pos.reshape(-1)] = srcs[k][w].repeat(idx.size)
+    got = dsp.classify_device_ragged(flat, off).cpu().numpy()
+    assert np.array_equal(got, want) and 0 < want.sum() < n_clips

@@ -1,6 +1,3 @@
 set -u
 mkdir -p gpurun_out/r4b
-timeout -k 10 600 python -m pytest tests/test_gpu_ragged.py tests/test_gpu_fused_pcm16.py tests/test_gpu_scrubjay.py tests/test_gpu_consumers.py -x -q > gpurun_out/r4b/ragged.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/r4b/ragged.log | cut -c1-250
-for w in config5 config5_2048 stop; do python bench.py --workload $w --no-cpu-baseline --steps 50 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['metric'], d['value'], d['roofline']['kernel_ms'], d['roofline']['frac'])"; done
-python tools/sq_fractions.py r4b frames
-python tools/sq_fractions.py r4b classify_f64
+timeout -k 10 800 python -m pytest tests/test_gpu_ragged.py tests/test_gpu_classify.py tests/test_gpu_classify_pcm16.py -x -q > gpurun_out/r4b/ragged2.log 2>&1; echo "tests rc=$?"; tail -25 gpurun_out/r4b/ragged2.log | cut -c1-250
