@@ -1319,6 +1319,22 @@ int dsp_debug_hold_classify_ctx(int device, int hold_ms)
     return DSP_OK;
 }
 
+int dsp_classify_stats(int device, long *gated_segments, long *listed_clips)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(DSP_EINVAL, "device index out of range");
+    ClassifyCtx &g_cls = g_cls_ctx[device];
+    std::lock_guard<std::mutex> lock(g_cls.mu);
+    if (g_cls.device < 0 || !g_cls.d_gate) return fail(DSP_EINVAL, "no classifier pass has run on this device");
+    DSP_ON_DEVICE(device);
+    g_cls.wait_idle();
+    int ng = 0, nh = 0;
+    DSP_HIP(hipMemcpy(&ng, g_cls.d_gate, sizeof(int), hipMemcpyDeviceToHost));
+    DSP_HIP(hipMemcpy(&nh, g_cls.d_hits, sizeof(int), hipMemcpyDeviceToHost));
+    if (gated_segments) *gated_segments = ng;
+    if (listed_clips) *listed_clips = nh;
+    return DSP_OK;
+}
+
 int dsp_classify_release(int device)
 {
     int count = 0;

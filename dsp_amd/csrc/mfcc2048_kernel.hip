@@ -63,7 +63,8 @@ constexpr int Q_WAVE_BYTES = Q_PART + 196 * 4;
 static_assert(Q_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
 constexpr int Q_W1024 = 4 * Q_WAVE_BYTES;          // block-shared: W1024^i, i < 1024
 constexpr int Q_W2048 = Q_W1024 + 1024 * 8;        // block-shared: W2048^k, k < 512
-constexpr int Q_WIN = Q_W2048 + 512 * 8;           // block-shared: window pairs (win[2a][l], win[2a+1][l]) at [a][l]
+constexpr int Q_TW1 = Q_W2048 + 512 * 8;           // block-shared: pass 1's twiddles W_256^(t k) at [t - 1][k], t = 1 .. 15, k < 16
+constexpr int Q_WIN = Q_TW1 + 15 * 16 * 8;         // block-shared: window pairs (win[2a][l], win[2a+1][l]) at [a][l]
 constexpr int Q_DCT = Q_WIN + 16 * 64 * 8;         // block-shared: dct_t[i][lane], i < ceil(n_mels / 2)
 constexpr int Q_BLOCK_BYTES = Q_DCT;               // + 256 B per DCT row (+ POOL: 2 x 64 floats, the Scaler's offset | scale), added by the launcher
 
@@ -121,10 +122,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     float *part = reinterpret_cast<float *>(wl + Q_PART);
     float *dct_t = reinterpret_cast<float *>(smem + Q_DCT);
     float2 *win2 = reinterpret_cast<float2 *>(smem + Q_WIN);
+    float2 *tw1 = reinterpret_cast<float2 *>(smem + Q_TW1);
     const int n_mels = args.n_mels, n_mfcc = args.n_mfcc;
     const int half = (n_mels + 1) / 2;                   // log-mels per DCT lane
     for (int i = threadIdx.x; i < 1024; i += 256) w1024[i] = make_float2(G->w1024[0][i], G->w1024[1][i]);
     for (int i = threadIdx.x; i < 512; i += 256) w2048[i] = make_float2(G->w2048[0][i], G->w2048[1][i]);
+    // pass 1 reads W_1024^(4 t k), k = lane % 16: out of the full table that is a stride of 8 t dwords -- 16 addresses on 8 / 4 / 2 / 1
+    // banks for t odd / 2 mod 4 / 4 mod 8 / 8 (tools/lds_banks_2048.py: 128 LDS cycles per frame where 30 would do); its own table
+    // [t - 1][k] puts the 16 values of a t side by side
+    if (threadIdx.x < 240) { const int i = 4 * (threadIdx.x / 16 + 1) * (threadIdx.x % 16); tw1[threadIdx.x] = make_float2(G->w1024[0][i], G->w1024[1][i]); }
     for (int i = threadIdx.x; i < half * 64; i += 256) dct_t[i] = (&G->dct_t[0][0])[i];
     // the window through LDS pays in the fused clip kernel (+4 %) and costs the plain one dearly (0.82 -> 1.34 ms per 250 000
     // frames, measured): it stays a global (L1) read there
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             const int k = lane & 15;
 #pragma unroll
             for (int t = 1; t < 16; ++t) {
-                const float2 w = w1024[4 * t * k];
+                const float2 w = tw1[16 * (t - 1) + k];
                 v[t] = cmul(v[t], c32{w.x, w.y});
             }
             radix16(v);

@@ -91,7 +91,7 @@ SYMBOLS = [
     "dsp_classify_batch_pcm16_host_f64", "dsp_classify_batch_pcm16_device_f64", "dsp_classify_release_f64", "dsp_classify_stats_f64", "dsp_classify_debug_f64",
     "dsp_classify_default_config", "dsp_classify_batch_host_cfg", "dsp_classify_batch_device_cfg", "dsp_sum_intense_f32",
     "dsp_butter_bandpass_filter_f32", "dsp_butter_bandpass_filter_f64", "dsp_compute_spectrogram_f32", "dsp_compute_spectrogram_f64",
-    "dsp_classify_batch_host", "dsp_classify_batch_device", "dsp_classify_batch_pcm16_host", "dsp_classify_batch_pcm16_device", "dsp_classify_release", "dsp_classify_ctx_create", "dsp_classify_ctx_destroy", "dsp_classify_batch_device_ctx", "dsp_debug_hold_classify_ctx", "dsp_find_midpoints", "dsp_classify_division_check",
+    "dsp_classify_batch_host", "dsp_classify_batch_device", "dsp_classify_batch_pcm16_host", "dsp_classify_batch_pcm16_device", "dsp_classify_release", "dsp_classify_stats", "dsp_classify_ctx_create", "dsp_classify_ctx_destroy", "dsp_classify_batch_device_ctx", "dsp_debug_hold_classify_ctx", "dsp_find_midpoints", "dsp_classify_division_check",
     "dsp_mfcc_stats_device", "dsp_svm_create", "dsp_svm_destroy", "dsp_svm_predict_device",
     "dsp_mfcc_default_config", "dsp_mfcc_scrubjay_infer_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
     "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",
@@ -181,6 +181,7 @@ def load() -> C.CDLL:
     L.dsp_scrubjay_fused_device.argtypes = [vp, vp, vp, C.c_long, ip, C.c_long, ip, vp, vp, vp, vp, vp]; L.dsp_scrubjay_fused_device.restype = ip
     L.dsp_scrubjay_fused_pcm16_device.argtypes = [vp, vp, vp, C.c_long, ip, C.c_long, ip, ip, ip, vp, vp, vp, vp, vp]; L.dsp_scrubjay_fused_pcm16_device.restype = ip
     lp = C.POINTER(C.c_long)
+    L.dsp_classify_stats.argtypes = [ip, lp, lp]; L.dsp_classify_stats.restype = ip
     L.dsp_classify_batch_ragged_device.argtypes = [vp, vp, C.c_long, lp, vp, vp]; L.dsp_classify_batch_ragged_device.restype = ip
     L.dsp_classify_batch_ragged_pcm16_device.argtypes = [vp, vp, C.c_long, lp, ip, ip, vp, vp]; L.dsp_classify_batch_ragged_pcm16_device.restype = ip
     L.dsp_classify_batch_ragged_host.argtypes = [vp, vp, C.c_long, lp, vp, vp]; L.dsp_classify_batch_ragged_host.restype = ip

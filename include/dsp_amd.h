@@ -258,6 +258,9 @@ int dsp_classify_batch_ragged_host(const dsp_classify_config *cfg, const float *
                                    dsp_classify_trace *trace);
 int dsp_classify_batch_ragged_pcm16_host(const dsp_classify_config *cfg, const int16_t *pcm, long n_clips, const long *offsets,
                                          int channels, int stereo_mode, int *labels, dsp_classify_trace *trace);
+/* What the LAST pass (sub-batch) of the shared context on `device` did (blocks until it has finished): segments of the 1000-3000 Hz
+ * output the energy gate left to the flag transform, clips that had midpoints.  Either pointer may be NULL.                           */
+int dsp_classify_stats(int device, long *gated_segments, long *listed_clips);
 /* A classifier context of the caller's own (tables + workspace on `device`).  The entry points above share one context per device, so
  * two calls on one device run one behind the other; calls through different contexts, on different streams, may overlap.            */
 typedef struct dsp_classify_ctx dsp_classify_ctx;
