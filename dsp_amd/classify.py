@@ -277,6 +277,49 @@ def classify_device_f64_pcm16(pcm, labels=None, stereo_mode: int = STEREO_CHANNE
     return labels
 
 
+def classify_ragged_f64(signal: np.ndarray, offsets, stereo_mode: int = STEREO_CHANNEL0, with_trace: bool = False, config=None):
+    """The float64 classifier on clips of different lengths in ONE call (dsp_classify_batch_ragged_host_f64 / _pcm16_host_f64): `signal`
+    is a flat host buffer -- float64 [total], int16 [total] or interleaved stereo int16 [total][2] -- and clip c is samples
+    [offsets[c], offsets[c + 1])."""
+    signal = np.ascontiguousarray(signal)
+    off, n_clips = _lib.c_offsets(offsets)
+    assert int(offsets[-1]) <= signal.shape[0]
+    labels = np.zeros(n_clips, np.int32)
+    tr = (_lib.ClassifyTraceF64 * max(n_clips, 1))() if with_trace else None
+    cfg = None if config is None else _lib.ClassifyConfigF64(*[float(v) for v in config])
+    cp = C.byref(cfg) if cfg is not None else None
+    if signal.dtype == np.int16:
+        assert signal.ndim in (1, 2)
+        _lib.check(_lib.load().dsp_classify_batch_ragged_pcm16_host_f64(cp, signal.ctypes.data, n_clips, off, signal.ndim, int(stereo_mode), labels.ctypes.data,
+                                                                         C.byref(tr) if with_trace else None), "dsp_classify_batch_ragged_pcm16_host_f64")
+    else:
+        signal = np.ascontiguousarray(signal, np.float64)
+        assert signal.ndim == 1
+        _lib.check(_lib.load().dsp_classify_batch_ragged_host_f64(cp, signal.ctypes.data, n_clips, off, labels.ctypes.data, C.byref(tr) if with_trace else None),
+                   "dsp_classify_batch_ragged_host_f64")
+    return (labels, _trace_f64(tr)[:n_clips]) if with_trace else labels
+
+
+def classify_device_ragged_f64(signal, offsets, labels=None, stereo_mode: int = STEREO_CHANNEL0, config=None):
+    """The same on a flat cuda buffer (float64 [total], int16 [total] or [total][2]) -> cuda int32 labels, stream-ordered."""
+    import torch
+    off, n_clips = _lib.c_offsets(offsets)
+    assert signal.is_cuda and signal.stride(-1) == 1 and int(offsets[-1]) <= signal.shape[0]
+    if labels is None:
+        labels = torch.empty(n_clips, dtype=torch.int32, device=signal.device)
+    st = C.c_void_p(torch.cuda.current_stream(signal.device).cuda_stream)
+    cfg = None if config is None else _lib.ClassifyConfigF64(*[float(v) for v in config])
+    cp = C.byref(cfg) if cfg is not None else None
+    if signal.dtype == torch.int16:
+        assert signal.dim() in (1, 2)
+        _lib.check(_lib.load().dsp_classify_batch_ragged_pcm16_device_f64(cp, signal.data_ptr(), n_clips, off, signal.dim(), int(stereo_mode), labels.data_ptr(), None, st),
+                   "dsp_classify_batch_ragged_pcm16_device_f64")
+    else:
+        assert signal.dtype == torch.float64 and signal.dim() == 1
+        _lib.check(_lib.load().dsp_classify_batch_ragged_device_f64(cp, signal.data_ptr(), n_clips, off, labels.data_ptr(), None, st), "dsp_classify_batch_ragged_device_f64")
+    return labels
+
+
 def classify_stats_f64(device: int = 0):
     """-> (segments, undecided, listed_clips) of the last float64 classifier pass on `device` (dsp_classify_stats_f64)."""
     a, b, c = C.c_long(), C.c_long(), C.c_long()

@@ -67,6 +67,7 @@ struct Scratch {
     long last_segments = 0;                // clips x columns of the last pass (dsp_classify_stats_f64)
     hipEvent_t done = nullptr;             // recorded behind the last call's work: the workspace is free once it has fired
     bool pending = false;
+    dsp::SpanRing spans;                   // ragged batches: the clips' spans on their way to the GPU (capi_util.hpp)
 
     void free_pass()
     {
@@ -100,6 +101,7 @@ struct Scratch {
         tab = nullptr; scr = nullptr; cu_table = nullptr;
         if (done) (void)hipEventDestroy(done);
         done = nullptr;
+        spans.release();
     }
 };
 Scratch g_w[kMaxDevices];                  // one per device: threads on different GPUs share nothing
@@ -130,20 +132,23 @@ void coefficients(dsp::IirCoefD &c_bp, dsp::IirCoefD &c_mp)
 }
 
 // one sub-batch resident at d_x (kind `in`, row stride `stride` samples): labels (+ trace) into the scratch arrays
-int run(const dsp_classify_config_f64 &cfg, Scratch &w, Pipeline pl, const void *d_x, int in, long cnt, int n, long stride, bool want_trace, hipStream_t st)
+// spans != nullptr: a ragged sub-batch (clip c at spans[c].off samples from d_x; n = the longest clip of the BATCH, total = samples in the buffer)
+int run(const dsp_classify_config_f64 &cfg, Scratch &w, Pipeline pl, const void *d_x, int in, long cnt, int n, long stride, bool want_trace, hipStream_t st,
+        const dsp::ClipSpan *spans = nullptr, long total = 0)
 {
     dsp::IirCoefD c_bp, c_mp;
     coefficients(c_bp, c_mp);
     const dsp::ClassifyRuleD rule{cfg.keep_lo, cfg.keep_hi, cfg.midpoint_db, cfg.middle_max, cfg.above_min, cfg.below_min};
     dsp::ClassifyTraceD *tr = want_trace ? w.trace : nullptr;
     w.last_segments = cnt * (long)columns(n);
+    if (spans && pl != kCkpt) return dsp::capi_fail(DSP_EINVAL, "ragged batches run on the default pipeline");
     if (pl == kCkpt) {
         const double guard = dsp::f64_threshold_guard();
-        DSP_CAPI_HIP(dsp::launch_iir2_screen_f64(d_x, in, cnt, n, stride, c_bp, c_mp, w.ck_bp, w.ck_mp, w.scr, w.U, cfg.midpoint_db, guard, w.loud, w.want, w.cu_table, st));
-        DSP_CAPI_HIP(dsp::launch_spec_f64_recheck(d_x, in, cnt, n, stride, c_mp, w.ck_mp, w.tab, w.want, cfg.midpoint_db, guard, w.loud, st));
-        DSP_CAPI_HIP(dsp::launch_classify_f64_midpoints(w.loud, cnt, n, 16000, w.mids, w.n_mids, w.hits, w.labels, tr, st, w.minmax));
-        DSP_CAPI_HIP(dsp::launch_spec_f64_listed_from_ckpt(d_x, in, cnt, n, stride, c_bp, w.ck_bp, w.tab, w.hits, w.s_bp, st, w.minmax));
-        DSP_CAPI_HIP(dsp::launch_classify_f64_bands(w.s_bp, w.hits, cnt, n, 16000, w.U, rule, w.mids, w.n_mids, w.labels, tr, st, w.minmax));
+        DSP_CAPI_HIP(dsp::launch_iir2_screen_f64(d_x, in, cnt, n, stride, c_bp, c_mp, w.ck_bp, w.ck_mp, w.scr, w.U, cfg.midpoint_db, guard, w.loud, w.want, w.cu_table, st, spans, total));
+        DSP_CAPI_HIP(dsp::launch_spec_f64_recheck(d_x, in, cnt, n, stride, c_mp, w.ck_mp, w.tab, w.want, cfg.midpoint_db, guard, w.loud, st, spans));
+        DSP_CAPI_HIP(dsp::launch_classify_f64_midpoints(w.loud, cnt, n, 16000, w.mids, w.n_mids, w.hits, w.labels, tr, st, w.minmax, spans));
+        DSP_CAPI_HIP(dsp::launch_spec_f64_listed_from_ckpt(d_x, in, cnt, n, stride, c_bp, w.ck_bp, w.tab, w.hits, w.s_bp, st, w.minmax, spans));
+        DSP_CAPI_HIP(dsp::launch_classify_f64_bands(w.s_bp, w.hits, cnt, n, 16000, w.U, rule, w.mids, w.n_mids, w.labels, tr, st, w.minmax, spans));
         return DSP_OK;
     }
     const double *xd = static_cast<const double *>(d_x);
@@ -328,6 +333,98 @@ int host_entry(const dsp_classify_config_f64 *cfgp, const void *signal, int in, 
     return DSP_OK;
 }
 
+// Ragged batches (classifier.c:286-297 reads a file of any length; its callers loop over files): offsets[n_clips + 1] (host) -> spans;
+// d_signal = the whole buffer on `device`.  Results to d_labels / d_trace (device) or labels / trace (host), whichever are given.
+int ragged(const dsp_classify_config_f64 *cfgp, const void *d_signal, int device, int in, long n_clips, const long *offsets, int *d_labels,
+           dsp_classify_trace_f64 *d_trace, int *labels, dsp_classify_trace_f64 *trace, void *stream)
+{
+    dsp_classify_config_f64 cfg;
+    if (cfgp) cfg = *cfgp; else dsp_classify_default_config_f64(&cfg);
+    if (!valid(cfg)) return dsp::capi_fail(DSP_EINVAL, "classify config: thresholds must be finite with keep_lo < keep_hi");
+    int n_max = 0;
+    for (long c = 0; c < n_clips; ++c) {
+        const long n = offsets[c + 1] - offsets[c];
+        if (offsets[c] < 0 || n < 0 || n > INT32_MAX) return dsp::capi_fail(DSP_EINVAL, "offsets must be non-negative and non-decreasing, clips shorter than 2^31 samples");
+        if (columns((int)n) > kMaxColumns) return dsp::capi_fail(DSP_EINVAL, "clip " + std::to_string(c) + " too long (more than 957 spectrogram columns = 13.4 s at 16 kHz)");
+        n_max = std::max(n_max, (int)n);
+    }
+    DSP_ON_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    if (columns(n_max) == 0) {                 // no clip holds a segment: no midpoints, label 0
+        if (d_labels) DSP_CAPI_HIP(hipMemsetAsync(d_labels, 0, (size_t)n_clips * sizeof(int), st));
+        if (d_trace) DSP_CAPI_HIP(hipMemsetAsync(d_trace, 0, (size_t)n_clips * sizeof(dsp_classify_trace_f64), st));
+        if (labels) for (long c = 0; c < n_clips; ++c) labels[c] = 0;
+        if (trace) for (long c = 0; c < n_clips; ++c) trace[c] = dsp_classify_trace_f64{};
+        return DSP_OK;
+    }
+    Scratch &w = g_w[device];
+    std::lock_guard<std::mutex> lock(w.mu);
+    const long kSubBatch = sub_batch(kCkpt);
+    int rc = reserve(w, device, kCkpt, std::min(kSubBatch, n_clips), n_max, 0);
+    if (rc < 0) return rc;
+    dsp::SpanRing::Slot *slot = nullptr;
+    DSP_CAPI_HIP(w.spans.acquire((size_t)n_clips * sizeof(dsp::ClipSpan), &slot));
+    dsp::ClipSpan *h = static_cast<dsp::ClipSpan *>(slot->h);
+    for (long c = 0; c < n_clips; ++c) h[c] = dsp::ClipSpan{offsets[c], (int)(offsets[c + 1] - offsets[c]), columns((int)(offsets[c + 1] - offsets[c]))};
+    if (w.pending) DSP_CAPI_HIP(hipStreamWaitEvent(st, w.done, 0));
+    DSP_CAPI_HIP(dsp::SpanRing::upload(slot, (size_t)n_clips * sizeof(dsp::ClipSpan), st));
+    struct SlotMark { dsp::SpanRing::Slot *s; hipStream_t st; ~SlotMark() { dsp::SpanRing::mark(s, st); } } slot_mark{slot, st};
+    BusyMark mark{w, st};
+    const dsp::ClipSpan *d_spans = static_cast<const dsp::ClipSpan *>(slot->d);
+    const bool want_trace = d_trace != nullptr || trace != nullptr;
+    for (long c0 = 0; c0 < n_clips; c0 += kSubBatch) {
+        const long cnt = std::min(kSubBatch, n_clips - c0);
+        if ((rc = run(cfg, w, kCkpt, d_signal, in, cnt, n_max, 0, want_trace, st, d_spans + c0, offsets[n_clips])) < 0) return rc;
+        if (d_labels) DSP_CAPI_HIP(hipMemcpyAsync(d_labels + c0, w.labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, st));
+        if (d_trace) DSP_CAPI_HIP(hipMemcpyAsync(d_trace + c0, w.trace, (size_t)cnt * sizeof(dsp_classify_trace_f64), hipMemcpyDeviceToDevice, st));
+        if (labels) DSP_CAPI_HIP(hipMemcpyAsync(labels + c0, w.labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (trace) DSP_CAPI_HIP(hipMemcpyAsync(trace + c0, w.trace, (size_t)cnt * sizeof(dsp_classify_trace_f64), hipMemcpyDeviceToHost, st));
+        if (labels || trace) DSP_CAPI_HIP(hipStreamSynchronize(st));
+    }
+    return DSP_OK;
+}
+
+int ragged_device_entry(const dsp_classify_config_f64 *cfgp, const void *d_signal, int in, long n_clips, const long *offsets, int *d_labels,
+                        dsp_classify_trace_f64 *d_trace, void *stream)
+{
+    if (!d_signal || !d_labels || !offsets || n_clips < 0) return dsp::capi_fail(DSP_EINVAL, "bad argument");
+    if (n_clips == 0) return DSP_OK;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, d_signal) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return dsp::capi_fail(DSP_EINVAL, "signal is not a device pointer");
+    }
+    if (attr.device < 0 || attr.device >= kMaxDevices) return dsp::capi_fail(DSP_EINVAL, "device index out of range");
+    return ragged(cfgp, d_signal, attr.device, in, n_clips, offsets, d_labels, d_trace, nullptr, nullptr, stream);
+}
+
+int ragged_host_entry(const dsp_classify_config_f64 *cfgp, const void *signal, int in, long n_clips, const long *offsets, int *labels, dsp_classify_trace_f64 *trace)
+{
+    if (!signal || !labels || !offsets || n_clips < 0) return dsp::capi_fail(DSP_EINVAL, "bad argument");
+    if (n_clips == 0) return DSP_OK;
+    if (offsets[n_clips] < offsets[0] || offsets[0] < 0) return dsp::capi_fail(DSP_EINVAL, "offsets must be non-negative and non-decreasing, clips shorter than 2^31 samples");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return dsp::capi_fail(DSP_ENODEV, "no HIP device: libdsp_amd has no CPU fallback");
+    const char *dev = std::getenv("DSP_AMD_DEVICE");
+    const int device = dev ? std::atoi(dev) : 0;
+    if (device < 0 || device >= count || device >= kMaxDevices) return dsp::capi_fail(DSP_EINVAL, "device index out of range");
+    void *d_flat = nullptr;
+    const size_t bytes = (size_t)offsets[n_clips] * in_bytes(in);
+    {
+        DSP_ON_DEVICE(device);
+        DSP_CAPI_HIP(hipMalloc(&d_flat, bytes + 16));
+        const hipError_t e = hipMemcpy(d_flat, signal, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d_flat); DSP_CAPI_HIP(e); }
+    }
+    const int rc = ragged(cfgp, d_flat, device, in, n_clips, offsets, nullptr, nullptr, labels, trace, nullptr);
+    {
+        dsp::DeviceScope on(device);
+        (void)hipStreamSynchronize(nullptr);
+        (void)hipFree(d_flat);
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -364,6 +461,34 @@ int dsp_classify_batch_pcm16_host_f64(const dsp_classify_config_f64 *cfgp, const
     int in = 0;
     const int rc = input_kind(channels, stereo_mode, in);
     return rc < 0 ? rc : host_entry(cfgp, pcm, in, n_clips, n, stride, labels, trace);
+}
+
+int dsp_classify_batch_ragged_device_f64(const dsp_classify_config_f64 *cfgp, const double *d_signal, long n_clips, const long *offsets, int *d_labels,
+                                         dsp_classify_trace_f64 *d_trace, void *stream)
+{
+    return ragged_device_entry(cfgp, d_signal, 0, n_clips, offsets, d_labels, d_trace, stream);
+}
+
+int dsp_classify_batch_ragged_pcm16_device_f64(const dsp_classify_config_f64 *cfgp, const int16_t *d_pcm, long n_clips, const long *offsets, int channels,
+                                               int stereo_mode, int *d_labels, dsp_classify_trace_f64 *d_trace, void *stream)
+{
+    int in = 0;
+    const int rc = input_kind(channels, stereo_mode, in);
+    return rc < 0 ? rc : ragged_device_entry(cfgp, d_pcm, in, n_clips, offsets, d_labels, d_trace, stream);
+}
+
+int dsp_classify_batch_ragged_host_f64(const dsp_classify_config_f64 *cfgp, const double *signal, long n_clips, const long *offsets, int *labels,
+                                       dsp_classify_trace_f64 *trace)
+{
+    return ragged_host_entry(cfgp, signal, 0, n_clips, offsets, labels, trace);
+}
+
+int dsp_classify_batch_ragged_pcm16_host_f64(const dsp_classify_config_f64 *cfgp, const int16_t *pcm, long n_clips, const long *offsets, int channels,
+                                             int stereo_mode, int *labels, dsp_classify_trace_f64 *trace)
+{
+    int in = 0;
+    const int rc = input_kind(channels, stereo_mode, in);
+    return rc < 0 ? rc : ragged_host_entry(cfgp, pcm, in, n_clips, offsets, labels, trace);
 }
 
 int dsp_classify_stats_f64(int device, long *segments, long *undecided, long *listed_clips)

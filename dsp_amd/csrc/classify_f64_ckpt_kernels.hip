@@ -126,12 +126,18 @@ __device__ __forceinline__ double sample_at(const void *__restrict__ x, long idx
 // =====================================================================================================================================
 // pass 1: recurrences, restart states, screening
 // =====================================================================================================================================
-template <int IN, bool EVEN_B, bool VEC>
-__global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void iir2_screen_f64_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T, const IirCoefD c_bp,
+// RAGGED (clips of different lengths; spans[clip] = start, samples, segments): T_row is the row length of loud / the restart states
+// (the longest clip's segment count), a block walks as many tiles as ITS longest clip has, and a lane stops keeping restart states and
+// verdicts at its own clip's last segment; what it computes past that point (the next clip's samples; the last piece of the buffer
+// again past its end) is never looked at.  Rows start anywhere: the 16-byte loads go out unaligned.
+template <int IN, bool EVEN_B, bool VEC, bool RAGGED = false>
+__global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3))) void iir2_screen_f64_kernel(const void *__restrict__ xin, long n_clips, int n, long stride, int T_row, const IirCoefD c_bp,
                                                                       const IirCoefD c_mp, double *__restrict__ ck_bp, double *__restrict__ ck_mp,
                                                                       const ScreenTablesD *__restrict__ tab, int *__restrict__ loud, int *__restrict__ want,
-                                                                      float thr_u, float guard, int *__restrict__ cu_table)
+                                                                      float thr_u, float guard, int *__restrict__ cu_table,
+                                                                      const ClipSpan *__restrict__ spans = nullptr, long total = 0)
 {
+    static_assert(!RAGGED || VEC, "ragged batches use the piece loads");
     __shared__ __attribute__((aligned(16))) double tin[2][64 * SC_XLD];                 // x tiles as doubles, [tile parity]
     __shared__ __attribute__((aligned(16))) double vbuf[2][64 * SC_XLD];                // v tiles of the 1000-3000 Hz filter
     __shared__ __attribute__((aligned(16))) unsigned char ybuf[SC_RING][64 * SC_YROW];  // its output as bf16, [tile mod 4][clip][16 samples]
@@ -195,6 +201,21 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 #endif
     const long clip0 = (long)blockIdx.x * 64;
     const int rows = (int)((n_clips - clip0) < 64 ? (n_clips - clip0) : 64);
+    __shared__ long s_base[RAGGED ? 64 : 1];
+    __shared__ int s_T[RAGGED ? 64 : 1], s_Tmax;
+    int T = T_row, my_T = T_row;                          // RAGGED: segments this block walks / of this lane's clip
+    if (RAGGED) {
+        if (threadIdx.x == 0) s_Tmax = 1;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            ClipSpan sp{0, 0, 0};
+            if ((int)threadIdx.x < rows) sp = spans[clip0 + threadIdx.x];
+            s_base[threadIdx.x] = sp.off; s_T[threadIdx.x] = sp.frames;
+            atomicMax(&s_Tmax, sp.frames);
+        }
+        __syncthreads();
+        T = s_Tmax; my_T = s_T[lane];
+    }
     const int n_tiles = (T - 1) * kTilesPerHop + kTilesPerSeg;           // samples past the last whole segment reach no output
     if (threadIdx.x < 64) {
         f_state[threadIdx.x] = 0u; f_sum[threadIdx.x] = 0.0f;
@@ -238,6 +259,11 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         for (int k = 0; k < LD_PER; ++k) {
             int r = (ltid >> 3) + 16 * k;
             r = r < rows ? r : rows - 1;
+            if (RAGGED) {
+                long idx = s_base[r] + (long)L * LT + (long)c * PP;
+                idx = idx < total - PP ? idx : total - PP;      // (past the buffer's end: its last whole piece again)
+                dst[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(xin) + idx * In<IN>::kBytes));
+            } else
             dst[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(xin) + ((clip0 + r) * stride + s0) * In<IN>::kBytes));
         }
     };
@@ -271,7 +297,8 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
         // (the fetch is issued whether or not its tile exists -- past the end it re-reads the rows' last pieces: a fetch under a run-time
         // condition makes the number of younger loads unknown to the compiler, which then waits for all of them)
         const bool live = cs < n_tiles, used_up = cs % KT == KT - 1;
-        switch (KT == 1 ? slot_hint : L % LD_DEPTH) {
+        (void)L;
+        switch (slot_hint) {
         case 0: if (live) commit(raw[0], cs, ltid); if (used_up) fetch(raw[0], L + LD_DEPTH, ltid); break;
         case 1: if (live) commit(raw[1], cs, ltid); if (used_up) fetch(raw[1], L + LD_DEPTH, ltid); break;
         default: if (live) commit(raw[LD_DEPTH - 1], cs, ltid); if (used_up) fetch(raw[LD_DEPTH - 1], L + LD_DEPTH, ltid); break;
@@ -285,7 +312,10 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 
     // Each role runs its own loop over the steps with ONE barrier per step (every wave of the block executes the same number of
     // barriers; the branch is wave-uniform): the compiler then allocates registers for the largest role, not for the sum of their states.
-    const int n_steps = (n_tiles + 3 + LD_DEPTH - 1) / LD_DEPTH * LD_DEPTH;     // (padded: the last steps only meet at the barrier)
+    // (round 4: int16 input too -- its slot changes every KT steps, so the loops are unrolled LD_DEPTH * KT times; behind the run-time switch
+    // it kept, the int16 kernel was the slower one, 2.45 against 2.18 ms, with a quarter of the bytes)
+    constexpr int UF = LD_DEPTH * KT;                     // steps after which the queue's slot pattern repeats
+    const int n_steps = (n_tiles + 3 + UF - 1) / UF * UF;                       // (padded: the last steps only meet at the barrier)
     if ((SC_ROLES & 1) && wv < 2) {
         // ================= recurrence waves: tile s at step s =================
         const IirCoefD &c = wv == 0 ? c_bp : c_mp;
@@ -303,7 +333,7 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                 const int seg = s / kTilesPerHop, p = s - seg * kTilesPerHop;
                 // restart states: offsets 0, 64, 128, 192 of segment seg (tiles 14 seg + {0, 4, 8, 12}; the last two tiles of a
                 // segment are the first two of the next)
-                if (p % kCkStep == 0 && seg < T && lane < rows) {
+                if (p % kCkStep == 0 && seg < my_T && lane < rows) {
                     d2 *dst = reinterpret_cast<d2 *>(ck + (((long)seg * kCkPerSegF64 + p / kCkStep) * n_clips + clip0 + lane) * 8);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) dst[j] = d2{d[2 * j], d[2 * j + 1]};      // (plain stores: the four 16-byte pieces of a lane's 64 bytes meet in L2; as nt stores they reached HBM as partial lines, 1.7 x the bytes)
@@ -332,9 +362,9 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
             __syncthreads();
         };
         // whole groups of LD_DEPTH steps, no condition between the copies (a copy that may be skipped makes its fetch conditional again)
-        for (int s0 = 0; s0 < n_steps; s0 += LD_DEPTH) {
+        for (int s0 = 0; s0 < n_steps; s0 += UF) {
 #pragma unroll
-            for (int u = 0; u < LD_DEPTH; ++u) step(s0 + u, (u + 1) % LD_DEPTH);
+            for (int u = 0; u < UF; ++u) step(s0 + u, ((u + 1) / KT) % LD_DEPTH);      // the slot of load tile (s + 1) / KT
         }
         SC_DIAG_WRITE();
     } else if ((SC_ROLES & 6) && wv >= 2) {
@@ -380,8 +410,8 @@ __global__ __launch_bounds__(SC_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
                     const float low = root > 0.f ? root * root : 0.f;   // the computed bins hold at least this much of 256 E
                     if (!(f_e[lane_o] - low < thr_u * (1.0f - guard) * 0.9999f)) st = 1u;      // a bin that was not computed could reach the threshold
                 }
-                if (lane_o < rows) {
-                    const long fr = (clip0 + lane_o) * T + pending_seg;
+                if (lane_o < rows && (!RAGGED || pending_seg < s_T[lane_o])) {
+                    const long fr = (clip0 + lane_o) * T_row + pending_seg;
                     loud[fr] = st == 2u ? 1 : (st == 1u ? 2 : 0);
                     if (st == 1u) want[1 + atomicAdd(want, 1)] = (int)fr;
                 }
@@ -563,8 +593,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                                  const double *__restrict__ ck, const SpecTablesD *__restrict__ tab,
                                                                  const int *__restrict__ worklist, double *__restrict__ sxx, int *__restrict__ loud,
                                                                  double mid_power, double midpoint_db, double guard, int vec_ok,
-                                                                 unsigned long long *__restrict__ minmax)
+                                                                 unsigned long long *__restrict__ minmax, const ClipSpan *__restrict__ spans = nullptr)
 {
+    // spans (ragged batches): clip c starts at spans[c].off; T stays the row length of the work lists and maps.  MAPS walks T slots per
+    // listed clip: the slots past a clip's last segment take that last segment again (the same values to the same places).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // [wave] rows[8][RC_ROW_LD] doubles, then the twiddles
     double *rows_all = reinterpret_cast<double *>(smem);
@@ -583,9 +615,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (wave * RC_FRAMES >= total) return;
     // (clip, t) of work item `it`
     auto item_of = [&](long it, long &clip, int &t) {
-        if (MAPS) { const long e = it / T; t = (int)(it - e * T); clip = worklist[1 + e]; }
+        if (MAPS) { const long e = it / T; t = (int)(it - e * T); clip = worklist[1 + e]; if (spans) { const int tc = spans[clip].frames; t = t < tc ? t : tc - 1; } }
         else { const long fr = worklist[1 + it]; clip = fr / T; t = (int)(fr - clip * T); }
     };
+    auto base_of = [&](long clip) { return spans ? spans[clip].off : clip * stride; };
     // A pass's input -- 16 segments of 256 samples as 16-byte pieces, coalesced (a segment is contiguous), and the restart state of
     // (item f, quarter j) -- is requested one pass AHEAD into registers: with one wave per SIMD (the rows fill the LDS) nothing else
     // hides the HBM latency, and four dependent load batches per pass were a quarter of this kernel's time.  Every load is
@@ -605,7 +638,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 long clip; int t;
                 item_of(it, clip, t);
                 const long s0 = (long)t * kSpecHop + (long)piece * PP;
-                q[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(xin) + (clip * stride + s0) * In<IN>::kBytes));
+                q[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(xin) + (base_of(clip) + s0) * In<IN>::kBytes));
             }
         }
         long it = item0 + f;
@@ -629,7 +662,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 it = it < total ? it : total - 1;
                 long clip; int t;
                 item_of(it, clip, t);
-                const void *row = reinterpret_cast<const unsigned char *>(xin) + clip * stride * In<IN>::kBytes;
+                const void *row = reinterpret_cast<const unsigned char *>(xin) + base_of(clip) * In<IN>::kBytes;
                 const long s0 = (long)t * kSpecHop + (long)piece * PP;
 #pragma unroll
                 for (int jj = 0; jj < PP; ++jj) o[jj] = sample_at<IN>(row, s0 + jj);
@@ -837,7 +870,7 @@ int f64_screen_blocks_per_pass()
 template <int IN>
 static hipError_t launch_screen_in(const void *x, long n_clips, int n, long stride, const IirCoefD &c_bp, const IirCoefD &c_mp, double *ck_bp,
                                    double *ck_mp, const ScreenTablesD *tables, double U, double midpoint_db, double guard, int *loud, int *want,
-                                   int *cu_table, hipStream_t stream)
+                                   int *cu_table, hipStream_t stream, const ClipSpan *spans, long total)
 {
     const int T = columns_of(n);
     const int blocks = (int)((n_clips + 63) / 64);
@@ -848,6 +881,12 @@ static hipError_t launch_screen_in(const void *x, long n_clips, int n, long stri
 #define DSP_SC_LAUNCH(E, V)                                                                                                                      \
     hipLaunchKernelGGL((iir2_screen_f64_kernel<IN, E, V>), dim3(blocks), dim3(SC_THREADS), 0, stream, x, n_clips, n, stride, T, c_bp, c_mp, ck_bp, \
                        ck_mp, tables, loud, want, thr_u, g, cu_table)
+    if (spans) {                  // ragged batches: the designed (even-tap) numerators, unaligned piece loads
+        if (!even || total < In<IN>::kPerPiece) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((iir2_screen_f64_kernel<IN, true, true, true>), dim3(blocks), dim3(SC_THREADS), 0, stream, x, n_clips, n, stride, T, c_bp, c_mp, ck_bp,
+                           ck_mp, tables, loud, want, thr_u, g, cu_table, spans, total);
+        return hipGetLastError();
+    }
     if (even && vec) DSP_SC_LAUNCH(true, true);
     else if (even) DSP_SC_LAUNCH(true, false);
     else if (vec) DSP_SC_LAUNCH(false, true);
@@ -858,7 +897,7 @@ static hipError_t launch_screen_in(const void *x, long n_clips, int n, long stri
 
 hipError_t launch_iir2_screen_f64(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const IirCoefD &c_mp,
                                   double *ck_bp, double *ck_mp, const ScreenTablesD *tables, double U, double midpoint_db, double guard,
-                                  int *loud, int *want, int *cu_table, hipStream_t stream)
+                                  int *loud, int *want, int *cu_table, hipStream_t stream, const ClipSpan *spans, long total)
 {
     const int T = columns_of(n);
     if (n_clips <= 0 || T <= 0) return hipSuccess;
@@ -871,10 +910,10 @@ hipError_t launch_iir2_screen_f64(const void *x, int in_kind, long n_clips, int 
     if (!spread) cu_table = nullptr;
     if (cu_table && (e = hipMemsetAsync(cu_table, 0, sizeof(int) * kSimdLoadCus, stream)) != hipSuccess) return e;
     switch (in_kind) {
-    case 0: return launch_screen_in<0>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream);
-    case 1: return launch_screen_in<1>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream);
-    case 2: return launch_screen_in<2>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream);
-    case 3: return launch_screen_in<3>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream);
+    case 0: return launch_screen_in<0>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream, spans, total);
+    case 1: return launch_screen_in<1>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream, spans, total);
+    case 2: return launch_screen_in<2>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream, spans, total);
+    case 3: return launch_screen_in<3>(x, n_clips, n, stride, c_bp, c_mp, ck_bp, ck_mp, tables, U, midpoint_db, guard, loud, want, cu_table, stream, spans, total);
     default: return hipErrorInvalidValue;
     }
 }
@@ -885,7 +924,7 @@ constexpr size_t kRcSmem = (size_t)4 * RC_FRAMES * RC_ROW_LD * sizeof(double) + 
 
 template <bool MAPS, int IN, bool EVEN_B>
 hipError_t launch_rc(const void *x, long n_clips, int n, long stride, const IirCoefD &c, const double *ck, const SpecTablesD *tab, const int *worklist,
-                     double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream, unsigned long long *minmax)
+                     double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream, unsigned long long *minmax, const ClipSpan *spans)
 {
     auto kernel = spec_f64_from_ckpt_kernel<MAPS, IN, EVEN_B>;
     static bool attr_set[64] = {false};
@@ -902,28 +941,28 @@ hipError_t launch_rc(const void *x, long n_clips, int n, long stride, const IirC
     const long max_items = n_clips * (long)T;                            // the bound: the list's count is read on the device
     const long blocks = std::min<long>((max_items + 4 * RC_FRAMES - 1) / (4 * RC_FRAMES), resident[dev]);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), kRcSmem, stream, x, n_clips, n, stride, T, c, ck, tab, worklist, sxx, loud, mid_power,
-                       midpoint_db, guard, (int)rows_vec_ok<IN>(x, stride), minmax);
+                       midpoint_db, guard, spans ? 1 : (int)rows_vec_ok<IN>(x, stride), minmax, spans);
     return hipGetLastError();
 }
 
 template <bool MAPS, int IN>
 hipError_t launch_rc_b(const void *x, long n_clips, int n, long stride, const IirCoefD &c, const double *ck, const SpecTablesD *tab, const int *worklist,
-                       double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream, unsigned long long *minmax)
+                       double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream, unsigned long long *minmax, const ClipSpan *spans)
 {
-    return even_taps_only(c) ? launch_rc<MAPS, IN, true>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax)
-                             : launch_rc<MAPS, IN, false>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax);
+    return even_taps_only(c) ? launch_rc<MAPS, IN, true>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax, spans)
+                             : launch_rc<MAPS, IN, false>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax, spans);
 }
 
 template <bool MAPS>
 hipError_t launch_rc_k(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c, const double *ck, const SpecTablesD *tab,
                        const int *worklist, double *sxx, int *loud, double mid_power, double midpoint_db, double guard, hipStream_t stream,
-                       unsigned long long *minmax = nullptr)
+                       unsigned long long *minmax = nullptr, const ClipSpan *spans = nullptr)
 {
     switch (in_kind) {
-    case 0: return launch_rc_b<MAPS, 0>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax);
-    case 1: return launch_rc_b<MAPS, 1>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax);
-    case 2: return launch_rc_b<MAPS, 2>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax);
-    case 3: return launch_rc_b<MAPS, 3>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax);
+    case 0: return launch_rc_b<MAPS, 0>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax, spans);
+    case 1: return launch_rc_b<MAPS, 1>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax, spans);
+    case 2: return launch_rc_b<MAPS, 2>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax, spans);
+    case 3: return launch_rc_b<MAPS, 3>(x, n_clips, n, stride, c, ck, tab, worklist, sxx, loud, mid_power, midpoint_db, guard, stream, minmax, spans);
     default: return hipErrorInvalidValue;
     }
 }
@@ -931,18 +970,18 @@ hipError_t launch_rc_k(const void *x, int in_kind, long n_clips, int n, long str
 }  // namespace
 
 hipError_t launch_spec_f64_recheck(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_mp, const double *ck_mp,
-                                   const SpecTablesD *tables, const int *want, double midpoint_db, double guard, int *loud, hipStream_t stream)
+                                   const SpecTablesD *tables, const int *want, double midpoint_db, double guard, int *loud, hipStream_t stream, const ClipSpan *spans)
 {
     if (n_clips <= 0 || columns_of(n) <= 0) return hipSuccess;
     const double mid_power = 1e-12 * std::pow(10.0, midpoint_db / 10.0);
-    return launch_rc_k<false>(x, in_kind, n_clips, n, stride, c_mp, ck_mp, tables, want, nullptr, loud, mid_power, midpoint_db, guard, stream);
+    return launch_rc_k<false>(x, in_kind, n_clips, n, stride, c_mp, ck_mp, tables, want, nullptr, loud, mid_power, midpoint_db, guard, stream, nullptr, spans);
 }
 
 hipError_t launch_spec_f64_listed_from_ckpt(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const double *ck_bp,
-                                            const SpecTablesD *tables, const int *hits, double *sxx, hipStream_t stream, unsigned long long *minmax)
+                                            const SpecTablesD *tables, const int *hits, double *sxx, hipStream_t stream, unsigned long long *minmax, const ClipSpan *spans)
 {
     if (n_clips <= 0 || columns_of(n) <= 0) return hipSuccess;
-    return launch_rc_k<true>(x, in_kind, n_clips, n, stride, c_bp, ck_bp, tables, hits, sxx, nullptr, 0.0, 0.0, 0.0, stream, minmax);
+    return launch_rc_k<true>(x, in_kind, n_clips, n, stride, c_bp, ck_bp, tables, hits, sxx, nullptr, 0.0, 0.0, 0.0, stream, minmax, spans);
 }
 
 }  // namespace dsp

@@ -442,8 +442,10 @@ __global__ __launch_bounds__(256) void classify_f64_tail_kernel(const double *__
 // results do not depend on it), mids[clip][] / n_mids[clip] carry them to classify_f64_bands_kernel; the others are label 0.
 __global__ __launch_bounds__(256) void classify_f64_midpoints_kernel(const int *__restrict__ loud, long n_clips, int T, int fs, double *__restrict__ mids,
                                                                      int *__restrict__ n_mids, int *__restrict__ hits, int *__restrict__ labels,
-                                                                     ClassifyTraceD *__restrict__ trace, unsigned long long *__restrict__ minmax)
+                                                                     ClassifyTraceD *__restrict__ trace, unsigned long long *__restrict__ minmax,
+                                                                     const ClipSpan *__restrict__ spans = nullptr)
 {
+    // spans (ragged batches): clip c has spans[c].frames columns, the head of its row of T
     __shared__ double times[kMaxColsF64];
     for (int j = threadIdx.x; j < T; j += 256) times[j] = column_time(j, fs);
     __syncthreads();
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256) void classify_f64_midpoints_kernel(const int *
     if (clip >= n_clips) return;
     const int *fl = loud + clip * T;
     double *m = mids + clip * kMaxMidpoints;
-    const int n_mid = cluster_midpoints([&](int j) { return fl[j] != 0; }, times, T, m);
+    const int n_mid = cluster_midpoints([&](int j) { return fl[j] != 0; }, times, spans ? spans[clip].frames : T, m);
     n_mids[clip] = n_mid;
     if (trace) {
         ClassifyTraceD *tr = trace + clip;
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(256) void classify_f64_midpoints_kernel(const int *
 __global__ __launch_bounds__(256) void classify_f64_bands_kernel(const double *__restrict__ sxx, const int *__restrict__ hits, int T, int fs, double U,
                                                                  ClassifyRuleD rule, BandRows bands, const double *__restrict__ mids_all,
                                                                  const int *__restrict__ n_mids, int *__restrict__ labels, ClassifyTraceD *__restrict__ trace,
-                                                                 const unsigned long long *__restrict__ minmax)
+                                                                 const unsigned long long *__restrict__ minmax, const ClipSpan *__restrict__ spans = nullptr)
 {
     __shared__ double times[kMaxColsF64];
     __shared__ double mids[kMaxMidpoints];
@@ -487,7 +489,8 @@ __global__ __launch_bounds__(256) void classify_f64_bands_kernel(const double *_
         __syncthreads();                                                     // times[] written; the previous entry's mids[] read
         if (tid < n_mid) mids[tid] = mids_all[clip * kMaxMidpoints + tid];
         __syncthreads();
-        const int label = band_sums_and_rule<true>(sxx + (long)e * T * kSpecBins, T, rule, bands, times, mids, n_mid, trace ? trace + clip : nullptr, sh, U,
+        // (ragged batches: the clip's map is the first spans[clip].frames rows of its T)
+        const int label = band_sums_and_rule<true>(sxx + (long)e * T * kSpecBins, spans ? spans[clip].frames : T, rule, bands, times, mids, n_mid, trace ? trace + clip : nullptr, sh, U,
                                                        minmax ? minmax + 2 * clip : nullptr);
         if (tid == 0) labels[clip] = label;
     }
@@ -506,7 +509,7 @@ hipError_t launch_classify_f64_tail(const double *sxx_bp, const double *sxx_mp, 
 }
 
 hipError_t launch_classify_f64_midpoints(const int *loud, long n_clips, int n, int fs, double *mids, int *n_mids, int *hits, int *labels,
-                                         ClassifyTraceD *trace, hipStream_t stream, unsigned long long *minmax)
+                                         ClassifyTraceD *trace, hipStream_t stream, unsigned long long *minmax, const ClipSpan *spans)
 {
     const int T = columns_of(n);
     if (n_clips <= 0) return hipSuccess;
@@ -514,12 +517,12 @@ hipError_t launch_classify_f64_midpoints(const int *loud, long n_clips, int n, i
     hipError_t e = hipMemsetAsync(hits, 0, sizeof(int), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(classify_f64_midpoints_kernel, dim3((unsigned)((n_clips + 255) / 256)), dim3(256), 0, stream, loud, n_clips, T, fs, mids, n_mids,
-                       hits, labels, trace, minmax);
+                       hits, labels, trace, minmax, spans);
     return hipGetLastError();
 }
 
 hipError_t launch_classify_f64_bands(const double *sxx, const int *hits, long n_clips, int n, int fs, double U, const ClassifyRuleD &rule, const double *mids,
-                                     const int *n_mids, int *labels, ClassifyTraceD *trace, hipStream_t stream, const unsigned long long *minmax)
+                                     const int *n_mids, int *labels, ClassifyTraceD *trace, hipStream_t stream, const unsigned long long *minmax, const ClipSpan *spans)
 {
     const int T = columns_of(n);
     if (n_clips <= 0) return hipSuccess;
@@ -527,7 +530,7 @@ hipError_t launch_classify_f64_bands(const double *sxx, const int *hits, long n_
     static int cache[64] = {0};
     const int resident = resident_blocks_of(classify_f64_bands_kernel, cache);
     const long blocks = std::min<long>(n_clips, 4L * resident);              // the bound: the list's count is read on the device
-    hipLaunchKernelGGL(classify_f64_bands_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, sxx, hits, T, fs, U, rule, band_rows(fs), mids, n_mids, labels, trace, minmax);
+    hipLaunchKernelGGL(classify_f64_bands_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, sxx, hits, T, fs, U, rule, band_rows(fs), mids, n_mids, labels, trace, minmax, spans);
     return hipGetLastError();
 }
 

@@ -180,10 +180,11 @@ hipError_t launch_spectrogram_f64_listed(const double *y, long n_clips, int n, l
 // smallest / largest positive cell of each listed clip's map there (double bits, atomicMin / atomicMax) and launch_classify_f64_bands reads
 // them instead of scanning the map
 hipError_t launch_classify_f64_midpoints(const int *loud, long n_clips, int n, int fs, double *mids, int *n_mids, int *hits, int *labels,
-                                         ClassifyTraceD *trace, hipStream_t stream, unsigned long long *minmax = nullptr);
+                                         ClassifyTraceD *trace, hipStream_t stream, unsigned long long *minmax = nullptr, const ClipSpan *spans = nullptr);
 // band sums and rule (:105-190) of the listed clips over their frame-major U * PSD maps: labels[c], trace sums
 hipError_t launch_classify_f64_bands(const double *sxx, const int *hits, long n_clips, int n, int fs, double U, const ClassifyRuleD &rule, const double *mids,
-                                     const int *n_mids, int *labels, ClassifyTraceD *trace, hipStream_t stream, const unsigned long long *minmax = nullptr);
+                                     const int *n_mids, int *labels, ClassifyTraceD *trace, hipStream_t stream, const unsigned long long *minmax = nullptr,
+                                     const ClipSpan *spans = nullptr);
 // the whole tail in one kernel per clip over [c][129][T] float64 PSD maps of the 3000-7500 Hz / 1000-3000 Hz filtered clips
 // (launch_spectrogram_f64): labels[c] = the rule's verdict (classifier.c:184), trace (optional): midpoints and band sums per clip
 hipError_t launch_classify_f64_tail(const double *sxx_bp, const double *sxx_mp, long n_clips, int n, int fs, const ClassifyRuleD &rule,
@@ -212,13 +213,17 @@ bool build_screen_tables_f64(const SpecTablesD &spec, int fs, ScreenTablesD &t);
 int f64_screen_blocks_per_pass();
 hipError_t launch_iir2_screen_f64(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const IirCoefD &c_mp,
                                   double *ck_bp, double *ck_mp, const ScreenTablesD *tables, double U, double midpoint_db, double guard,
-                                  int *loud, int *want, int *cu_table, hipStream_t stream);
+                                  int *loud, int *want, int *cu_table, hipStream_t stream, const ClipSpan *spans = nullptr, long total = 0);
+// (spans != nullptr, here and below: a ragged batch -- clip c at spans[c].off samples from x with spans[c].frames segments; n = the longest
+// clip, whose segment count is the row length of loud / the restart states / the maps; total = samples in the buffer)
 // the float64 verdict on the listed (undecided) segments, recomputed from ck_mp: loud[frame] = 0 / 1
 hipError_t launch_spec_f64_recheck(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_mp, const double *ck_mp,
-                                   const SpecTablesD *tables, const int *want, double midpoint_db, double guard, int *loud, hipStream_t stream);
+                                   const SpecTablesD *tables, const int *want, double midpoint_db, double guard, int *loud, hipStream_t stream,
+                                   const ClipSpan *spans = nullptr);
 // sxx[entry][t][129] = U * PSD of the 3000-7500 Hz output of the clips on the work list hits, recomputed from ck_bp
 hipError_t launch_spec_f64_listed_from_ckpt(const void *x, int in_kind, long n_clips, int n, long stride, const IirCoefD &c_bp, const double *ck_bp,
-                                            const SpecTablesD *tables, const int *hits, double *sxx, hipStream_t stream, unsigned long long *minmax = nullptr);
+                                            const SpecTablesD *tables, const int *hits, double *sxx, hipStream_t stream, unsigned long long *minmax = nullptr,
+                                            const ClipSpan *spans = nullptr);
 // DSP_AMD_F64_GUARD (read per call; tests): the half-width of the band around the threshold inside which the reference's own expression
 // decides, default 2e-9
 double f64_threshold_guard();

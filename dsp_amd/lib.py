@@ -96,6 +96,7 @@ SYMBOLS = [
     "dsp_mfcc_default_config", "dsp_mfcc_scrubjay_infer_config", "dsp_mfcc_plan_create", "dsp_mfcc_plan_destroy", "dsp_mfcc_plan_config",
     "dsp_mfcc_frames_for", "dsp_mfcc_frames_device", "dsp_mfcc_clips_device", "dsp_mfcc_frames_host",
     "dsp_mfcc_clips_host", "dsp_mfcc_clips_pcm16_device", "dsp_mfcc_plan_set_launch", "dsp_mfcc_plan_set_kernel", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables", "dsp_prefilter_scan_check",
+    "dsp_classify_batch_ragged_device_f64", "dsp_classify_batch_ragged_pcm16_device_f64", "dsp_classify_batch_ragged_host_f64", "dsp_classify_batch_ragged_pcm16_host_f64",
     "dsp_classify_batch_ragged_device", "dsp_classify_batch_ragged_pcm16_device", "dsp_classify_batch_ragged_host", "dsp_classify_batch_ragged_pcm16_host",
     "dsp_scrubjay_fused_ragged_device", "dsp_scrubjay_fused_ragged_pcm16_device", "dsp_classify_signal_batch_ragged_device", "dsp_classify_signal_batch_ragged_pcm16_device",
     "dsp_scrubjay_fused_device", "dsp_scrubjay_fused_pcm16_device", "dsp_classify_signal_batch_pcm16_device", "dsp_stop_model_create", "dsp_stop_model_destroy", "dsp_stop_predict_device", "dsp_classify_signal_batch_device",
@@ -181,6 +182,10 @@ def load() -> C.CDLL:
     L.dsp_scrubjay_fused_device.argtypes = [vp, vp, vp, C.c_long, ip, C.c_long, ip, vp, vp, vp, vp, vp]; L.dsp_scrubjay_fused_device.restype = ip
     L.dsp_scrubjay_fused_pcm16_device.argtypes = [vp, vp, vp, C.c_long, ip, C.c_long, ip, ip, ip, vp, vp, vp, vp, vp]; L.dsp_scrubjay_fused_pcm16_device.restype = ip
     lp = C.POINTER(C.c_long)
+    L.dsp_classify_batch_ragged_device_f64.argtypes = [vp, vp, C.c_long, lp, vp, vp, vp]; L.dsp_classify_batch_ragged_device_f64.restype = ip
+    L.dsp_classify_batch_ragged_pcm16_device_f64.argtypes = [vp, vp, C.c_long, lp, ip, ip, vp, vp, vp]; L.dsp_classify_batch_ragged_pcm16_device_f64.restype = ip
+    L.dsp_classify_batch_ragged_host_f64.argtypes = [vp, vp, C.c_long, lp, vp, vp]; L.dsp_classify_batch_ragged_host_f64.restype = ip
+    L.dsp_classify_batch_ragged_pcm16_host_f64.argtypes = [vp, vp, C.c_long, lp, ip, ip, vp, vp]; L.dsp_classify_batch_ragged_pcm16_host_f64.restype = ip
     L.dsp_classify_stats.argtypes = [ip, lp, lp]; L.dsp_classify_stats.restype = ip
     L.dsp_classify_batch_ragged_device.argtypes = [vp, vp, C.c_long, lp, vp, vp]; L.dsp_classify_batch_ragged_device.restype = ip
     L.dsp_classify_batch_ragged_pcm16_device.argtypes = [vp, vp, C.c_long, lp, ip, ip, vp, vp]; L.dsp_classify_batch_ragged_pcm16_device.restype = ip

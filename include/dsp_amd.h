@@ -308,6 +308,17 @@ int dsp_classify_batch_pcm16_host_f64(const dsp_classify_config_f64 *cfg, const 
                                       int stereo_mode, int *labels, dsp_classify_trace_f64 *trace);
 int dsp_classify_batch_pcm16_device_f64(const dsp_classify_config_f64 *cfg, const int16_t *d_pcm, long n_clips, int n, long stride, int channels,
                                         int stereo_mode, int *d_labels, dsp_classify_trace_f64 *d_trace, void *stream);
+/* RAGGED batches (offsets as dsp_classify_batch_ragged_device: a HOST array of n_clips + 1 sample positions per channel): the float64
+ * classify() of donut-classifier/classifier.c on clips of different lengths in one call -- the files its reader (:286-297) takes one per
+ * run.  Labels and trace records of a one-clip call on every clip, bit for bit.  d_trace / trace may be NULL.                          */
+int dsp_classify_batch_ragged_device_f64(const dsp_classify_config_f64 *cfg, const double *d_signal, long n_clips, const long *offsets,
+                                         int *d_labels, dsp_classify_trace_f64 *d_trace, void *stream);
+int dsp_classify_batch_ragged_pcm16_device_f64(const dsp_classify_config_f64 *cfg, const int16_t *d_pcm, long n_clips, const long *offsets,
+                                               int channels, int stereo_mode, int *d_labels, dsp_classify_trace_f64 *d_trace, void *stream);
+int dsp_classify_batch_ragged_host_f64(const dsp_classify_config_f64 *cfg, const double *signal, long n_clips, const long *offsets, int *labels,
+                                       dsp_classify_trace_f64 *trace);
+int dsp_classify_batch_ragged_pcm16_host_f64(const dsp_classify_config_f64 *cfg, const int16_t *pcm, long n_clips, const long *offsets,
+                                             int channels, int stereo_mode, int *labels, dsp_classify_trace_f64 *trace);
 /* What the LAST pass of the float64 classifier on `device` did (blocks until it has finished): spectrogram segments of the
  * 1000-3000 Hz output, how many of them the screening left to the float64 transform, clips that had midpoints.  Any pointer may be NULL. */
 int dsp_classify_stats_f64(int device, long *segments, long *undecided, long *listed_clips);

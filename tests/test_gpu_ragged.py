@@ -259,3 +259,57 @@ def test_classify_ragged_across_sub_batches_and_block_edges(dsp):
             flat[pos.reshape(-1)] = srcs[k][w].repeat(idx.size)
     got = dsp.classify_device_ragged(flat, off).cpu().numpy()
     assert np.array_equal(got, want) and 0 < want.sum() < n_clips
+
+
+def _trace_equal_f64(a, b):
+    return np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_classify_f64_ragged_equals_one_call_per_clip(dsp, golden):
+    """dsp_classify_batch_ragged_*_f64 (the float64 classify() of donut-classifier/classifier.c): labels, midpoints and band sums of
+    every clip as a one-clip call returns them, bit for bit -- default thresholds and a 30 dB midpoint threshold (where the faint tails
+    have midpoints too); float64 samples, int16 mono, stereo channel 0 / average; device and host entry points."""
+    import torch
+    rng = np.random.default_rng(92)
+    clips = [x.astype(np.float64) for x in _classify_clips(rng, 90)]
+    flat, off = _pack(clips)
+    for cfg in (None, (0.70, 0.85, 30.0, 75.0, 300.0, 100.0)):
+        labels, trace = dsp.classify_ragged_f64(flat, off, with_trace=True, config=cfg)
+        dev = dsp.classify_device_ragged_f64(torch.from_numpy(flat).cuda(), off, config=cfg).cpu().numpy()
+        assert np.array_equal(dev, labels)
+        seen = 0
+        for c, x in enumerate(clips):
+            l1, t1 = dsp.classify_batch_f64(x[None, :], with_trace=True, config=cfg)
+            assert labels[c] == l1[0] and _trace_equal_f64(trace[c], t1[0]), (c, x.size, cfg)
+            seen += len(t1[0][0])
+        assert seen > 20
+    pcm = [np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16) for x in clips[:40]]
+    flat, off = _pack(pcm)
+    labels, trace = dsp.classify_ragged_f64(flat, off, with_trace=True)
+    assert np.array_equal(dsp.classify_device_ragged_f64(torch.from_numpy(flat).cuda(), off).cpu().numpy(), labels)
+    for c, x in enumerate(pcm):
+        l1, t1 = dsp.classify_batch_f64_pcm16(x[None, :], with_trace=True)
+        assert labels[c] == l1[0] and _trace_equal_f64(trace[c], t1[0]), (c, x.size)
+    st = [np.stack([x, (x // 3).astype(np.int16)], axis=1) for x in pcm]
+    flat, off = _pack(st)
+    for mode in (dsp.STEREO_CHANNEL0, dsp.STEREO_AVERAGE):
+        labels, trace = dsp.classify_ragged_f64(flat, off, stereo_mode=mode, with_trace=True)
+        for c, x in enumerate(st):
+            l1, t1 = dsp.classify_batch_f64_pcm16(x[None], stereo_mode=mode, with_trace=True)
+            assert labels[c] == l1[0] and _trace_equal_f64(trace[c], t1[0]), (mode, c)
+    assert not dsp.classify_ragged_f64(flat[:, 0].copy(), np.array([0, 100, 355])).any()
+    with pytest.raises(dsp.DspError, match="too long"):
+        dsp.classify_ragged_f64(np.zeros(300000), np.array([0, 1000, 300000]))
+
+
+def test_classify_f64_ragged_on_the_donut_recordings(dsp, golden):
+    """The classifier's own 16 kHz recordings in ONE call, int16 channel 0 as classifier.c:286-297 reads them: against one call per file."""
+    g = golden("donut16k_ref.npz")
+    names = sorted({k.split("__")[0] for k in g.files})
+    files = [np.ascontiguousarray(g[n + "__pcm"]) for n in names]
+    flat, off = _pack(files)
+    for cfg in (None, (0.70, 0.85, 30.0, 75.0, 300.0, 100.0)):
+        labels, trace = dsp.classify_ragged_f64(flat, off, stereo_mode=dsp.STEREO_CHANNEL0, with_trace=True, config=cfg)
+        for c, x in enumerate(files):
+            l1, t1 = dsp.classify_batch_f64_pcm16(x[None], stereo_mode=dsp.STEREO_CHANNEL0, with_trace=True, config=cfg)
+            assert labels[c] == l1[0] and _trace_equal_f64(trace[c], t1[0]), (names[c], cfg)
