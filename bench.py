@@ -301,6 +301,43 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
                    "20 coefficients; restated from aubio 0.4, parity unpinned)" if own else "")
                 + (f"; labels + probabilities (8 B per clip) all-gathered over {world} ranks every step, pipelined" if world > 1 else ""))
         kernel = "mfcc2048_kernel<POOL, AUB>" if own else "mfcc512_wave_kernel<POOL>"
+    elif args.workload in ("config5_ragged", "classify_ragged"):
+        # ragged batches (the reference's callers loop over files of different lengths): clips of 0.5 - 1.5 s back to back in
+        # one buffer, ONE call; the same total samples as the uniform workload beside it, so the two lines compare directly
+        import numpy as np
+        fused = args.workload == "config5_ragged"
+        n = args.clips or (125_000 if fused else 49152)
+        rng = np.random.default_rng(1234 + rank)
+        lens = rng.integers(8000, 24001, n)
+        lens[-1] += 16000 * n - int(lens.sum()) if abs(16000 * n - int(lens.sum())) < 8000 else 0
+        off = np.zeros(n + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        total = int(off[-1])
+        from dsp_amd import lib as L
+        c_off = L.c_offsets(off)
+        if fused:
+            from dsp_amd.scrubjay import ScrubJay
+            flat = torch.rand(total, device=dev, generator=gen) * 2 - 1
+            sj = ScrubJay(dict(np.load(os.path.join(ROOT, "tests", "golden", "scrubjay_svm.npz"))), local, n_mfcc=20)
+            step = lambda: sj.ragged(flat, c_off, 500)        # noqa: E731
+            units, unit, bytes_per = n, "clips/s", 4.0 * total / n + 8
+            what = (f"{n} fp32 clips of 0.5 - 1.5 s ({total} samples in one buffer, offsets[n + 1]) -> MFCC(20) -> mean|std -> Scaler -> RBF-SVM in ONE launch "
+                    "of the fused clip kernel (dsp_scrubjay_fused_ragged_device); config5's bytes, ragged")
+            kernel = "mfcc512_wave_kernel<POOL> (ClipCursor over spans)"
+        else:
+            from tests import signals as S
+            flat = (torch.rand(total, device=dev, generator=gen) * 2 - 1) * 0.05
+            call = torch.from_numpy(S.classify_cases()["scrub_a"]).to(dev)
+            for c in range(0, n, 4):                           # every fourth clip carries (the head of / a repetition of) the call pattern
+                m = int(lens[c])
+                seg = call.repeat(2)[:m]
+                flat[int(off[c]):int(off[c]) + m] = seg + flat[int(off[c]):int(off[c]) + m] * 0.01
+            labels = torch.empty(n, dtype=torch.int32, device=dev)
+            step = lambda: dsp_amd.classify_device_ragged(flat, c_off, labels)   # noqa: E731
+            units, unit, bytes_per = n, "clips/s", 4.0 * total / n + 4
+            what = (f"{n} fp32 clips of 0.5 - 1.5 s ({total} samples in one buffer, offsets[n + 1]; every fourth with the call pattern) through classify() "
+                    "in ONE call (dsp_classify_batch_ragged_device); classify's bytes, ragged")
+            kernel = "iir2_ckpt_kernel<RAGGED> + spec_from_ckpt_kernel<flags> + classify_midpoints_kernel + spec_from_ckpt_kernel<[time][bin]> + classify_bands_kernel"
     elif args.workload == "stop":
         import numpy as np
         n = args.clips or 125_000
@@ -544,7 +581,7 @@ def main():
                          "steps end before the GPU's clocks have ramped (first launches after idle run 0.6 ms); reported in config")
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU per step")
     ap.add_argument("--gather", action="store_true", help="all-gather the per-rank features every step (RCCL)")
-    ap.add_argument("--workload", choices=["frames", "clips", "classify", "classify_pcm16", "classify_f64", "classify_f64_pcm16", "config3", "config5", "config5_2048", "pcm16", "stop"], default="frames",
+    ap.add_argument("--workload", choices=["frames", "clips", "classify", "classify_pcm16", "classify_f64", "classify_f64_pcm16", "classify_ragged", "config3", "config5", "config5_2048", "config5_ragged", "pcm16", "stop"], default="frames",
                     help="frames = BASELINE configs[1] (the headline metric, default); clips = configs[3] per-GPU share "
                          "(12 500 x 1 s clips, reference framing 400/160); classify = the donut classifier on 1 s clips")
     ap.add_argument("--clips", type=int, default=0, help="clips per GPU per step for --workload clips / classify")

@@ -175,8 +175,8 @@ def classify_ragged(signal: np.ndarray, offsets, stereo_mode: int = 0, with_trac
 def classify_device_ragged(signal, offsets, labels=None, stereo_mode: int = 0, config=None):
     """The same on a flat cuda buffer (float32 [total], int16 [total] or [total][2]) -> cuda int32 labels, stream-ordered."""
     import torch
-    off, n_clips = _lib.c_offsets(offsets)
-    assert signal.is_cuda and signal.stride(-1) == 1 and int(offsets[-1]) <= signal.shape[0]
+    off, n_clips = offsets if isinstance(offsets, tuple) else _lib.c_offsets(offsets)      # (a prepared (ctypes array, n_clips) pair: no conversion per call)
+    assert signal.is_cuda and signal.stride(-1) == 1 and int(off[n_clips]) <= signal.shape[0]
     if labels is None:
         labels = torch.empty(n_clips, dtype=torch.int32, device=signal.device)
     st = C.c_void_p(torch.cuda.current_stream(signal.device).cuda_stream)
@@ -303,8 +303,8 @@ def classify_ragged_f64(signal: np.ndarray, offsets, stereo_mode: int = STEREO_C
 def classify_device_ragged_f64(signal, offsets, labels=None, stereo_mode: int = STEREO_CHANNEL0, config=None):
     """The same on a flat cuda buffer (float64 [total], int16 [total] or [total][2]) -> cuda int32 labels, stream-ordered."""
     import torch
-    off, n_clips = _lib.c_offsets(offsets)
-    assert signal.is_cuda and signal.stride(-1) == 1 and int(offsets[-1]) <= signal.shape[0]
+    off, n_clips = offsets if isinstance(offsets, tuple) else _lib.c_offsets(offsets)      # (a prepared (ctypes array, n_clips) pair: no conversion per call)
+    assert signal.is_cuda and signal.stride(-1) == 1 and int(off[n_clips]) <= signal.shape[0]
     if labels is None:
         labels = torch.empty(n_clips, dtype=torch.int32, device=signal.device)
     st = C.c_void_p(torch.cuda.current_stream(signal.device).cuda_stream)

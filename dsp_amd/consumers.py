@@ -95,8 +95,8 @@ class StopModel:
         """Clips of different lengths in ONE launch (the files main_test.c:254-331 loops over): `signal` is a flat cuda buffer (float32
         [total], int16 [total] or stereo int16 [total][2]), clip c = samples [offsets[c], offsets[c + 1]) -> P("stop") per clip."""
         import torch
-        off, n = _lib.c_offsets(offsets)
-        assert signal.is_cuda and signal.stride(-1) == 1 and int(offsets[-1]) <= signal.shape[0]
+        off, n = offsets if isinstance(offsets, tuple) else _lib.c_offsets(offsets)      # (a prepared (ctypes array, n_clips) pair: no conversion per call)
+        assert signal.is_cuda and signal.stride(-1) == 1 and int(off[n]) <= signal.shape[0]
         prob = torch.empty(n, dtype=torch.float32, device=signal.device)
         if signal.dtype == torch.float32:
             assert signal.dim() == 1

@@ -21,6 +21,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "capi_util.hpp"
 #include "classify_kernels.hpp"
@@ -362,12 +363,26 @@ int ragged(const dsp_classify_config_f64 *cfgp, const void *d_signal, int device
     const long kSubBatch = sub_batch(kCkpt);
     int rc = reserve(w, device, kCkpt, std::min(kSubBatch, n_clips), n_max, 0);
     if (rc < 0) return rc;
+    // in order of length, longest first (a block's 64 clips alike: it walks to its longest); order[i] = the caller's index of the i-th
+    // clip as run, the results go home through it
+    if (n_clips >= (1L << 31)) return dsp::capi_fail(DSP_EINVAL, "too many clips");
+    std::vector<int> order((size_t)n_clips), segs((size_t)n_clips);
+    for (long c = 0; c < n_clips; ++c) segs[c] = columns((int)(offsets[c + 1] - offsets[c]));
+    dsp::order_by_key_desc(segs.data(), n_clips, columns(n_max), order.data());
+    const size_t span_bytes = (size_t)n_clips * sizeof(dsp::ClipSpan), perm_bytes = (size_t)n_clips * sizeof(int);
     dsp::SpanRing::Slot *slot = nullptr;
-    DSP_CAPI_HIP(w.spans.acquire((size_t)n_clips * sizeof(dsp::ClipSpan), &slot));
+    DSP_CAPI_HIP(w.spans.acquire(span_bytes + perm_bytes, &slot));
     dsp::ClipSpan *h = static_cast<dsp::ClipSpan *>(slot->h);
-    for (long c = 0; c < n_clips; ++c) h[c] = dsp::ClipSpan{offsets[c], (int)(offsets[c + 1] - offsets[c]), columns((int)(offsets[c + 1] - offsets[c]))};
+    for (long i = 0; i < n_clips; ++i) {
+        const long c = order[i];
+        h[i] = dsp::ClipSpan{offsets[c], (int)(offsets[c + 1] - offsets[c]), columns((int)(offsets[c + 1] - offsets[c])), c, 0};
+    }
+    std::memcpy(static_cast<char *>(slot->h) + span_bytes, order.data(), perm_bytes);
     if (w.pending) DSP_CAPI_HIP(hipStreamWaitEvent(st, w.done, 0));
-    DSP_CAPI_HIP(dsp::SpanRing::upload(slot, (size_t)n_clips * sizeof(dsp::ClipSpan), st));
+    DSP_CAPI_HIP(dsp::SpanRing::upload(slot, span_bytes + perm_bytes, st));
+    const int *d_perm = reinterpret_cast<const int *>(static_cast<const char *>(slot->d) + span_bytes);
+    std::vector<int> h_labels;
+    std::vector<dsp_classify_trace_f64> h_trace;
     struct SlotMark { dsp::SpanRing::Slot *s; hipStream_t st; ~SlotMark() { dsp::SpanRing::mark(s, st); } } slot_mark{slot, st};
     BusyMark mark{w, st};
     const dsp::ClipSpan *d_spans = static_cast<const dsp::ClipSpan *>(slot->d);
@@ -375,11 +390,23 @@ int ragged(const dsp_classify_config_f64 *cfgp, const void *d_signal, int device
     for (long c0 = 0; c0 < n_clips; c0 += kSubBatch) {
         const long cnt = std::min(kSubBatch, n_clips - c0);
         if ((rc = run(cfg, w, kCkpt, d_signal, in, cnt, n_max, 0, want_trace, st, d_spans + c0, offsets[n_clips])) < 0) return rc;
-        if (d_labels) DSP_CAPI_HIP(hipMemcpyAsync(d_labels + c0, w.labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToDevice, st));
-        if (d_trace) DSP_CAPI_HIP(hipMemcpyAsync(d_trace + c0, w.trace, (size_t)cnt * sizeof(dsp_classify_trace_f64), hipMemcpyDeviceToDevice, st));
-        if (labels) DSP_CAPI_HIP(hipMemcpyAsync(labels + c0, w.labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, st));
-        if (trace) DSP_CAPI_HIP(hipMemcpyAsync(trace + c0, w.trace, (size_t)cnt * sizeof(dsp_classify_trace_f64), hipMemcpyDeviceToHost, st));
-        if (labels || trace) DSP_CAPI_HIP(hipStreamSynchronize(st));
+        if (d_labels) DSP_CAPI_HIP(dsp::launch_scatter_records(w.labels, d_perm + c0, cnt, sizeof(int), d_labels, st));
+        if (d_trace) DSP_CAPI_HIP(dsp::launch_scatter_records(w.trace, d_perm + c0, cnt, sizeof(dsp_classify_trace_f64), d_trace, st));
+        if (labels) {
+            h_labels.resize((size_t)cnt);
+            DSP_CAPI_HIP(hipMemcpyAsync(h_labels.data(), w.labels, (size_t)cnt * sizeof(int), hipMemcpyDeviceToHost, st));
+        }
+        if (trace) {
+            h_trace.resize((size_t)cnt);
+            DSP_CAPI_HIP(hipMemcpyAsync(h_trace.data(), w.trace, (size_t)cnt * sizeof(dsp_classify_trace_f64), hipMemcpyDeviceToHost, st));
+        }
+        if (labels || trace) {
+            DSP_CAPI_HIP(hipStreamSynchronize(st));
+            for (long i = 0; i < cnt; ++i) {
+                if (labels) labels[order[c0 + i]] = h_labels[i];
+                if (trace) trace[order[c0 + i]] = h_trace[i];
+            }
+        }
     }
     return DSP_OK;
 }

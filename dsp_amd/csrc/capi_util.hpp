@@ -3,8 +3,10 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/dsp_amd.h"
 
@@ -71,6 +73,23 @@ struct SpanRing {
         }
     }
 };
+}
+
+// order[i] = index of the i-th largest key, ties in input order (what std::stable_sort gives) -- by counting: a ragged batch of 125 000
+// clips is ordered in well under a millisecond, where the comparison sort took longer than the kernel it was ordering for
+namespace dsp {
+inline void order_by_key_desc(const int *key, long n, int key_max, int *order)
+{
+    if (key_max < 0 || key_max > (1 << 22)) {               // (absurd key ranges: the comparison sort)
+        for (long i = 0; i < n; ++i) order[i] = (int)i;
+        std::stable_sort(order, order + n, [&](int a, int b) { return key[a] > key[b]; });
+        return;
+    }
+    std::vector<long> start((size_t)key_max + 2, 0);
+    for (long i = 0; i < n; ++i) ++start[(size_t)(key_max - key[i]) + 1];
+    for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+    for (long i = 0; i < n; ++i) order[start[(size_t)(key_max - key[i])]++] = (int)i;
+}
 }
 
 #define DSP_CAPI_HIP(call)                                                                              \

@@ -789,7 +789,11 @@ hipError_t launch_iir2_ckpt(const void *x, long n_clips, int n, long stride, con
     const int blocks = (int)((n_clips + 63) / 64);
     // worth its ~10 us (table reset, the blocks' wait) only when CUs hold three or more blocks: up to two blocks per CU every
     // recurrence wave has at most one neighbour anyway (measured: 12 288 clips +0.03 ms, 24 576 +-0, 49 152 -0.13 ms, 131 072 -0.33 ms)
-    static const int n_cu = [] { int dev = 0, n = 0; return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256; }();
+    static int n_cu_of[64] = {0};                    // per device
+    int cur_dev = 0;
+    if (hipGetDevice(&cur_dev) != hipSuccess || cur_dev < 0 || cur_dev >= 64) cur_dev = 0;
+    if (n_cu_of[cur_dev] <= 0) { int n = 0; n_cu_of[cur_dev] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, cur_dev) == hipSuccess && n > 0 ? n : 256; }
+    const int n_cu = n_cu_of[cur_dev];
     if (!simd_aware || (blocks <= 2 * n_cu && simd_mode != 2)) simd_load = nullptr;
     if (simd_load) {
         hipError_t e = hipMemsetAsync(simd_load, 0, sizeof(int) * kSimdLoadCus * kSimdLoadStride, stream);
@@ -1528,11 +1532,14 @@ __global__ __launch_bounds__(RC_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
     RC_STAMP(7);
 }
 
-// resident 512-thread blocks of the chip for one instantiation (queried once per process)
+// resident 512-thread blocks of the chip for one instantiation (queried once per process AND device: a process may drive several GPUs)
 template <int OUT, bool EVEN_B>
 static int rc_resident_blocks()
 {
-    static int cached = 0;
+    static int cache[64] = {0};
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess || cur < 0 || cur >= 64) cur = 0;
+    int &cached = cache[cur];
     if (cached > 0) return cached;
     int per_cu = 0, dev = 0, n_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, spec_from_ckpt_kernel<OUT, EVEN_B>, RC_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -2176,6 +2183,29 @@ hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int
                            labels, trace, hits, rule, need, minmax, spans);
     else
         hipLaunchKernelGGL(classify_bands_kernel<false>, dim3(blocks), dim3(256), 0, stream, sxx_bp, T, fs, labels, trace, hits, rule, need, minmax, spans);
+    return hipGetLastError();
+}
+
+// Ragged batches run in order of length (a block's 64 clips alike); their per-clip results go home through the permutation:
+// dst record perm[i] = src record i (records of rec_words 32-bit words).
+__global__ __launch_bounds__(256) void scatter_records_kernel(const unsigned *__restrict__ src, const int *__restrict__ perm, long n, int rec_words,
+                                                              unsigned *__restrict__ dst)
+{
+    const long total = n * rec_words;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / rec_words;
+        dst[(long)perm[r] * rec_words + (i - r * rec_words)] = src[i];
+    }
+}
+
+hipError_t launch_scatter_records(const void *src, const int *perm, long n, size_t rec_bytes, void *dst, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    if (rec_bytes % 4 != 0 || rec_bytes == 0) return hipErrorInvalidValue;
+    const long total = n * (long)(rec_bytes / 4);
+    const unsigned blocks = (unsigned)std::min<long>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(scatter_records_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const unsigned *>(src), perm, n, (int)(rec_bytes / 4),
+                       static_cast<unsigned *>(dst));
     return hipGetLastError();
 }
 

@@ -139,6 +139,9 @@ struct ClassifyRule { float keep_lo, keep_hi, middle_max, above_min, below_min; 
 hipError_t launch_classify_bands(float *sxx_bp, long n_clips, int n, int fs, int *labels, ClassifyTrace *trace, const int *hits,
                                  hipStream_t stream, const ClassifyRule &rule, const int *need = nullptr, const unsigned *minmax = nullptr,
                                  const ClipSpan *spans = nullptr);
+// dst record perm[i] = src record i, i < n (records of rec_bytes, a multiple of 4): how a ragged batch's results, computed in order of
+// length, return to the caller's order
+hipError_t launch_scatter_records(const void *src, const int *perm, long n, size_t rec_bytes, void *dst, hipStream_t stream);
 // Counts, into *mismatches (device, zeroed by the caller), the floats p in [kDivFastLo, kDivFastHi] for which the three-instruction
 // form of p / tables->U (see SpecTables::rU) differs from the division: every bit pattern in the range is tried.
 hipError_t launch_spec_div_verify(const SpecTables *tables, unsigned long long *mismatches, hipStream_t stream);

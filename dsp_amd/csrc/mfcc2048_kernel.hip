@@ -417,13 +417,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 asm volatile("" : "+s"(ap));
                 const PoolSvmArgs &pool = ap->pool;
                 const SvmModelDev &sm = pool.svm;
+                const long clip_o = ap->spans ? ap->spans[clip_f].orig : clip_f;      // ragged batches run in the host's order; results go to the caller's index
                 if ((lane & 1) == 0 && c < n_mfcc) {
                     const double mean = pool_s / (double)pool_t;
                     const double var = pool_q / (double)pool_t - mean * mean;
                     const float f_mean = (float)mean, f_std = sqrtf((float)(var > 0 ? var : 0));
                     if (pool.feat) {
-                        pool.feat[clip_f * 2L * n_mfcc + c] = f_mean;
-                        pool.feat[clip_f * 2L * n_mfcc + n_mfcc + c] = f_std;
+                        pool.feat[clip_o * 2L * n_mfcc + c] = f_mean;
+                        pool.feat[clip_o * 2L * n_mfcc + n_mfcc + c] = f_std;
                     }
                     feat[c] = (f_mean - scaler[c]) * scaler[64 + c];
                     feat[n_mfcc + c] = (f_std - scaler[n_mfcc + c]) * scaler[64 + n_mfcc + c];
@@ -457,9 +458,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                     int label;
                     float p1;
                     svm_binary_tail(score, sm.prob_a, sm.prob_b, label, p1);
-                    pool.labels[clip_f] = label;
-                    if (pool.decision) pool.decision[clip_f] = score;
-                    if (pool.prob1) pool.prob1[clip_f] = p1;
+                    pool.labels[clip_o] = label;
+                    if (pool.decision) pool.decision[clip_o] = score;
+                    if (pool.prob1) pool.prob1[clip_o] = p1;
                 }
                 pool_s = 0.0; pool_q = 0.0; pool_t = 0;
                 wave_lds_sync();

@@ -254,7 +254,10 @@ struct WaveCursor {
 
 // Cursor of the fused clip kernels (one wavefront walks one clip from its first frame to its last; clips dealt round-robin to the
 // waves).  Uniform batches: clip c starts at c * clip_stride and has fpc frames; ragged batches (spans != nullptr): start, samples and
-// frame count come from the clip's ClipSpan, one 16-byte scalar load per clip.  Same members as WaveCursor where the kernels read them.
+// frame count come from the clip's ClipSpan, one scalar load per clip -- the HOST has put the spans in an order that makes the fixed
+// deal even (by length, snaking over the waves; capi.cpp ragged_spans) and the results go to ClipSpan::orig.  (Handing the clips out
+// by an atomic counter inside the kernel was tried first: the extra live state cost the frame loop 4 - 15 spilled VGPRs.)
+// Same members as WaveCursor where the kernels read them.
 struct ClipCursor {
     long f, off, clip;
     long n_clips, n_waves, clip_stride;

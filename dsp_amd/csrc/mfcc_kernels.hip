@@ -298,7 +298,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
     };
 #pragma unroll
     for (int d = 0; d < PF; ++d) refill(d);
-    if (fq[0] < 0) return;
+    // a wave without work leaves -- but in the fused clip kernels only after the block's shared tables below are filled: every thread of
+    // the block writes its share of them (a wave that left before that left holes: harmless while the tables were at most 64 entries
+    // and the idle waves a block's LAST ones, wrong once ragged batches hand the clips out by counter)
+    if (POOL == 0 && fq[0] < 0) return;
 
     // ---- POOL: per-clip running sums of lane c's coefficient (float64, frames in order), the clip's end -------------
     int pool_t = 0;
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         }
         __syncthreads();
     }
+    if (POOL != 0 && fq[0] < 0) return;
     auto pool_tile = [&](const f4v (&d)[CT], int count) {
         // coefficients of the tile -> LDS as Dt[c][n] (the mel-energy tile has been consumed), then lane c adds its
         // row frame by frame: the same order of float64 additions as mfcc_stats (svm_kernels.hip / scrubjay_infer.c:36-66)
@@ -368,6 +372,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
         // (the kernarg segment itself: taking &args would make the compiler copy the argument struct to scratch)
         const Mfcc512Args *ap = kernarg_of_mfcc512();
         asm volatile("" : "+s"(ap));
+        if (ap->spans) clip = ap->spans[clip].orig;              // ragged batches run in the host's order; results go to the caller's index
         const PoolSvmArgs &pool = ap->pool;
         const SvmModelDev &m = pool.svm;
         PF_STAMP(0);
@@ -486,6 +491,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSP_WAVES_P
 #pragma clang fp contract(off)
         const Mfcc512Args *ap = kernarg_of_mfcc512();
         asm volatile("" : "+s"(ap));
+        if (ap->spans) clip = ap->spans[clip].orig;              // ragged batches run in the host's order; results go to the caller's index
         const StopModelDev &m = ap->stop.m;
         int lane = threadIdx.x & 63;
         asm volatile("" : "+v"(lane));
@@ -934,6 +940,32 @@ hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_l
     return hipErrorInvalidConfiguration;
 }
 
+typedef void (*StopKernel)(const Mfcc512Args);
+static StopKernel stop_kernel_of(int in_kind, int gather, int frame_len)
+{
+    if (in_kind == 1) return mfcc512_wave_kernel<4, 10, 3, 400, 1, 1, true, 2>;       // int16 PCM: main_test.c's reader feeds classify_signal
+    if (in_kind == 2) return mfcc512_wave_kernel<4, 10, 3, 400, 2, 1, true, 2>;
+    if (in_kind == 3) return mfcc512_wave_kernel<4, 10, 3, 400, 3, 1, true, 2>;
+    if (gather == 3 && frame_len == 400) return mfcc512_wave_kernel<4, 10, 3, 400, 0, 1, true, 2>;
+    if (gather == 3) return mfcc512_wave_kernel<4, 10, 3, 0, 0, 1, true, 2>;
+    if (gather == 6) return mfcc512_wave_kernel<4, 10, 6, 0, 0, 1, true, 2>;
+    return nullptr;
+}
+
+// the blocks launch_mfcc512_stop will start for a caller's count: at most what the chip holds with this variant's LDS (the host lays
+// ragged batches out for that many wavefronts)
+int mfcc512_stop_grid(int blocks, const StopModelDev &m, int in_kind, int gather, int frame_len)
+{
+    const StopKernel kernel = stop_kernel_of(in_kind, gather, frame_len);
+    if (!kernel) return blocks;
+    const size_t lds = lds_bytes<4, 10>(true, 2, stop_small_floats(m));
+    int per_cu = 0, dev = 0, n_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0)
+        blocks = std::min(blocks, per_cu * n_cu);
+    return std::max(blocks, 1);
+}
+
 // classify_signal fused (POOL = 2): the reference's shape only (13 coefficients of 40 mel energies: DCT_SPLIT 4, DCT_LEN 10)
 hipError_t launch_mfcc512_stop(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream)
 {
@@ -945,21 +977,11 @@ hipError_t launch_mfcc512_stop(const Mfcc512Args &args, int dct_split, int dct_l
     for (int l = 1; l < 4; ++l)
         if (m.units[l] < 1 || m.units[l] > kStopMaxUnits) return hipErrorInvalidConfiguration;
     const size_t lds = lds_bytes<4, 10>(true, 2, stop_small_floats(m));
+    const StopKernel kernel = stop_kernel_of(args.in_kind, gather, args.frame_len);
+    if (!kernel) return hipErrorInvalidConfiguration;
     // persistent-style grid: the blocks the chip really holds with this variant's LDS (the caller's count is the plain kernel's)
-    auto launch = [&](auto kernel) {
-        int per_cu = 0, dev = 0, n_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0)
-            blocks = std::min(blocks, per_cu * n_cu);
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, stream, args);
-    };
-    if (args.in_kind == 1) launch(mfcc512_wave_kernel<4, 10, 3, 400, 1, 1, true, 2>);       // int16 PCM: main_test.c's reader feeds classify_signal
-    else if (args.in_kind == 2) launch(mfcc512_wave_kernel<4, 10, 3, 400, 2, 1, true, 2>);
-    else if (args.in_kind == 3) launch(mfcc512_wave_kernel<4, 10, 3, 400, 3, 1, true, 2>);
-    else if (gather == 3 && args.frame_len == 400) launch(mfcc512_wave_kernel<4, 10, 3, 400, 0, 1, true, 2>);
-    else if (gather == 3) launch(mfcc512_wave_kernel<4, 10, 3, 0, 0, 1, true, 2>);
-    else if (gather == 6) launch(mfcc512_wave_kernel<4, 10, 6, 0, 0, 1, true, 2>);
-    else return hipErrorInvalidConfiguration;
+    blocks = mfcc512_stop_grid(blocks, m, args.in_kind, gather, args.frame_len);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, stream, args);
     return hipGetLastError();
 }
 

@@ -73,6 +73,7 @@ hipError_t launch_mfcc512(const Mfcc512Args &args, int dct_split, int dct_len, i
 // fused clip -> label path: args.chunk must equal args.frames_per_clip, args.out is not written
 hipError_t launch_mfcc512_pool(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream);
 // fused clip -> stop-word probability (reference shape only: 13 coefficients, 40 mel): args.chunk == args.frames_per_clip, args.stop set
+int mfcc512_stop_grid(int blocks, const StopModelDev &m, int in_kind, int gather, int frame_len);      // the grid launch_mfcc512_stop starts for a caller's count
 hipError_t launch_mfcc512_stop(const Mfcc512Args &args, int dct_split, int dct_len, int gather, int blocks, hipStream_t stream);
 hipError_t launch_mfcc512_row(const Mfcc512Args &args, const RowTables512 *row_tables, int dct_split, int dct_len,
                               int gather, int blocks, hipStream_t stream);

@@ -103,7 +103,7 @@ SYMBOLS = [
     "dsp_classify_signal", "dsp_speaker_model_create", "dsp_speaker_model_destroy", "dsp_speaker_llr_device",
     "dsp_upsample_linear_device", "dsp_upsample_linear_host",
     "dsp_gather_create", "dsp_gather_destroy", "dsp_gather_n_devices", "dsp_gather_all",
-    "dsp_last_error", "dsp_device_count", "dsp_version",
+    "dsp_last_error", "dsp_device_count", "dsp_version", "dsp_abi_sizeof",
 ]
 
 # the reference's own C++-linkage names (sync/lib/classifier.h:14-19, include/dsp_amd_classifier.h), Itanium-mangled
@@ -146,6 +146,10 @@ def load() -> C.CDLL:
         raise DspError(f"cannot load {path}: {e} (the HIP extension is required; there is no fallback)") from e
     vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.c_int
     cfgp = C.POINTER(MfccConfig)
+    L.dsp_abi_sizeof.argtypes = [ip]; L.dsp_abi_sizeof.restype = ip
+    for which, mirror in ((0, MfccConfig), (1, ClassifyTrace), (2, ClassifyTraceF64)):      # the ctypes mirrors against the library's own structs
+        if L.dsp_abi_sizeof(which) != C.sizeof(mirror):
+            raise DspError(f"{path}: struct {mirror.__name__} is {L.dsp_abi_sizeof(which)} bytes in the library, {C.sizeof(mirror)} in dsp_amd/lib.py")
     L.compute_mfcc.argtypes = [vp, ip, vp, ip]; L.compute_mfcc.restype = ip
     L.fft_real_forward.argtypes = [vp, vp]; L.fft_real_forward.restype = None
     L.dsp_fft_real_forward_host.argtypes = [vp, C.c_long, ip, C.c_long, ip, vp]; L.dsp_fft_real_forward_host.restype = ip

@@ -135,8 +135,8 @@ class ScrubJay:
         float32 [total], int16 [total] or interleaved stereo int16 [total][2] -- and clip c is samples [offsets[c], offsets[c + 1]).
         Results as a one-clip call per clip gives them (dsp_scrubjay_fused_ragged_device / _pcm16_device)."""
         import torch
-        off, n = _lib.c_offsets(offsets)
-        assert signal.is_cuda and signal.stride(-1) == 1 and int(offsets[-1]) <= signal.shape[0]
+        off, n = offsets if isinstance(offsets, tuple) else _lib.c_offsets(offsets)      # (a prepared (ctypes array, n_clips) pair: no conversion per call)
+        assert signal.is_cuda and signal.stride(-1) == 1 and int(off[n]) <= signal.shape[0]
         labels = torch.empty(n, dtype=torch.int32, device=signal.device)
         dec = torch.empty(n, dtype=torch.float32, device=signal.device)
         p1 = torch.empty(n, dtype=torch.float32, device=signal.device)

@@ -495,6 +495,10 @@ int dsp_prefilter_scan_check(int prefilter, int *steps4);
 const char *dsp_last_error(void);   /* thread-local, "" when none */
 int dsp_device_count(void);
 const char *dsp_version(void);
+/* ABI check for bindings that mirror the structs (ctypes, cgo, JNI ...): sizeof of the library's own dsp_mfcc_config,
+ * dsp_classify_trace and dsp_classify_trace_f64 for which = 0, 1, 2 (-1 otherwise).  dsp_mfcc_config carries no size field of its own:
+ * compare once after loading -- a binding built against an older header (fewer fields) must not pass its struct to this library.      */
+int dsp_abi_sizeof(int which);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

@@ -385,3 +385,26 @@ def test_end_to_end_on_the_reference_recordings(golden):
         assert int(labels[0]) == label == int(g[f"{name}__vote"])
         assert abs(float(decision[0]) - float(g[f"{name}__decision"])) < 5e-3
         assert abs(float(prob1[0]) - float(g[f"{name}__proba"][1])) < 5e-3
+
+
+def test_fused_kernel_with_many_support_vectors_and_a_partial_last_block(golden):
+    """A model with more support vectors than one wavefront copies into the block's LDS table (the reference's has 55), on batches
+    whose last block has idle wavefronts: every thread of a block must have written its share of the table before an idle wave leaves
+    (round 4: the idle waves left first; harmless only while the table was at most 64 entries long)."""
+    import torch
+    from dsp_amd import scrubjay
+    m = {k: np.array(v) for k, v in golden("scrubjay_svm.npz").items()}
+    rng = np.random.default_rng(5)
+    reps = 7                                                          # 385 support vectors
+    m["sv"] = np.concatenate([m["sv"] + rng.standard_normal(m["sv"].shape).astype(np.float32) * 0.05 * k for k in range(reps)]).astype(np.float32)
+    m["coef"] = np.concatenate([m["coef"] * (1.0 - 0.1 * k) for k in range(reps)]).astype(np.float32)
+    m["vectors_per_class"] = (np.asarray(m["vectors_per_class"]) * reps).astype(m["vectors_per_class"].dtype)
+    sj = scrubjay.ScrubJay(m)
+    gen = torch.Generator(device="cuda").manual_seed(18)
+    for n in (1, 2, 5, 7, 1021):
+        clips = torch.rand((n, 16000), device="cuda", generator=gen) * 2 - 1
+        clips[::3] *= 0.01
+        a = sj(clips, fused=False)
+        b = sj(clips, fused=True)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), n

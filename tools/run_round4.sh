@@ -12,7 +12,7 @@ if [ "$PART" == "a" ]; then
     timeout -k 10 1000 python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; tail -4 $OUT/tests.log | cut -c1-300
     cp gpurun_out/gate_report.json $OUT/gate_report.json 2>/dev/null
     python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; cut -c1-200 $OUT/bench.json
-    for w in clips config3 config5 config5_2048 classify classify_pcm16 classify_f64 classify_f64_pcm16 pcm16 stop; do
+    for w in clips config3 config5 config5_ragged config5_2048 classify classify_ragged classify_pcm16 classify_f64 classify_f64_pcm16 pcm16 stop; do
         python bench.py --workload $w --no-cpu-baseline --steps 50 >> $OUT/side_workloads.jsonl 2>> $OUT/side.err
     done
     python - <<PY
@@ -30,6 +30,8 @@ elif [ "$PART" == "b" ]; then
 elif [ "$PART" == "c" ]; then
     for w in frames classify classify_pcm16 classify_f64 classify_f64_pcm16; do
         python tools/traffic.py $TAG $w 2>&1 | tail -1
+    done
+    for w in frames config5 config5_2048 classify classify_pcm16 classify_f64 classify_f64_pcm16; do
         python tools/sq_fractions.py $TAG $w 2>&1 | tail -1
     done
 else
