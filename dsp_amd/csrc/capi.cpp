@@ -1502,23 +1502,20 @@ void dsp_svm_destroy(dsp_svm *s)
 // The kernels deal the spans to their n_waves wavefronts in fixed order (wave w walks spans w, w + n_waves, ...), so the ORDER of the
 // spans is the load balance: by frame count, longest first, and snaking -- left to right over the waves in even rounds, right to left in
 // odd ones -- every wave's total is within a clip of the mean (in the caller's order: +14 % on clips of 0.5 - 1.5 s).
-static int ragged_spans(dsp_mfcc_plan *p, const long *offsets, long n_clips, int max_frames, long n_waves, dsp::SpanRing::Slot **slot, int *t_max, void *stream)
+// (host only: no HIP call) fills h[n_clips]; returns DSP_OK or DSP_EINVAL with the reason
+static int build_fused_spans(const dsp_mfcc_config &cfg, const long *offsets, long n_clips, int max_frames, long n_waves, dsp::ClipSpan *h, int *t_max)
 {
-    if (!offsets) return fail(DSP_EINVAL, "offsets is NULL");
-    if (n_clips >= (1L << 31)) return fail(DSP_EINVAL, "too many clips");
     std::vector<int> frames((size_t)n_clips), order((size_t)n_clips);
     int tm = 0;
     for (long c = 0; c < n_clips; ++c) {
         const long n = offsets[c + 1] - offsets[c];
         if (offsets[c] < 0 || n < 0 || n > INT32_MAX) return fail(DSP_EINVAL, "offsets must be non-negative and non-decreasing, clips shorter than 2^31 samples");
-        const int t = dsp_mfcc_frames_for(&p->cfg, (int)n, max_frames);
+        const int t = dsp_mfcc_frames_for(&cfg, (int)n, max_frames);
         if (t == 0) return fail(DSP_EINVAL, "clip " + std::to_string(c) + " of the ragged batch is shorter than one frame");
-        frames[c] = t; order[c] = (int)c;
+        frames[c] = t;
         tm = std::max(tm, t);
     }
     dsp::order_by_key_desc(frames.data(), n_clips, tm, order.data());
-    DSP_HIP(p->spans.acquire((size_t)n_clips * sizeof(dsp::ClipSpan), slot));
-    dsp::ClipSpan *h = static_cast<dsp::ClipSpan *>((*slot)->h);
     n_waves = std::max(1L, n_waves);
     for (long i = 0; i < n_clips; ++i) {
         const long round = i / n_waves, j = i - round * n_waves;
@@ -1527,9 +1524,32 @@ static int ragged_spans(dsp_mfcc_plan *p, const long *offsets, long n_clips, int
         const long c = order[i];
         h[pos] = dsp::ClipSpan{offsets[c], (int)(offsets[c + 1] - offsets[c]), frames[c], c, 0};
     }
-    DSP_HIP(dsp::SpanRing::upload(*slot, (size_t)n_clips * sizeof(dsp::ClipSpan), (hipStream_t)stream));
     *t_max = tm;
     return DSP_OK;
+}
+
+static int ragged_spans(dsp_mfcc_plan *p, const long *offsets, long n_clips, int max_frames, long n_waves, dsp::SpanRing::Slot **slot, int *t_max, void *stream)
+{
+    if (!offsets) return fail(DSP_EINVAL, "offsets is NULL");
+    if (n_clips >= (1L << 31)) return fail(DSP_EINVAL, "too many clips");
+    DSP_HIP(p->spans.acquire((size_t)n_clips * sizeof(dsp::ClipSpan), slot));
+    const int rc = build_fused_spans(p->cfg, offsets, n_clips, max_frames, n_waves, static_cast<dsp::ClipSpan *>((*slot)->h), t_max);
+    if (rc < 0) return rc;
+    DSP_HIP(dsp::SpanRing::upload(*slot, (size_t)n_clips * sizeof(dsp::ClipSpan), (hipStream_t)stream));
+    return DSP_OK;
+}
+
+/* Test hook (host only): the order a ragged batch of the fused clip kernels runs in -- spans[pos] = {start, samples, frames, caller's
+ * index} as 4 longs per clip; wave w of n_waves walks pos = w, w + n_waves, ...  tests/test_capi_cpu.py checks it (also under ASan). */
+extern "C" int dsp_debug_fused_spans(const dsp_mfcc_config *cfg, const long *offsets, long n_clips, int max_frames, long n_waves, long *out4)
+{
+    if (!cfg || !offsets || n_clips < 0 || (n_clips > 0 && !out4)) return fail(DSP_EINVAL, "bad argument");
+    std::vector<dsp::ClipSpan> h((size_t)n_clips);
+    int tm = 0;
+    const int rc = build_fused_spans(*cfg, offsets, n_clips, max_frames, n_waves, h.data(), &tm);
+    if (rc < 0) return rc;
+    for (long i = 0; i < n_clips; ++i) { out4[4 * i] = h[i].off; out4[4 * i + 1] = h[i].n; out4[4 * i + 2] = h[i].frames; out4[4 * i + 3] = h[i].orig; }
+    return tm;
 }
 
 // clip -> label in one kernel; in_kind 0 = float samples, 1 / 2 / 3 = int16 mono / stereo channel 0 / stereo average.

@@ -98,7 +98,7 @@ SYMBOLS = [
     "dsp_mfcc_clips_host", "dsp_mfcc_clips_pcm16_device", "dsp_mfcc_plan_set_launch", "dsp_mfcc_plan_set_kernel", "dsp_butter_bandpass", "dsp_mfcc_tables", "dsp_mfcc_lane_tables", "dsp_prefilter_scan_check",
     "dsp_classify_batch_ragged_device_f64", "dsp_classify_batch_ragged_pcm16_device_f64", "dsp_classify_batch_ragged_host_f64", "dsp_classify_batch_ragged_pcm16_host_f64",
     "dsp_classify_batch_ragged_device", "dsp_classify_batch_ragged_pcm16_device", "dsp_classify_batch_ragged_host", "dsp_classify_batch_ragged_pcm16_host",
-    "dsp_scrubjay_fused_ragged_device", "dsp_scrubjay_fused_ragged_pcm16_device", "dsp_classify_signal_batch_ragged_device", "dsp_classify_signal_batch_ragged_pcm16_device",
+    "dsp_debug_fused_spans", "dsp_scrubjay_fused_ragged_device", "dsp_scrubjay_fused_ragged_pcm16_device", "dsp_classify_signal_batch_ragged_device", "dsp_classify_signal_batch_ragged_pcm16_device",
     "dsp_scrubjay_fused_device", "dsp_scrubjay_fused_pcm16_device", "dsp_classify_signal_batch_pcm16_device", "dsp_stop_model_create", "dsp_stop_model_destroy", "dsp_stop_predict_device", "dsp_classify_signal_batch_device",
     "dsp_classify_signal", "dsp_speaker_model_create", "dsp_speaker_model_destroy", "dsp_speaker_llr_device",
     "dsp_upsample_linear_device", "dsp_upsample_linear_host",
@@ -195,6 +195,7 @@ def load() -> C.CDLL:
     L.dsp_classify_batch_ragged_pcm16_device.argtypes = [vp, vp, C.c_long, lp, ip, ip, vp, vp]; L.dsp_classify_batch_ragged_pcm16_device.restype = ip
     L.dsp_classify_batch_ragged_host.argtypes = [vp, vp, C.c_long, lp, vp, vp]; L.dsp_classify_batch_ragged_host.restype = ip
     L.dsp_classify_batch_ragged_pcm16_host.argtypes = [vp, vp, C.c_long, lp, ip, ip, vp, vp]; L.dsp_classify_batch_ragged_pcm16_host.restype = ip
+    L.dsp_debug_fused_spans.argtypes = [cfgp, lp, C.c_long, ip, C.c_long, lp]; L.dsp_debug_fused_spans.restype = ip
     L.dsp_scrubjay_fused_ragged_device.argtypes = [vp, vp, vp, C.c_long, lp, ip, vp, vp, vp, vp, vp]; L.dsp_scrubjay_fused_ragged_device.restype = ip
     L.dsp_scrubjay_fused_ragged_pcm16_device.argtypes = [vp, vp, vp, C.c_long, lp, ip, ip, ip, vp, vp, vp, vp, vp]; L.dsp_scrubjay_fused_ragged_pcm16_device.restype = ip
     L.dsp_classify_signal_batch_ragged_device.argtypes = [vp, vp, vp, C.c_long, lp, vp, vp]; L.dsp_classify_signal_batch_ragged_device.restype = ip

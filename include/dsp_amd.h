@@ -402,6 +402,11 @@ int dsp_scrubjay_fused_ragged_pcm16_device(dsp_mfcc_plan *plan, dsp_svm *svm, co
                                            int channels, int stereo_mode, int max_frames, int *d_labels, float *d_decision,
                                            float *d_prob1, float *d_feat, void *stream);
 
+/* Test hook, host only (no GPU call): the order a ragged batch of the fused clip kernels runs in.  out4[4 * pos .. + 3] = start, samples,
+ * frames, caller's index of the clip at position pos; wavefront w of n_waves walks positions w, w + n_waves, ...  Returns the longest
+ * clip's frame count.                                                                                                                 */
+int dsp_debug_fused_spans(const dsp_mfcc_config *cfg, const long *offsets, long n_clips, int max_frames, long n_waves, long *out4);
+
 /* --- consumers of the MFCC matrix and the resampler (8f-4) ------- */
 
 /* The stop-word net behind classify_signal (2fa/audio/word/c/stop_detector.h:10,

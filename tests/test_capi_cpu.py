@@ -171,3 +171,41 @@ def test_gather_entry_points_reject_bad_arguments_and_fail_loudly_without_a_gpu(
         assert L.dsp_gather_create(devs, 2, C.byref(h)) == -2 and not h.value        # DSP_ENODEV
     assert L.dsp_gather_all(None, None, None, 4, None) < 0 and L.dsp_gather_n_devices(None) < 0
     L.dsp_gather_destroy(None)
+
+
+def test_ragged_batches_are_ordered_for_an_even_deal():
+    """dsp_debug_fused_spans (host only): every clip once, with the frames its own length gives, and -- wave w walking positions
+    w, w + n_waves, ... -- every wave's frame total within one clip of the mean; clips without a frame and offsets that run backwards
+    are refused by name."""
+    import ctypes as C
+    from dsp_amd import lib as L
+    lib = L.load()
+    cfg = L.MfccConfig()
+    lib.dsp_mfcc_default_config(C.byref(cfg))
+    rng = np.random.default_rng(11)
+    for n_clips, n_waves in ((1, 4), (7, 4), (1000, 64), (5000, 4096), (4097, 4096)):
+        lens = rng.integers(400, 48000, n_clips)
+        off = np.zeros(n_clips + 1, dtype=np.int64)
+        off[1:] = np.cumsum(lens)
+        c_off, _ = L.c_offsets(off)
+        out = (C.c_long * (4 * n_clips))()
+        tm = lib.dsp_debug_fused_spans(C.byref(cfg), c_off, n_clips, 500, n_waves, out)
+        spans = np.array(out[:], dtype=np.int64).reshape(n_clips, 4)
+        frames = np.minimum(1 + (lens - 400) // 160, 500)
+        assert tm == frames.max()
+        assert sorted(spans[:, 3].tolist()) == list(range(n_clips))
+        assert np.array_equal(spans[:, 0], off[spans[:, 3]]) and np.array_equal(spans[:, 1], lens[spans[:, 3]]) and np.array_equal(spans[:, 2], frames[spans[:, 3]])
+        per_wave = np.array([spans[w::n_waves, 2].sum() for w in range(min(n_waves, n_clips))])
+        if n_clips >= 2 * n_waves:
+            assert per_wave.max() - per_wave.min() <= frames.max(), (n_clips, n_waves, per_wave.max(), per_wave.min())
+    bad = np.array([0, 16000, 16399], dtype=np.int64)
+    c_bad, _ = L.c_offsets(bad)
+    out = (C.c_long * 8)()
+    assert lib.dsp_debug_fused_spans(C.byref(cfg), c_bad, 2, 500, 4, out) == -1 and b"clip 1" in lib.dsp_last_error()
+    back = np.array([0, 16000, 8000], dtype=np.int64)
+    c_back, _ = L.c_offsets(back)
+    assert lib.dsp_debug_fused_spans(C.byref(cfg), c_back, 2, 500, 4, out) == -1 and b"non-decreasing" in lib.dsp_last_error()
+    # the classifiers' ragged entry points refuse bad arguments before any GPU call
+    lab = (C.c_int * 2)()
+    assert lib.dsp_classify_batch_ragged_host(None, None, 2, c_back, lab, None) == -1
+    assert lib.dsp_classify_batch_ragged_host_f64(None, None, 2, c_back, lab, None) == -1
