@@ -601,24 +601,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // [wave] rows[8][RC_ROW_LD] doubles, then the twiddles
     double *rows_all = reinterpret_cast<double *>(smem);
     FftTwiddles &tw = *reinterpret_cast<FftTwiddles *>(smem + (size_t)4 * RC_FRAMES * RC_ROW_LD * sizeof(double));
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, half = lane >> 5, i = lane & 31;
+    // (wib through readfirstlane: the compiler must KNOW that a wave's item numbers are uniform, or the loop below is a divergent one)
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, i = lane & 31;
     double *rows = rows_all + (size_t)wib * RC_FRAMES * RC_ROW_LD;
     fill_twiddles(tw, tab, threadIdx.x);
     __syncthreads();
     FftLane L;
     fft_lane_init(L, tw, tab, i);
     const double U = tab->U;
-    const long total = MAPS ? (long)worklist[0] * T : (long)worklist[0];
+    const long n_entries = worklist[0];
+    const long total = MAPS ? n_entries * T : n_entries;
     const long wave = (long)blockIdx.x * 4 + wib, n_waves = (long)gridDim.x * 4;
     const int f = (lane >> 2) & (RC_FRAMES - 1), j = lane & 3;          // recompute role (lanes 0 .. 31): item f of the pass, quarter j
     const bool filters = lane < 4 * RC_FRAMES;
     if (wave * RC_FRAMES >= total) return;
-    // (clip, t) of work item `it`
-    auto item_of = [&](long it, long &clip, int &t) {
-        if (MAPS) { const long e = it / T; t = (int)(it - e * T); clip = worklist[1 + e]; if (spans) { const int tc = spans[clip].frames; t = t < tc ? t : tc - 1; } }
-        else { const long fr = worklist[1 + it]; clip = fr / T; t = (int)(fr - clip * T); }
+    // (clip, t) of item k of the pass that starts at item pass0.  MAPS: item = entry e * T + t, and (e0, t0) of a pass's first item is
+    // CARRIED from pass to pass (constant step, one carry): round 4's first form divided a 64-bit item number by T for every 16-byte
+    // piece it requested -- on the vector unit, because the wave number was not known to be uniform --, 21 emulated divisions per pass
+    // of eight segments: a quarter of this kernel's instructions with float64 input (16 pieces per lane), 1.31 ms against 1.02 ms from int16.
+    // Items past the end: the last one stands in (their results are not stored).
+    auto locate = [&](long pass0, long e0, int t0, int k, long &clip, int &t) {
+        if (MAPS) {
+            long e = e0;
+            t = t0 + k;
+            while (t >= T) { t -= T; ++e; }
+            if (e >= n_entries) { e = n_entries - 1; t = T - 1; }
+            clip = worklist[1 + e];
+            if (spans) { const int tc = spans[clip].frames; t = t < tc ? t : tc - 1; }
+        } else {
+            long it = pass0 + k;
+            it = it < total ? it : total - 1;
+            const int fr = worklist[1 + it];
+            const int c = fr / T;
+            clip = c; t = fr - c * T;
+        }
     };
     auto base_of = [&](long clip) { return spans ? spans[clip].off : clip * stride; };
+    const long pass_step = n_waves * RC_FRAMES;
+    const long step_e = MAPS ? pass_step / T : 0;                        // once per wave
+    const int step_t = MAPS ? (int)(pass_step - step_e * T) : 0;
+    long e_req = MAPS ? (wave * RC_FRAMES) / T : 0;                      // the pass being REQUESTED starts at entry e_req, column t_req
+    int t_req = MAPS ? (int)(wave * RC_FRAMES - e_req * T) : 0;
+    long e_cur = 0;                                                      // ... and the pass being worked on
+    int t_cur = 0;
     // A pass's input -- 16 segments of 256 samples as 16-byte pieces, coalesced (a segment is contiguous), and the restart state of
     // (item f, quarter j) -- is requested one pass AHEAD into registers: with one wave per SIMD (the rows fill the LDS) nothing else
     // hides the HBM latency, and four dependent load batches per pass were a quarter of this kernel's time.  Every load is
@@ -633,21 +658,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int u = 0; u < PER_LANE; ++u) {
                 const int pc = lane + 64 * u, k = pc / PIECES, piece = pc % PIECES;
-                long it = item0 + k;
-                it = it < total ? it : total - 1;
                 long clip; int t;
-                item_of(it, clip, t);
+                locate(item0, e_req, t_req, k, clip, t);
                 const long s0 = (long)t * kSpecHop + (long)piece * PP;
                 q[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(xin) + (base_of(clip) + s0) * In<IN>::kBytes));
             }
         }
-        long it = item0 + f;
-        it = it < total ? it : total - 1;
         long clip; int t;
-        item_of(it, clip, t);
+        locate(item0, e_req, t_req, f, clip, t);
         const d2 *src = reinterpret_cast<const d2 *>(ck + (((long)t * kCkPerSegF64 + j) * n_clips + clip) * 8);
 #pragma unroll
         for (int u = 0; u < 4; ++u) ckq[u] = src[u];
+        // the request's position becomes the working one; the next request lies one pass further
+        e_cur = e_req; t_cur = t_req;
+        e_req += step_e; t_req += step_t;
+        if (t_req >= T) { t_req -= T; ++e_req; }
     };
     request(wave * RC_FRAMES);
     for (long item0 = wave * RC_FRAMES; item0 < total; item0 += n_waves * RC_FRAMES) {
@@ -658,10 +683,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             double o[PP];
             if (vec_ok) piece_to_f64<IN>(q[u], o);
             else {
-                long it = item0 + k;
-                it = it < total ? it : total - 1;
                 long clip; int t;
-                item_of(it, clip, t);
+                locate(item0, e_cur, t_cur, k, clip, t);
                 const void *row = reinterpret_cast<const unsigned char *>(xin) + base_of(clip) * In<IN>::kBytes;
                 const long s0 = (long)t * kSpecHop + (long)piece * PP;
 #pragma unroll
@@ -677,6 +700,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int u = 0; u < 4; ++u) { d[2 * u] = ckq[u].x; d[2 * u + 1] = ckq[u].y; }
         // ---- the next pass's input on its way while this one is filtered and transformed ----
+        const long e_now = e_cur;                                        // (request() moves the working position on)
+        const int t_now = t_cur;
         request(item0 + n_waves * RC_FRAMES);
         wave_sync_lds();
         // ---- the filter over the quarter: classifier.c:427-441 per sample, y over x in place ----
@@ -752,7 +777,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     if (i == 0 && it < total && hi > 0) {
                         long clip; int t;
-                        item_of(it, clip, t);
+                        locate(item0, e_now, t_now, k, clip, t);
                         atomicMin(&minmax[2 * clip], (unsigned long long)__double_as_longlong(lo));
                         atomicMax(&minmax[2 * clip + 1], (unsigned long long)__double_as_longlong(hi));
                     }
