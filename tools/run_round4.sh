@@ -23,7 +23,7 @@ for l in open("$OUT/side_workloads.jsonl"):
 PY
 elif [ "$PART" == "b" ]; then
     ( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_frames -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/trace_frames.json 2> $OUT/trace_frames.err )
-    for w in classify classify_pcm16 classify_f64 classify_f64_pcm16; do
+    for w in classify classify_pcm16 classify_f64 classify_f64_pcm16 classify_ragged config5 config5_ragged config5_2048 stop; do
         ( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python3 $R/bench.py --workload $w --no-cpu-baseline --steps 20 > $OUT/trace_$w.json 2> $OUT/trace_$w.err )
     done
     find $OUT -name "*kernel_stats.csv" | while read f; do echo "== $f"; head -6 "$f" | cut -c1-160; done
