@@ -356,8 +356,9 @@ int dsp_mfcc_plan_create(const dsp_mfcc_config *cfg, int device, dsp_mfcc_plan *
     }
     p->n_cu = prop.multiProcessorCount;
     if (cfg->n_fft == 2048) {
-        p->resident_blocks_2048 = dsp::mfcc2048_blocks_per_cu(cfg->n_mels, false);
-        p->resident_blocks_2048_pool = dsp::mfcc2048_blocks_per_cu(cfg->n_mels, true);
+        const bool aub = cfg->spectrum != DSP_SPECTRUM_POWER || cfg->log_mode == DSP_LOG_LOG10_FLOOR || cfg->framing == DSP_FRAMING_STREAM;
+        p->resident_blocks_2048 = dsp::mfcc2048_blocks_per_cu(cfg->n_mels, false, aub);
+        p->resident_blocks_2048_pool = dsp::mfcc2048_blocks_per_cu(cfg->n_mels, true, aub);
     } else if (cfg->n_fft == 512) {
         p->resident_blocks_frame = dsp::mfcc512_blocks_per_cu(p->host.dct_split, p->host.dct_len, p->host.mel_gather,
                                                               cfg->frame_length == 512, false);

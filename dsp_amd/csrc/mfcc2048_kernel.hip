@@ -64,9 +64,13 @@ static_assert(Q_WAVE_BYTES % 16 == 0, "keep the carve 16-byte aligned");
 constexpr int Q_W1024 = 4 * Q_WAVE_BYTES;          // block-shared: W1024^i, i < 1024
 constexpr int Q_W2048 = Q_W1024 + 1024 * 8;        // block-shared: W2048^k, k < 512
 constexpr int Q_TW1 = Q_W2048 + 512 * 8;           // block-shared: pass 1's twiddles W_256^(t k) at [t - 1][k], t = 1 .. 15, k < 16
-constexpr int Q_WIN = Q_TW1 + 15 * 16 * 8;         // block-shared: window pairs (win[2a][l], win[2a+1][l]) at [a][l]
-constexpr int Q_DCT = Q_WIN + 16 * 64 * 8;         // block-shared: dct_t[i][lane], i < ceil(n_mels / 2)
-constexpr int Q_BLOCK_BYTES = Q_DCT;               // + 256 B per DCT row (+ POOL: 2 x 64 floats, the Scaler's offset | scale), added by the launcher
+constexpr int Q_SEGW = Q_TW1 + 15 * 16 * 8;        // block-shared, PRE kernels only: the mel segments' weights seg_w[c][i][lane] (12 KB; out of 48 VGPRs per lane)
+constexpr int Q_SEGW_BYTES = k2048SegSlots * k2048SegTaps * 64 * 4;
+// PRE (= the aubio-semantics kernels, 40 filters: 81.5 KB per block, two blocks per CU still fit; the 128-filter librosa plans would not):
+// the filterbank weights live in LDS and the registers they held carry the next frame's samples, requested one frame ahead
+__device__ __host__ constexpr int q_win(bool pre) { return Q_SEGW + (pre ? Q_SEGW_BYTES : 0); }      // block-shared: window pairs (win[2a][l], win[2a+1][l]) at [a][l]
+__device__ __host__ constexpr int q_dct(bool pre) { return q_win(pre) + 16 * 64 * 8; }                // block-shared: dct_t[i][lane], i < ceil(n_mels / 2)
+// + 256 B per DCT row (+ POOL: 2 x 64 floats, the Scaler's offset | scale), added by the launcher
 
 }  // namespace
 
@@ -120,9 +124,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     float2 *w1024 = reinterpret_cast<float2 *>(smem + Q_W1024);
     float2 *w2048 = reinterpret_cast<float2 *>(smem + Q_W2048);
     float *part = reinterpret_cast<float *>(wl + Q_PART);
-    float *dct_t = reinterpret_cast<float *>(smem + Q_DCT);
-    float2 *win2 = reinterpret_cast<float2 *>(smem + Q_WIN);
+    constexpr bool PRE = AUB;
+    float *dct_t = reinterpret_cast<float *>(smem + q_dct(PRE));
+    float2 *win2 = reinterpret_cast<float2 *>(smem + q_win(PRE));
     float2 *tw1 = reinterpret_cast<float2 *>(smem + Q_TW1);
+    float *segw = reinterpret_cast<float *>(smem + Q_SEGW);
     const int n_mels = args.n_mels, n_mfcc = args.n_mfcc;
     const int half = (n_mels + 1) / 2;                   // log-mels per DCT lane
     for (int i = threadIdx.x; i < 1024; i += 256) w1024[i] = make_float2(G->w1024[0][i], G->w1024[1][i]);
@@ -149,15 +155,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     // mel segments: this lane's three 16-bin windows and their weights stay in registers; filters lane and lane + 64 add
     // their partial sums [s0, s0 + cnt)
     const bool seg_ok = G->seg_ok != 0;
+    // The filterbank's weights used to ride in 48 registers per lane across the frame loop; they are read from a block-shared LDS copy
+    // now (conflict-free: consecutive lanes, consecutive words), and the registers carry the NEXT frame's samples instead (request_frame)
     int seg_k0[k2048SegSlots];
-    float seg_w[k2048SegSlots][k2048SegTaps];
+    float seg_w[PRE ? 1 : k2048SegSlots][PRE ? 1 : k2048SegTaps];      // !PRE: in registers, as before
     int mel_s0[2], mel_cnt[2];
 #pragma unroll
     for (int c = 0; c < k2048SegSlots; ++c) {
         seg_k0[c] = G->seg_k0[c][lane];
 #pragma unroll
-        for (int i = 0; i < k2048SegTaps; ++i) seg_w[c][i] = G->seg_w[c][i][lane];
+        for (int i = 0; i < k2048SegTaps; ++i) {
+            if constexpr (PRE) segw[(c * k2048SegTaps + i) * 64 + lane] = G->seg_w[c][i][lane];      // (every wave writes the same values; a wave reads what its own lanes wrote)
+            else seg_w[c][i] = G->seg_w[c][i][lane];
+        }
     }
+    (void)seg_w; (void)segw;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = lane + 64 * i;
@@ -183,10 +195,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     int pool_t = 0;
     (void)pool_s; (void)pool_q; (void)pool_t;
 
-    while (cur.valid()) {
-        const long f = cur.f, clip_f = cur.clip;
-        const bool last_of_chunk = cur.left == 0 || cur.remaining == 1;
-        (void)clip_f; (void)last_of_chunk;
+    // The frame's samples are requested ONE FRAME AHEAD, from the middle of the frame before it (behind the power spectrum, where the
+    // transform's 32 registers are free again): at the loop's top they stood, with the whole HBM latency, in front of every frame's
+    // first instruction -- a wave spent 35 % of its cycles in s_waitcnt (SQ_WAIT_ANY), most of it there, and two waves per SIMD do
+    // not cover that for each other.  raw[a] = samples 2 (lane + 64 a), + 1 of the frame, zero outside [lo_i, hi_i).
+    c32 raw[16];
+    auto request_frame = [&]() {         // the frame `cur` stands at (cur.valid())
         long src = cur.off;                                              // first sample of the frame (samples per channel from args.in)
         // samples [lo_i, hi_i) of the frame exist; the rest reads as zero.  Complete frames: [0, frame_len).
         int lo_i = 0, hi_i = frame_len;
@@ -198,10 +212,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             if constexpr (POOL) n_clip = cur.n_samples;
             hi_i = min(frame_len, n_clip - start);
         }
-        cur.next();
-
-        // ---- load + window: v[a] = z[lane + 64 a] --------------------------------------------------------------------
-        c32 v[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             const int i = 2 * (lane + 64 * a);
@@ -211,11 +221,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             } else if (i < hi_i && (!AUB || i >= lo_i)) {
                 x0 = load_one_2048<IN>(args.in, src + i);
             }
+            raw[a] = {x0, x1};
+        }
+    };
+    if constexpr (PRE) request_frame();
+
+    while (cur.valid()) {
+        const long f = cur.f, clip_f = cur.clip;
+        const bool last_of_chunk = cur.left == 0 || cur.remaining == 1;
+        (void)clip_f; (void)last_of_chunk;
+        if constexpr (!PRE) request_frame();                             // (registers are tight there: the samples are loaded where they are used)
+        cur.next();
+
+        // ---- window: v[a] = z[lane + 64 a] --------------------------------------------------------------------
+        c32 v[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
             if (WIN_LDS) {
                 const float2 w = win2[64 * a + lane];
-                v[a] = {x0 * w.x, x1 * w.y};
+                v[a] = {raw[a].x * w.x, raw[a].y * w.y};
             } else {
-                v[a] = {x0 * G->win[2 * a][lane], x1 * G->win[2 * a + 1][lane]};
+                v[a] = {raw[a].x * G->win[2 * a][lane], raw[a].y * G->win[2 * a + 1][lane]};
             }
         }
 
@@ -305,6 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
             pbuf[512] = magnitude ? __builtin_amdgcn_sqrtf(p512) : p512;
         }
         wave_lds_sync();
+        if constexpr (PRE) { if (cur.valid()) request_frame(); }         // the next frame's samples: in flight during mel, log, DCT and the clip's tail
 
         // ---- mel: lane m (and m + 64) walks filter m's run of weights in ascending bins (mfcc.c:158-164) --------------------
         float e[2] = {0.0f, 0.0f};
@@ -316,7 +343,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 const float *rd = pbuf + seg_k0[c];
                 float acc = 0.0f;
 #pragma unroll
-                for (int i = 0; i < k2048SegTaps; ++i) acc = fmaf(seg_w[c][i], rd[i], acc);
+                for (int i = 0; i < k2048SegTaps; ++i) {
+                    if constexpr (PRE) acc = fmaf(segw[(c * k2048SegTaps + i) * 64 + lane], rd[i], acc);
+                    else acc = fmaf(seg_w[c][i], rd[i], acc);
+                }
                 part[c * 64 + lane] = acc;
             }
             wave_lds_sync();
@@ -469,14 +499,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     }
 }
 
-static size_t lds_bytes_2048(int n_mels, bool pool) { return (size_t)Q_BLOCK_BYTES + (size_t)((n_mels + 1) / 2) * 256 + (pool ? 128 * 4 : 0); }
+static size_t lds_bytes_2048(int n_mels, bool pool, bool aub) { return (size_t)q_dct(aub) + (size_t)((n_mels + 1) / 2) * 256 + (pool ? 128 * 4 : 0); }
 
 hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables, int blocks, hipStream_t stream, bool pool)
 {
     const bool clips = args.frames_per_clip > 0;
     const dim3 g(blocks), b(256);
-    const size_t Q_BLOCK_BYTES = lds_bytes_2048(args.n_mels, pool);
     const bool aub = args.spectrum != 0 || args.log_mode == 2 || args.stream_framing != 0;
+    const size_t Q_BLOCK_BYTES = lds_bytes_2048(args.n_mels, pool, aub);
     if (args.stream_framing && (!clips || (args.samples_per_clip <= 0 && !(pool && args.spans)) || args.hop > args.frame_len)) return hipErrorInvalidConfiguration;      // (ragged: lengths in the spans)
     if (args.in_kind != 0 && (!aub || !clips || args.in_kind < 0 || args.in_kind > 3)) return hipErrorInvalidConfiguration;      // int16: the scrubjay_infer.c front end, clips
     if (pool) {
@@ -501,11 +531,14 @@ hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables,
     return hipGetLastError();
 }
 
-int mfcc2048_blocks_per_cu(int n_mels, bool pool)
+int mfcc2048_blocks_per_cu(int n_mels, bool pool, bool aub)
 {
     int n = 0;
-    hipError_t e = pool ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<true, true>, 256, lds_bytes_2048(n_mels, true))
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<false, false>, 256, lds_bytes_2048(n_mels, false));
+    hipError_t e;
+    if (aub) e = pool ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<true, true, true>, 256, lds_bytes_2048(n_mels, true, true))
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<false, false, true>, 256, lds_bytes_2048(n_mels, false, true));
+    else e = pool ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<true, true>, 256, lds_bytes_2048(n_mels, true, false))
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mfcc2048_kernel<false, false>, 256, lds_bytes_2048(n_mels, false, false));
     return e == hipSuccess && n > 0 ? n : 2;
 }
 

@@ -95,7 +95,7 @@ struct PairExtra512;
 hipError_t launch_mfcc512_pair(const Mfcc512Args &args, const PairExtra512 *extra, int blocks, hipStream_t stream);
 int mfcc512_pair_blocks_per_cu();
 hipError_t launch_mfcc2048(const Mfcc512Args &args, const GenTables2048 *tables, int blocks, hipStream_t stream, bool pool);
-int mfcc2048_blocks_per_cu(int n_mels, bool pool);
+int mfcc2048_blocks_per_cu(int n_mels, bool pool, bool aub = false);      // aub: the aubio-semantics kernels (spectrum / log10 / stream framing) and their LDS
 int mfcc512_blocks_per_cu(int dct_split, int dct_len, int gather, bool full, bool tile);
 
 }  // namespace dsp

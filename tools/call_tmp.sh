@@ -1,7 +1,5 @@
 set -u
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/round_r4f; mkdir -p $OUT
-for w in classify_ragged config5 config5_ragged config5_2048 stop; do
-    ( cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python3 $R/bench.py --workload $w --no-cpu-baseline --steps 20 > $OUT/trace_$w.json 2> $OUT/trace_$w.err )
-done
-bash tools/run_round4.sh r4f c 2>&1 | tail -14
-bash tools/run_round4.sh r4f d 2>&1 | tail -3
+mkdir -p gpurun_out/r4b
+timeout -k 10 900 python -m pytest tests/test_gpu_scrubjay.py tests/test_gpu_fused_pcm16.py tests/test_gpu_ragged.py tests/test_gpu_mfcc.py -x -q > gpurun_out/r4b/t2048b.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/r4b/t2048b.log | cut -c1-250
+for w in config5_2048 config5_2048; do python bench.py --workload $w --no-cpu-baseline --steps 50 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['metric'], d['value'], d['roofline']['kernel_ms'], d['roofline']['frac'])"; done
+python tools/sq_fractions.py r4g config5_2048 2>&1 | tail -1
