@@ -313,3 +313,19 @@ def test_classify_f64_ragged_on_the_donut_recordings(dsp, golden):
         for c, x in enumerate(files):
             l1, t1 = dsp.classify_batch_f64_pcm16(x[None], stereo_mode=dsp.STEREO_CHANNEL0, with_trace=True, config=cfg)
             assert labels[c] == l1[0] and _trace_equal_f64(trace[c], t1[0]), (names[c], cfg)
+
+
+def test_classify_f64_ragged_across_passes(dsp, monkeypatch):
+    """A ragged float64 batch that spans several passes through the workspace (DSP_AMD_F64_SUB_BATCH=128): the clips run in order of
+    length, pass by pass, and every label and trace record still lands at the caller's index."""
+    import torch
+    rng = np.random.default_rng(93)
+    clips = [x.astype(np.float64) for x in _classify_clips(rng, 300)]
+    flat, off = _pack(clips)
+    whole, trace = dsp.classify_ragged_f64(flat, off, with_trace=True)
+    monkeypatch.setenv("DSP_AMD_F64_SUB_BATCH", "128")
+    labels, tr2 = dsp.classify_ragged_f64(flat, off, with_trace=True)
+    dev = dsp.classify_device_ragged_f64(torch.from_numpy(flat).cuda(), off).cpu().numpy()
+    assert np.array_equal(labels, whole) and np.array_equal(dev, whole) and whole.sum() > 10
+    for a, b in zip(trace, tr2):
+        assert _trace_equal_f64(a, b)
