@@ -1,1 +1,2 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_ragged.py -x -q 2>&1 | tail -5
+python tools/sq_fractions.py r4h frames 2>&1 | tail -1
+python tools/sq_fractions.py r4h frames 2>&1 | tail -1
