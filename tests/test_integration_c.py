@@ -67,3 +67,44 @@ def test_c_caller_runs_and_matches_the_reference_golden(tmp_path, golden):
     assert f"{g['stop_pcm'].size} samples -> {ref.shape[0]} frames" in r.stdout
     frame0 = np.array([float(v) for v in r.stdout.split("frame 0:")[1].split()[:13]], np.float32)
     assert np.abs(frame0 - ref[0]).max() <= 1e-4 * np.abs(ref[0]).max() + 3e-4 + 5e-5      # printed with 4 decimals
+
+
+def _write_wav_ch(path, pcm):
+    pcm = np.ascontiguousarray(pcm, np.int16)
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1 if pcm.ndim == 1 else pcm.shape[1])
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.tobytes())
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="no gcc")
+def test_ragged_c_caller_links_against_the_library(tmp_path):
+    exe = _gcc(str(tmp_path / "main_files"), [os.path.join(ROOT, "examples", "main_files.c")], [os.path.join(ROOT, "include")])
+    import torch
+    if not torch.cuda.is_available():
+        wav = str(tmp_path / "a.wav")
+        _write_wav_ch(wav, np.zeros(4000, np.int16))
+        r = subprocess.run([exe, wav], capture_output=True, text=True)
+        assert r.returncode == 1 and "no HIP device" in r.stderr             # loud, no CPU fallback
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="no gcc")
+def test_ragged_c_caller_labels_the_donut_recordings_in_one_call(tmp_path, golden):
+    """examples/main_files.c: the donut classifier's own recordings (stereo int16, 0.15 - 3 s) as WAV files on one command line -> one
+    ragged call -> the reference's line per file, with the labels the compiled reference returned."""
+    g = golden("donut16k_ref.npz")
+    names = sorted({k.split("__")[0] for k in g.files})
+    files = []
+    for n in names:
+        files.append(str(tmp_path / (n + ".wav")))
+        _write_wav_ch(files[-1], g[n + "__pcm"])
+    exe = _gcc(str(tmp_path / "main_files"), [os.path.join(ROOT, "examples", "main_files.c")], [os.path.join(ROOT, "include")])
+    for flag in ([], ["-d"]):
+        r = subprocess.run([exe] + flag + files, capture_output=True, text=True, check=True)
+        lines = r.stdout.strip().splitlines()
+        assert len(lines) == len(names)
+        for n, line in zip(names, lines):
+            assert line.startswith(str(tmp_path / (n + ".wav")))
+            assert ("has a Scrub Jay" in line) == bool(int(g[n + "__label"])), (flag, line)
