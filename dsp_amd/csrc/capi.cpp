@@ -683,9 +683,9 @@ struct ClassifyCtx {
     int *d_simd = nullptr;                                 // iir2_ckpt_kernel's per-CU SIMD load table (launch_iir2_ckpt)
     int *d_gate = nullptr;                                 // work list of the segments whose energy does not rule a loud cell out (IIR kernel)
     dsp::ClassifyTrace *d_trace = nullptr;
-    long cap_clips = 0;
-    int cap_n = 0;
-    bool cap_x = false;
+    long cap_clips = 0;                                    // per-clip arrays (labels, hits, trace, minmax)
+    long cap_segs = 0;                                     // per-segment arrays: clips x segments per clip of the largest pass so far
+    long cap_x_floats = 0;                                 // staging buffer of the host entry points, in floats (0: none)
     float keep_min_db = 70.0f;                             // the midpoint threshold d_tab->mp_keep_min was computed for
     bool gate_ok = false;                                  // SpecTables::gate_ok of d_tab
     std::mutex mu;
@@ -784,7 +784,7 @@ void cls_free_workspace(ClassifyCtx &g_cls)
         if (p) hipFree(p);
     g_cls.d_x = g_cls.d_sbp = g_cls.d_ck_bp = g_cls.d_ck_mp = g_cls.d_mean_mp = nullptr;
     g_cls.d_labels = g_cls.d_hits = g_cls.d_loud = g_cls.d_gate = g_cls.d_simd = nullptr; g_cls.d_trace = nullptr; g_cls.d_minmax = nullptr;
-    g_cls.cap_clips = 0; g_cls.cap_n = 0; g_cls.cap_x = false;
+    g_cls.cap_clips = 0; g_cls.cap_segs = 0; g_cls.cap_x_floats = 0;
 }
 
 void cls_release(ClassifyCtx &g_cls)      // (on g_cls.device, made current by the caller)
@@ -799,29 +799,31 @@ void cls_release(ClassifyCtx &g_cls)      // (on g_cls.device, made current by t
     g_cls.device = -1;
 }
 
-// workspace of one sub-batch; need_x: also a staging buffer for the clips themselves (host entry points)
+// workspace of one sub-batch; need_x: also a staging buffer for the clips themselves (host entry points).  The per-segment arrays
+// are [clip][T(n)] with the pass's own T, so what a pass needs of them is its PRODUCT clips x T: a ragged batch's pass of few long
+// clips and its pass of many short ones share one allocation (sized by each dimension's maximum it would be their outer product --
+// 32 GB of maps for 65 536 clips of which one is 13 s long).
 int cls_reserve(ClassifyCtx &g_cls, long clips, int n, bool need_x)
 {
-    if (clips <= g_cls.cap_clips && n <= g_cls.cap_n && (!need_x || g_cls.cap_x)) return DSP_OK;
+    const long T = std::max(1, spec_bins(n));
+    const long x_floats = need_x ? clips * cls_row(n) : 0;
+    if (clips <= g_cls.cap_clips && clips * T <= g_cls.cap_segs && x_floats <= g_cls.cap_x_floats) return DSP_OK;
     g_cls.wait_idle();
-    need_x = need_x || g_cls.cap_x;
-    clips = std::max(clips, g_cls.cap_clips);
-    n = std::max(n, g_cls.cap_n);
+    const long rows = std::max(clips, g_cls.cap_clips), segs = std::max(clips * T, g_cls.cap_segs), xf = std::max(x_floats, g_cls.cap_x_floats);
     cls_free_workspace(g_cls);
-    const size_t T = (size_t)std::max(1, spec_bins(n));
-    if (need_x) DSP_HIP(hipMalloc(&g_cls.d_x, (size_t)clips * cls_row(n) * sizeof(float)));      // (staged int16 rows are at most as long)
-    DSP_HIP(hipMalloc(&g_cls.d_sbp, (size_t)clips * dsp::kSpecBins * T * sizeof(float)));
-    DSP_HIP(hipMalloc(&g_cls.d_ck_bp, (size_t)clips * T * dsp::kCkPerSegBp * 8 * sizeof(float)));
-    DSP_HIP(hipMalloc(&g_cls.d_ck_mp, (size_t)clips * T * dsp::kCkPerSegMp * 8 * sizeof(float)));
-    DSP_HIP(hipMalloc(&g_cls.d_loud, (size_t)clips * T * sizeof(int)));
-    DSP_HIP(hipMalloc(&g_cls.d_minmax, (size_t)clips * 2 * sizeof(unsigned)));
+    if (xf > 0) DSP_HIP(hipMalloc(&g_cls.d_x, (size_t)xf * sizeof(float)));      // (staged int16 rows are at most as long)
+    DSP_HIP(hipMalloc(&g_cls.d_sbp, (size_t)segs * dsp::kSpecBins * sizeof(float)));
+    DSP_HIP(hipMalloc(&g_cls.d_ck_bp, (size_t)segs * dsp::kCkPerSegBp * 8 * sizeof(float)));
+    DSP_HIP(hipMalloc(&g_cls.d_ck_mp, (size_t)segs * dsp::kCkPerSegMp * 8 * sizeof(float)));
+    DSP_HIP(hipMalloc(&g_cls.d_loud, (size_t)segs * sizeof(int)));
+    DSP_HIP(hipMalloc(&g_cls.d_minmax, (size_t)rows * 2 * sizeof(unsigned)));
     DSP_HIP(hipMalloc(&g_cls.d_simd, sizeof(int) * dsp::kSimdLoadCus * dsp::kSimdLoadStride));
-    DSP_HIP(hipMalloc(&g_cls.d_gate, ((size_t)clips * T + 1) * sizeof(int)));      // work list of gated-in frames: count + frame numbers
-    DSP_HIP(hipMalloc(&g_cls.d_mean_mp, (size_t)clips * T * sizeof(float)));
-    DSP_HIP(hipMalloc(&g_cls.d_labels, (size_t)clips * sizeof(int)));
-    DSP_HIP(hipMalloc(&g_cls.d_hits, (size_t)(clips + 1) * sizeof(int)));
-    DSP_HIP(hipMalloc(&g_cls.d_trace, (size_t)clips * sizeof(dsp::ClassifyTrace)));
-    g_cls.cap_clips = clips; g_cls.cap_n = n; g_cls.cap_x = need_x;
+    DSP_HIP(hipMalloc(&g_cls.d_gate, ((size_t)segs + 1) * sizeof(int)));      // work list of gated-in frames: count + frame numbers
+    DSP_HIP(hipMalloc(&g_cls.d_mean_mp, (size_t)segs * sizeof(float)));
+    DSP_HIP(hipMalloc(&g_cls.d_labels, (size_t)rows * sizeof(int)));
+    DSP_HIP(hipMalloc(&g_cls.d_hits, (size_t)(rows + 1) * sizeof(int)));
+    DSP_HIP(hipMalloc(&g_cls.d_trace, (size_t)rows * sizeof(dsp::ClassifyTrace)));
+    g_cls.cap_clips = rows; g_cls.cap_segs = segs; g_cls.cap_x_floats = xf;
     return DSP_OK;
 }
 
@@ -1171,7 +1173,6 @@ int cls_ragged(const dsp_classify_config *cfgp, const void *d_signal, int device
         if (trace) std::memset(trace, 0, (size_t)n_clips * sizeof(dsp_classify_trace));
         return DSP_OK;
     }
-    if ((rc = cls_reserve(g_cls, std::min(kClsSubBatch, n_clips), n_max, false)) < 0) return rc;
     // The clips run in order of length, longest first: the kernels take 64 clips per block and walk to the block's longest, so a block of
     // alike clips wastes nothing (measured on clips of 0.5 - 1.5 s in the caller's order: +54 % over the same samples in equal clips).
     // order[i] = the caller's index of the i-th clip as run; results go home through it (launch_scatter_records / on the host).
@@ -1193,12 +1194,27 @@ int cls_ragged(const dsp_classify_config *cfgp, const void *d_signal, int device
     const int *d_perm = reinterpret_cast<const int *>(static_cast<const char *>(slot->d) + span_bytes);
     std::vector<int> h_labels;
     std::vector<dsp::ClassifyTrace> h_trace;
+    // Passes: as many clips as a pass of equal 1 s clips has SEGMENTS for (the workspaces are [clip][segments of the pass's longest clip]):
+    // few clips per pass while they are long, the full 65 536 once they are short
+    // (four times that before a pass is cut short: a small remainder pass costs a whole clip's sequential chain for few clips -- 0.5 - 1.5 s
+    // clips in two passes measured 3.6 ms against 3.1 ms in one; the bound is there for batches with very long clips, ~11 GB of workspace)
+    constexpr long kPassSegs = 4 * kClsSubBatch * 71;
+    struct Pass { long c0, cnt; int n_row; };
+    std::vector<Pass> passes;
+    for (long c0 = 0; c0 < n_clips;) {
+        const int t_row = std::max(1, h[c0].frames);                            // sorted: the pass's longest clip comes first
+        const long cnt = std::min({kClsSubBatch, n_clips - c0, std::max(64L, kPassSegs / t_row)});
+        passes.push_back(Pass{c0, cnt, (t_row - 1) * dsp::kSpecHop + dsp::kSpecSeg});
+        c0 += cnt;
+    }
+    for (const Pass &ps : passes)
+        if ((rc = cls_reserve(g_cls, ps.cnt, ps.n_row, false)) < 0) { dsp::SpanRing::mark(slot, st); return rc; }
     struct SlotMark { dsp::SpanRing::Slot *s; hipStream_t st; ~SlotMark() { dsp::SpanRing::mark(s, st); } } slot_mark{slot, st};
     ClsBusyMark mark{g_cls, st};
     const dsp::ClipSpan *d_spans = static_cast<const dsp::ClipSpan *>(slot->d);
-    for (long c0 = 0; c0 < n_clips; c0 += kClsSubBatch) {
-        const long cnt = std::min(kClsSubBatch, n_clips - c0);
-        if ((rc = cls_run(g_cls, cfg, d_signal, in, cnt, n_max, 0, st, trace != nullptr, d_spans + c0, offsets[n_clips])) < 0) return rc;
+    for (const Pass &ps : passes) {
+        const long c0 = ps.c0, cnt = ps.cnt;
+        if ((rc = cls_run(g_cls, cfg, d_signal, in, cnt, ps.n_row, 0, st, trace != nullptr, d_spans + c0, offsets[n_clips])) < 0) return rc;
         if (d_labels) DSP_HIP(dsp::launch_scatter_records(g_cls.d_labels, d_perm + c0, cnt, sizeof(int), d_labels, st));
         if (labels) {
             h_labels.resize((size_t)cnt);

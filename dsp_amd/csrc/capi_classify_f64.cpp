@@ -53,12 +53,12 @@ struct Scratch {
     unsigned long long *minmax = nullptr;  // [clip][2]: smallest / largest positive cell of a listed clip's map (double bits)
     int *cu_table = nullptr;               // launch_iir2_screen_f64's per-CU arrival counters
     double U = 0.0;
-    // per pass of `cap_clips` clips with `cap_T` columns
+    // per pass: `cap_clips` clips, `cap_cells` = clips x columns of the largest pass
     double *ck_bp = nullptr, *ck_mp = nullptr, *s_bp = nullptr, *mids = nullptr;
     int *labels = nullptr, *loud = nullptr, *want = nullptr, *n_mids = nullptr, *hits = nullptr;
     dsp::ClassifyTraceD *trace = nullptr;
     long cap_clips = 0;
-    int cap_T = 0;
+    size_t cap_cells = 0;
     // staging of host input (bytes) and the yardstick pipelines' filtered signals (doubles per row)
     void *x = nullptr;
     size_t cap_x = 0;
@@ -76,7 +76,7 @@ struct Scratch {
             if (p) (void)hipFree(p);
         minmax = nullptr;
         ck_bp = ck_mp = s_bp = mids = nullptr; labels = loud = want = n_mids = hits = nullptr; trace = nullptr;
-        cap_clips = 0; cap_T = 0;
+        cap_clips = 0; cap_cells = 0;
     }
     void free_yardstick()
     {
@@ -186,24 +186,27 @@ int reserve(Scratch &w, int device, Pipeline pl, long clips, int n, size_t x_byt
         DSP_CAPI_HIP(hipMemcpy(w.scr, s.get(), sizeof(*s), hipMemcpyHostToDevice));
         w.U = t->U;
     }
-    if (clips > w.cap_clips || (int)T > w.cap_T) {
+    // (the per-segment arrays are sized by the PRODUCT clips x T of the largest pass: a ragged batch's pass of few long clips and its
+    // pass of many short ones share them; by each dimension's maximum a single 13 s clip among 49 152 would ask for 72 GB)
+    const size_t cells_needed = (size_t)clips * std::max<size_t>(T, 1);
+    if (clips > w.cap_clips || cells_needed > w.cap_cells) {
         w.wait_idle();
         clips = std::max(clips, w.cap_clips);
-        const size_t TT = std::max(T, (size_t)w.cap_T);
+        const size_t cells = std::max(cells_needed, w.cap_cells);
         w.free_pass();
-        const size_t ck = (size_t)clips * TT * dsp::kCkPerSegF64 * 8 * sizeof(double);
+        const size_t ck = cells * dsp::kCkPerSegF64 * 8 * sizeof(double);
         DSP_CAPI_HIP(hipMalloc(&w.ck_bp, ck));
         DSP_CAPI_HIP(hipMalloc(&w.ck_mp, ck));
-        DSP_CAPI_HIP(hipMalloc(&w.s_bp, (size_t)clips * dsp::kSpecBins * TT * sizeof(double)));
+        DSP_CAPI_HIP(hipMalloc(&w.s_bp, cells * dsp::kSpecBins * sizeof(double)));
         DSP_CAPI_HIP(hipMalloc(&w.mids, (size_t)clips * dsp::kMaxMidpoints * sizeof(double)));
-        DSP_CAPI_HIP(hipMalloc(&w.loud, (size_t)clips * TT * sizeof(int)));
-        DSP_CAPI_HIP(hipMalloc(&w.want, ((size_t)clips * TT + 1) * sizeof(int)));
+        DSP_CAPI_HIP(hipMalloc(&w.loud, cells * sizeof(int)));
+        DSP_CAPI_HIP(hipMalloc(&w.want, (cells + 1) * sizeof(int)));
         DSP_CAPI_HIP(hipMalloc(&w.n_mids, (size_t)clips * sizeof(int)));
         DSP_CAPI_HIP(hipMalloc(&w.hits, ((size_t)clips + 1) * sizeof(int)));
         DSP_CAPI_HIP(hipMalloc(&w.labels, (size_t)clips * sizeof(int)));
         DSP_CAPI_HIP(hipMalloc(&w.trace, (size_t)clips * sizeof(dsp::ClassifyTraceD)));
         DSP_CAPI_HIP(hipMalloc(&w.minmax, (size_t)clips * 2 * sizeof(unsigned long long)));
-        w.cap_clips = clips; w.cap_T = (int)TT;
+        w.cap_clips = clips; w.cap_cells = cells;
     }
     if (x_bytes > w.cap_x) {
         w.wait_idle();
@@ -361,8 +364,7 @@ int ragged(const dsp_classify_config_f64 *cfgp, const void *d_signal, int device
     Scratch &w = g_w[device];
     std::lock_guard<std::mutex> lock(w.mu);
     const long kSubBatch = sub_batch(kCkpt);
-    int rc = reserve(w, device, kCkpt, std::min(kSubBatch, n_clips), n_max, 0);
-    if (rc < 0) return rc;
+    int rc = DSP_OK;
     // in order of length, longest first (a block's 64 clips alike: it walks to its longest); order[i] = the caller's index of the i-th
     // clip as run, the results go home through it
     if (n_clips >= (1L << 31)) return dsp::capi_fail(DSP_EINVAL, "too many clips");
@@ -387,9 +389,22 @@ int ragged(const dsp_classify_config_f64 *cfgp, const void *d_signal, int device
     BusyMark mark{w, st};
     const dsp::ClipSpan *d_spans = static_cast<const dsp::ClipSpan *>(slot->d);
     const bool want_trace = d_trace != nullptr || trace != nullptr;
-    for (long c0 = 0; c0 < n_clips; c0 += kSubBatch) {
-        const long cnt = std::min(kSubBatch, n_clips - c0);
-        if ((rc = run(cfg, w, kCkpt, d_signal, in, cnt, n_max, 0, want_trace, st, d_spans + c0, offsets[n_clips])) < 0) return rc;
+    // passes: as many clips as a pass of equal 1 s clips has segments for (few while the clips are long, the full pass once they are short)
+    // (four times that before a pass is cut short: a small remainder pass costs a whole clip's sequential chain for few clips)
+    const long pass_cells = 4 * kSubBatch * 71;
+    struct Pass { long c0, cnt; int n_row; };
+    std::vector<Pass> passes;
+    for (long c0 = 0; c0 < n_clips;) {
+        const int t_row = std::max(1, h[c0].frames);                            // sorted: the pass's longest clip comes first
+        const long cnt = std::min({kSubBatch, n_clips - c0, std::max(64L, pass_cells / t_row)});
+        passes.push_back(Pass{c0, cnt, (t_row - 1) * dsp::kSpecHop + dsp::kSpecSeg});
+        c0 += cnt;
+    }
+    for (const Pass &ps : passes)
+        if ((rc = reserve(w, device, kCkpt, ps.cnt, ps.n_row, 0)) < 0) return rc;
+    for (const Pass &ps : passes) {
+        const long c0 = ps.c0, cnt = ps.cnt;
+        if ((rc = run(cfg, w, kCkpt, d_signal, in, cnt, ps.n_row, 0, want_trace, st, d_spans + c0, offsets[n_clips])) < 0) return rc;
         if (d_labels) DSP_CAPI_HIP(dsp::launch_scatter_records(w.labels, d_perm + c0, cnt, sizeof(int), d_labels, st));
         if (d_trace) DSP_CAPI_HIP(dsp::launch_scatter_records(w.trace, d_perm + c0, cnt, sizeof(dsp_classify_trace_f64), d_trace, st));
         if (labels) {
