@@ -260,6 +260,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
     """Secondary measurements (not the headline metric): same timing protocol, its own JSON line."""
     gen = torch.Generator(device=dev).manual_seed(2000 + rank)
     side_finish = None                 # drains a pipelined gather at the end of a region (config 5 at N > 1)
+    settle_step = None                 # the step without its collective: the settle loop runs for a TIME, so ranks do different counts of it
     if args.workload == "pcm16":
         n = args.clips or 1_000_000
         pcm = torch.randint(-32768, 32768, (n, FRAME), dtype=torch.int16, device=dev, generator=gen)
@@ -293,6 +294,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
                 block[:, 1].copy_(p1.view(torch.int32))
             lab_pipe.submit(compute)
         side_finish = lab_pipe.drain if lab_pipe is not None else None
+        settle_step = lambda: sj(clips, 500, fused=True)       # noqa: E731  (a gather in the time-based settle loop would hang: unequal counts)
         units, unit, bytes_per = n, "clips/s", 64_000 + 8      # label + probability out
         what = (f"BASELINE configs[4] per-GPU share ({n} clips): 1 s 16 kHz fp32 clip -> MFCC(20) -> mean|std -> Scaler -> RBF-SVM "
                 "(scrubjay_svm.onnx attributes) fused in ONE kernel, one wavefront per clip; the MFCC matrix never reaches HBM"
@@ -426,7 +428,7 @@ def side_workload(args, torch, dist, dsp_amd, dev, local, rank, world):
                 "(2 x IIR, 2 x spectrogram, rule), bit-exact with the reference")
         kernel = "iir2_ckpt_kernel + spec_from_ckpt_kernel<flags> + classify_midpoints_kernel + spec_from_ckpt_kernel<[time][bin]> + classify_bands_kernel"
     sens = open_sensors(local)
-    settle(step, torch, args.settle)
+    settle(settle_step or step, torch, args.settle)
     for _ in range(max(1, args.warmup // 4)):
         step()
     if side_finish:
