@@ -24,7 +24,7 @@ int stop_fused_device(dsp_mfcc_plan *plan, const StopModelDev &m, const void *d_
 int plan_device(const dsp_mfcc_plan *plan);          // the GPU a plan lives on
 }
 
-// Ragged batches: the clips' spans (mfcc_kernels.hpp ClipSpan: start, samples, frames -- 16 bytes per clip) travel to the GPU through a
+// Ragged batches: the clips' spans (clip_span.hpp ClipSpan: start, samples, frames, caller's index -- 32 bytes per clip) travel to the GPU through a
 // small ring of pinned host / device buffer pairs, so that a call neither waits for the stream it enqueues on nor shares a buffer with
 // the call before it (which may still be running, on this stream or another).  A slot is reused only after the event recorded behind
 // the kernels that read it.
